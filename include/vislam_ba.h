@@ -1,0 +1,136 @@
+/*
+ * vislam_ba.h -- C ABI of the MI355X local bundle-adjustment backend.
+ *
+ * Drop-in boundary.  The reference (mc275/MC_SLAM) has no FFI layer; the boundary
+ * is the point where its host code hands a freshly built factor graph to g2o:
+ *
+ *     optimizer.initializeOptimization(); optimizer.optimize(5); ... optimizer.optimize(10);
+ *       src/Optimizer.cpp:458-493   (Optimizer::LocalBAPRVIDP,            variant 2)
+ *       src/Optimizer.cpp:1259-1317 (Optimizer::LocalBundleAdjustmentNavStatePRV, variant 1)
+ *       src/Optimizer.cpp:4093-4143 (Optimizer::LocalBundleAdjustment,    variant 0)
+ *
+ * Everything g2o does between those lines (active-set construction, residuals + analytic Jacobians,
+ * Huber weighting, H/b assembly, Schur complement, reduced solve, back-substitution, manifold update,
+ * GN / LM control flow, the two-stage outlier protocol) happens behind vba_solve().  The host keeps graph
+ * extraction (src/Optimizer.cpp:49-451) and write-back (:496-623).
+ *
+ * Plain C: flat caller-owned arrays, f64 + i32, no C++ / torch types across the line.
+ */
+#ifndef VISLAM_BA_H
+#define VISLAM_BA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBA_VARIANT_SE3_XYZ 0 /* VertexSE3Expmap + VertexSBAPointXYZ + EdgeSE3ProjectXYZ (types_six_dof_expmap.h:80) */
+#define VBA_VARIANT_PRV_XYZ 1 /* VertexNavStatePR/V/Bias + XYZ + EdgeNavStatePRPointXYZ (g2otypes.h:255)          */
+#define VBA_VARIANT_PRV_IDP 2 /* VertexNavStatePR/V/Bias + VertexIDP + EdgePRIDP (g2otypes.h:22,65)                */
+
+#define VBA_ALGO_GN 0 /* OptimizationAlgorithmGaussNewton with the |dchi2|<1e-3 stop (gauss_newton.cpp:97) */
+#define VBA_ALGO_LM 1 /* OptimizationAlgorithmLevenberg, g2o lambda/rho schedule (levenberg.cpp:61-164)    */
+
+#define VBA_IMU_MEAS_STRIDE 61 /* dt, dP(3), dV(3), dR(9 row-major), JPg, JPa, JVg, JVa, JRg (9 each, row-major) */
+#define VBA_TRACE_MAX 64
+
+/* status values of vba_result.status */
+#define VBA_OK 0
+#define VBA_ABORTED_AFTER_STAGE1 1 /* stop flag seen after optimize(5): src/Optimizer.cpp:464-470 */
+#define VBA_ABORTED_BEFORE 2       /* stop flag set on entry: src/Optimizer.cpp:453-455, nothing touched */
+#define VBA_SOLVER_FAILED (-2)     /* reduced system not positive definite (linear_solver_eigen.h:105-111 -> Fail) */
+
+typedef struct vba_problem {
+    int32_t variant;          /* VBA_VARIANT_* */
+    int32_t n_kf, n_kf_free;  /* free keyframes first (hessian order = caller order), fixed after */
+    int32_t n_pt, n_obs, n_imu;
+    /* keyframe state, updated IN PLACE for the free entries.
+     * variant 0: T_cw as SE3Quat  (tx ty tz qx qy qz qw)          se3quat.h:40-47
+     * variant 1,2: NavState P, R  (px py pz qx qy qz qw) = T_wb   src/IMU/NavState.h:124-138 */
+    double *kf_pose;          /* [n_kf][7] */
+    double *kf_vel;           /* [n_kf][3]  (variants 1,2; only KFs touched by IMU edges are read) */
+    double *kf_bias;          /* [n_kf][12] bg(3) ba(3) dbg(3) dba(3); only dbg,dba are optimised */
+    /* landmarks, updated IN PLACE.  variant 0,1: world xyz.  variant 2: rho, xbar, ybar (rho updated;
+     * xbar,ybar = normalised ref-KF pixel, src/Optimizer.cpp:382-385) */
+    double *pt;               /* [n_pt][3] */
+    const int32_t *pt_ref_kf; /* [n_pt] variant 2: reference keyframe index (may be a fixed KF) */
+    const int32_t *pt_obs_begin; /* [n_pt+1] CSR: observations of point p are [begin[p], begin[p+1]) */
+    const int32_t *obs_kf;    /* [n_obs] observing keyframe (variant 2: never the reference KF, :395-398) */
+    const double *obs_uv;     /* [n_obs][2] undistorted pixel (kpUn.pt) */
+    const double *obs_w;      /* [n_obs] invSigma2 of the keypoint octave (information = w * I2) */
+    double K[4];              /* fx fy cx cy */
+    double T_cb[7];           /* camera<-body extrinsic, t_cb(3) q_cb(4) (variants 1,2; ConfigParam::GetEigT_cb) */
+    double g_w[3];            /* gravity in world (variants 1,2) */
+    const int32_t *imu_kf_i;  /* [n_imu] keyframe i (previous) */
+    const int32_t *imu_kf_j;  /* [n_imu] keyframe j (owner of the preintegrator, pKF1) */
+    const double *imu_meas;   /* [n_imu][VBA_IMU_MEAS_STRIDE] */
+    const double *imu_info_prv; /* [n_imu][81] row-major information of EdgeNavStatePRV in P,phi,V order
+                                 * (= inverse of the V/phi-swapped covariance, src/Optimizer.cpp:273-280) */
+    double inv_bg_rw2, inv_ba_rw2; /* 1/IMUData::getGyrBiasRW2(), 1/getAccBiasRW2(); bias info = diag/dt (:244-249,302) */
+    double huber_vis, huber_prv, huber_bias; /* Huber deltas (float-rounded sqrt(5.991), sqrt(2166.6), sqrt(1681.2)) */
+    int32_t algo;             /* VBA_ALGO_* */
+    int32_t its_stage1, its_stage2; /* 5, 10 */
+    double chi2_th;           /* 5.991 */
+    double depth_min;         /* isDepthPositive threshold: 0.01 (EdgePRIDP, g2otypes.h:122-127) or 0.0 */
+    double rho_min;           /* 2e-6 (variant 2 outlier gate, src/Optimizer.cpp:484) */
+} vba_problem;
+
+typedef struct vba_result {
+    double chi2_vis;   /* sum e'We over level-0 vision edges at the final estimates (N3 in SURVEY 8a) */
+    double chi2_prv;   /* same for EdgeNavStatePRV */
+    double chi2_bias;  /* same for EdgeNavStateBias */
+    int32_t its_done[2];  /* outer iterations executed by optimize(5) / optimize(10) (cjIterations) */
+    int32_t n_outliers;   /* number of set entries of obs_outlier */
+    int32_t status;       /* VBA_OK / VBA_ABORTED_* / VBA_SOLVER_FAILED */
+    uint8_t *obs_outlier; /* [n_obs] caller-allocated or NULL: 1 = host must erase (src/Optimizer.cpp:509-514) */
+    double *obs_chi2;     /* [n_obs] caller-allocated or NULL: e->chi2() as the reference's erase loop reads it */
+    int32_t n_trace;      /* entries of chi2_trace */
+    double chi2_trace[VBA_TRACE_MAX]; /* activeRobustChi2 after every accepted/terminating evaluation (diagnostic) */
+    double lambda_final;  /* LM only */
+} vba_result;
+
+/* Per-kernel-class device time of the last vba_batch_run, measured with HIP events on the backend's
+ * own stream (only filled when profiling is enabled with vba_set_profile). */
+#define VBA_PROF_LINEARIZE 0
+#define VBA_PROF_CONTROL 1
+#define VBA_PROF_SCHUR 2
+#define VBA_PROF_FACTOR 3
+#define VBA_PROF_TRSV 4
+#define VBA_PROF_UPDATE 5
+#define VBA_PROF_MISC 6
+#define VBA_PROF_N 8
+typedef struct vba_profile {
+    double ms[VBA_PROF_N];       /* summed device time per class */
+    int64_t launches[VBA_PROF_N];
+    double bytes[VBA_PROF_N];    /* algorithmic bytes moved per class (SURVEY 8d accounting) */
+    double total_ms;             /* first launch -> last launch of the run */
+} vba_profile;
+
+/* One handle per host thread / GPU; owns device buffers and a stream.  Errors: nonzero return, message
+ * via vba_last_error.  Never throws, never aborts. */
+int vba_create(int device, void **handle);
+int vba_destroy(void *handle);
+const char *vba_last_error(void *handle);
+
+/* Replaces optimizer.initializeOptimization(); optimize(its_stage1); <outlier pass>; optimize(its_stage2)
+ * (src/Optimizer.cpp:458-493 / 4093-4143).  stop_flag (may be NULL) plays g2o's forceStopFlag
+ * (sparse_optimizer.h:188): polled before the solve, between outer iterations and between the stages. */
+int vba_solve(void *handle, vba_problem *inout, vba_result *out, const volatile int *stop_flag);
+
+/* Batched / device-resident form: independent windows solved in lock-step on one GPU.
+ * upload = H2D + structure build (g2o buildStructure, block_solver.hpp:143-295);
+ * run    = the whole two-stage solve from the uploaded initial state, everything HBM-resident;
+ * download = D2H of states and per-edge results into the caller's arrays.
+ * run may be repeated (each run restarts from the uploaded state). */
+int vba_batch_upload(void *handle, int32_t n_windows, vba_problem *const *problems);
+int vba_batch_run(void *handle, const volatile int *stop_flag);
+int vba_batch_download(void *handle, int32_t n_windows, vba_problem *const *inout, vba_result *const *out);
+
+int vba_set_profile(void *handle, int32_t enable);
+int vba_get_profile(void *handle, vba_profile *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISLAM_BA_H */

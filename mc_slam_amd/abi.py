@@ -1,0 +1,194 @@
+"""ctypes mirror of include/vislam_ba.h (the C-ABI of the local-BA backend).
+
+`Problem` keeps the caller-owned arrays of one local-BA window as numpy arrays (the layout the host
+facade hands over after graph extraction, src/Optimizer.cpp:49-451 of the reference) and exposes them as
+a `vba_problem` struct without copying.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+VARIANT_SE3_XYZ, VARIANT_PRV_XYZ, VARIANT_PRV_IDP = 0, 1, 2
+ALGO_GN, ALGO_LM = 0, 1
+IMU_MEAS_STRIDE = 61
+TRACE_MAX = 64
+PROF_N = 8
+PROF_NAMES = ["linearize", "control", "schur", "factor", "trsv", "update", "misc", "_"]
+
+# float-rounded Huber deltas exactly as the reference builds them (const float th = sqrt(...)):
+# src/Optimizer.cpp:241-242, 327
+HUBER_VIS = float(np.float32(np.sqrt(5.991)))
+HUBER_PRV = float(np.float32(np.sqrt(100 * 21.666)))
+HUBER_BIAS = float(np.float32(np.sqrt(100 * 16.812)))
+# src/IMU/imudata.cpp:25-31
+GYR_BIAS_RW2 = 2.0e-5 * 2.0e-5
+ACC_BIAS_RW2 = 5.0e-3 * 5.0e-3
+GYR_MEAS_COV = 1.7e-4 * 1.7e-4 / 0.005
+ACC_MEAS_COV = 2.0e-3 * 2.0e-3 / 0.005 * 100
+
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+_pu8 = C.POINTER(C.c_uint8)
+
+
+class vba_problem(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("n_kf", C.c_int32), ("n_kf_free", C.c_int32),
+        ("n_pt", C.c_int32), ("n_obs", C.c_int32), ("n_imu", C.c_int32),
+        ("kf_pose", _pd), ("kf_vel", _pd), ("kf_bias", _pd), ("pt", _pd),
+        ("pt_ref_kf", _pi), ("pt_obs_begin", _pi), ("obs_kf", _pi),
+        ("obs_uv", _pd), ("obs_w", _pd),
+        ("K", C.c_double * 4), ("T_cb", C.c_double * 7), ("g_w", C.c_double * 3),
+        ("imu_kf_i", _pi), ("imu_kf_j", _pi), ("imu_meas", _pd), ("imu_info_prv", _pd),
+        ("inv_bg_rw2", C.c_double), ("inv_ba_rw2", C.c_double),
+        ("huber_vis", C.c_double), ("huber_prv", C.c_double), ("huber_bias", C.c_double),
+        ("algo", C.c_int32), ("its_stage1", C.c_int32), ("its_stage2", C.c_int32),
+        ("chi2_th", C.c_double), ("depth_min", C.c_double), ("rho_min", C.c_double),
+    ]
+
+
+class vba_result(C.Structure):
+    _fields_ = [
+        ("chi2_vis", C.c_double), ("chi2_prv", C.c_double), ("chi2_bias", C.c_double),
+        ("its_done", C.c_int32 * 2), ("n_outliers", C.c_int32), ("status", C.c_int32),
+        ("obs_outlier", _pu8), ("obs_chi2", _pd),
+        ("n_trace", C.c_int32), ("chi2_trace", C.c_double * TRACE_MAX),
+        ("lambda_final", C.c_double),
+    ]
+
+
+class vba_profile(C.Structure):
+    _fields_ = [
+        ("ms", C.c_double * PROF_N), ("launches", C.c_int64 * PROF_N),
+        ("bytes", C.c_double * PROF_N), ("total_ms", C.c_double),
+    ]
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+@dataclass
+class Problem:
+    """One local-BA window in the flat SoA form of `vba_problem`."""
+    variant: int
+    n_kf_free: int
+    kf_pose: np.ndarray            # [n_kf,7]
+    pt: np.ndarray                 # [n_pt,3]
+    pt_obs_begin: np.ndarray       # [n_pt+1]
+    obs_kf: np.ndarray             # [n_obs]
+    obs_uv: np.ndarray             # [n_obs,2]
+    obs_w: np.ndarray              # [n_obs]
+    K: np.ndarray                  # [4]
+    kf_vel: Optional[np.ndarray] = None    # [n_kf,3]
+    kf_bias: Optional[np.ndarray] = None   # [n_kf,12]
+    pt_ref_kf: Optional[np.ndarray] = None
+    T_cb: np.ndarray = field(default_factory=lambda: np.array([0, 0, 0, 0, 0, 0, 1.0]))
+    g_w: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    imu_kf_i: Optional[np.ndarray] = None
+    imu_kf_j: Optional[np.ndarray] = None
+    imu_meas: Optional[np.ndarray] = None      # [n_imu,61]
+    imu_info_prv: Optional[np.ndarray] = None  # [n_imu,81]
+    algo: int = ALGO_GN
+    its_stage1: int = 5
+    its_stage2: int = 10
+    chi2_th: float = 5.991
+    depth_min: float = 0.0
+    rho_min: float = 2e-6
+    huber_vis: float = HUBER_VIS
+    huber_prv: float = HUBER_PRV
+    huber_bias: float = HUBER_BIAS
+    truth: dict = field(default_factory=dict)  # generator ground truth (not part of the ABI)
+
+    def __post_init__(self):
+        self.kf_pose = _f64(self.kf_pose, (-1, 7))
+        self.pt = _f64(self.pt, (-1, 3))
+        self.pt_obs_begin = _i32(self.pt_obs_begin)
+        self.obs_kf = _i32(self.obs_kf)
+        self.obs_uv = _f64(self.obs_uv, (-1, 2))
+        self.obs_w = _f64(self.obs_w)
+        self.K = _f64(self.K)
+        n_kf = self.n_kf
+        self.kf_vel = _f64(self.kf_vel if self.kf_vel is not None else np.zeros((n_kf, 3)), (-1, 3))
+        self.kf_bias = _f64(self.kf_bias if self.kf_bias is not None else np.zeros((n_kf, 12)), (-1, 12))
+        self.pt_ref_kf = _i32(self.pt_ref_kf if self.pt_ref_kf is not None else np.zeros(self.n_pt))
+        self.T_cb = _f64(self.T_cb)
+        self.g_w = _f64(self.g_w)
+        self.imu_kf_i = _i32(self.imu_kf_i if self.imu_kf_i is not None else [])
+        self.imu_kf_j = _i32(self.imu_kf_j if self.imu_kf_j is not None else [])
+        self.imu_meas = _f64(self.imu_meas if self.imu_meas is not None else np.zeros((0, IMU_MEAS_STRIDE)),
+                             (-1, IMU_MEAS_STRIDE))
+        self.imu_info_prv = _f64(self.imu_info_prv if self.imu_info_prv is not None else np.zeros((0, 81)), (-1, 81))
+
+    n_kf = property(lambda self: self.kf_pose.shape[0])
+    n_pt = property(lambda self: self.pt.shape[0])
+    n_obs = property(lambda self: self.obs_kf.shape[0])
+    n_imu = property(lambda self: self.imu_kf_i.shape[0])
+
+    def copy(self) -> "Problem":
+        import copy as _c
+        q = _c.copy(self)
+        for k in ("kf_pose", "kf_vel", "kf_bias", "pt"):
+            setattr(q, k, getattr(self, k).copy())
+        return q
+
+    def as_struct(self) -> vba_problem:
+        s = vba_problem()
+        s.variant, s.n_kf, s.n_kf_free = self.variant, self.n_kf, self.n_kf_free
+        s.n_pt, s.n_obs, s.n_imu = self.n_pt, self.n_obs, self.n_imu
+        p = lambda a, t: a.ctypes.data_as(t)
+        s.kf_pose, s.kf_vel, s.kf_bias, s.pt = (p(self.kf_pose, _pd), p(self.kf_vel, _pd),
+                                                p(self.kf_bias, _pd), p(self.pt, _pd))
+        s.pt_ref_kf, s.pt_obs_begin, s.obs_kf = p(self.pt_ref_kf, _pi), p(self.pt_obs_begin, _pi), p(self.obs_kf, _pi)
+        s.obs_uv, s.obs_w = p(self.obs_uv, _pd), p(self.obs_w, _pd)
+        s.K[:] = self.K.tolist()
+        s.T_cb[:] = self.T_cb.tolist()
+        s.g_w[:] = self.g_w.tolist()
+        s.imu_kf_i, s.imu_kf_j = p(self.imu_kf_i, _pi), p(self.imu_kf_j, _pi)
+        s.imu_meas, s.imu_info_prv = p(self.imu_meas, _pd), p(self.imu_info_prv, _pd)
+        s.inv_bg_rw2, s.inv_ba_rw2 = 1.0 / GYR_BIAS_RW2, 1.0 / ACC_BIAS_RW2
+        s.huber_vis, s.huber_prv, s.huber_bias = self.huber_vis, self.huber_prv, self.huber_bias
+        s.algo, s.its_stage1, s.its_stage2 = self.algo, self.its_stage1, self.its_stage2
+        s.chi2_th, s.depth_min, s.rho_min = self.chi2_th, self.depth_min, self.rho_min
+        return s
+
+
+@dataclass
+class Result:
+    chi2_vis: float
+    chi2_prv: float
+    chi2_bias: float
+    its_done: tuple
+    n_outliers: int
+    status: int
+    obs_outlier: np.ndarray
+    obs_chi2: np.ndarray
+    chi2_trace: np.ndarray
+    lambda_final: float
+
+
+class ResultBuf:
+    """Caller-allocated result storage for one window."""
+
+    def __init__(self, n_obs: int):
+        self.outlier = np.zeros(max(n_obs, 1), dtype=np.uint8)
+        self.chi2 = np.zeros(max(n_obs, 1), dtype=np.float64)
+        self.n_obs = n_obs
+        self.s = vba_result()
+        self.s.obs_outlier = self.outlier.ctypes.data_as(_pu8)
+        self.s.obs_chi2 = self.chi2.ctypes.data_as(_pd)
+
+    def get(self) -> Result:
+        s = self.s
+        return Result(s.chi2_vis, s.chi2_prv, s.chi2_bias, (s.its_done[0], s.its_done[1]), s.n_outliers, s.status,
+                      self.outlier[:self.n_obs].copy(), self.chi2[:self.n_obs].copy(),
+                      np.array(s.chi2_trace[:s.n_trace]), s.lambda_final)

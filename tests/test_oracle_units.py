@@ -1,0 +1,239 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference ships no tests for this path, so these are the pins: every analytic Jacobian against
+central differences through the SAME retraction (g2o's own definition of a correct Jacobian,
+base_multi_edge.hpp:63-126), closed forms, and the small-angle branches at the reference's thresholds.
+"""
+import numpy as np
+import pytest
+
+from mc_slam_amd import abi, synth
+
+
+def _rand_pose(rng, scale=1.0):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    return np.concatenate([rng.normal(0, scale, 3), q])
+
+
+@pytest.mark.parametrize("theta", [0.0, 1e-11, 1e-6, 0.9e-5, 1.1e-5, 0.1, 1.0, 3.0])
+def test_so3_exp_log_roundtrip(oracle, theta):
+    rng = np.random.default_rng(1)
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    w = ax * theta
+    q = oracle.so3_exp(w)
+    assert abs(np.linalg.norm(q) - 1) < 1e-15
+    np.testing.assert_allclose(oracle.so3_log(q), w, atol=1e-12)
+    # against Rodrigues
+    np.testing.assert_allclose(oracle.quat_to_R(q), synth.so3_exp(w), atol=1e-12)
+
+
+@pytest.mark.parametrize("theta", [0.0, 0.9e-5, 1.1e-5, 0.1, 1.0, 3.0])
+def test_so3_jr_times_jrinv_is_identity(oracle, theta):
+    w = np.array([0.3, -0.5, 0.81]); w = w / np.linalg.norm(w) * theta
+    np.testing.assert_allclose(oracle.so3_jr(w) @ oracle.so3_jrinv(w), np.eye(3), atol=1e-9)
+    if theta < 1e-5:   # so3.cpp:37,58: identity below the threshold
+        assert (oracle.so3_jr(w) == np.eye(3)).all() and (oracle.so3_jrinv(w) == np.eye(3)).all()
+
+
+def test_so3_jr_is_derivative_of_exp(oracle):
+    w = np.array([0.2, -0.4, 0.3])
+    Jr = oracle.so3_jr(w)
+    R = synth.so3_exp(w)
+    for k in range(3):
+        d = np.zeros(3); d[k] = 1e-6
+        # Exp(w + d) ~= Exp(w) Exp(Jr d)
+        M = R.T @ synth.so3_exp(w + d)
+        v = np.array([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1]]) / 2
+        np.testing.assert_allclose(v / 1e-6, Jr[:, k], atol=1e-5)
+
+
+def test_quat_matrix_roundtrip(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        R = oracle.quat_to_R(q)
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-14)
+        q2 = oracle.R_to_quat(R)
+        assert min(np.abs(q2 - q).max(), np.abs(q2 + q).max()) < 1e-14
+        np.testing.assert_allclose(R, synth.quat_to_rot(q), atol=1e-15)
+
+
+def test_se3_exp_branches(oracle):
+    # theta < 1e-5: R = V = I + Omega + Omega^2 (sic), se3quat.h:237-243
+    u = np.array([3e-6, -2e-6, 1e-6, 0.1, 0.2, -0.3])
+    T = oracle.se3_exp(u)
+    Om = synth.hat(u[:3])
+    Rs = np.eye(3) + Om + Om @ Om
+    np.testing.assert_allclose(T[:3], Rs @ u[3:], atol=1e-15)
+    # generic: closed form
+    u = np.array([0.3, -0.2, 0.5, 0.1, 0.2, -0.3])
+    th = np.linalg.norm(u[:3]); Om = synth.hat(u[:3])
+    R = np.eye(3) + np.sin(th) / th * Om + (1 - np.cos(th)) / th ** 2 * Om @ Om
+    V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Om + (th - np.sin(th)) / th ** 3 * Om @ Om
+    T = oracle.se3_exp(u)
+    np.testing.assert_allclose(oracle.quat_to_R(T[3:]), R, atol=1e-14)
+    np.testing.assert_allclose(T[:3], V @ u[3:], atol=1e-14)
+    assert T[6] >= 0
+
+
+def test_huber(oracle):
+    d = abi.HUBER_VIS
+    for e in [0.0, d * d - 1e-9, d * d]:
+        np.testing.assert_allclose(oracle.huber(e, d), [e, 1, 0])
+    e = d * d + 1e-9
+    r = oracle.huber(e, d)
+    assert abs(r[0] - (2 * np.sqrt(e) * d - d * d)) < 1e-15 and abs(r[1] - d / np.sqrt(e)) < 1e-15
+    e = 100 * d * d
+    r = oracle.huber(e, d)
+    np.testing.assert_allclose(r, [2 * 10 * d * d - d * d, 0.1, -0.5 * 0.1 / e], rtol=1e-14)
+    # the deltas are float-rounded (const float thHuber = sqrt(...), src/Optimizer.cpp:241-242,327)
+    assert abi.HUBER_VIS == float(np.float32(np.sqrt(5.991)))
+
+
+def _numdiff(f, n, h=1e-6):
+    """central differences of f(delta) around delta = 0"""
+    cols = []
+    for k in range(n):
+        d = np.zeros(n); d[k] = h
+        cols.append((f(d) - f(-d)) / (2 * h))
+    return np.stack(cols, axis=1)
+
+
+def test_edge_idp_jacobians(oracle):
+    rng = np.random.default_rng(7)
+    _, _, Tcb = synth.extrinsics()
+    K = synth.EUROC_K
+    for _ in range(10):
+        ref = _rand_pose(rng, 0.3); obs = ref.copy()
+        obs = oracle.oplus_pr(ref, rng.normal(0, 0.2, 6))
+        pt = np.array([rng.uniform(0.1, 0.5), rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3)])
+        uv = rng.uniform(100, 400, 2)
+        e, Pc, Jr, J1, J2 = oracle.edge_idp(pt, ref, obs, Tcb, K, uv)
+        if Pc[2] < 0.5:
+            continue
+        f0 = lambda d: oracle.edge_idp(pt + np.array([d[0], 0, 0]), ref, obs, Tcb, K, uv, jac=False)[0]
+        f1 = lambda d: oracle.edge_idp(pt, oracle.oplus_pr(ref, d), obs, Tcb, K, uv, jac=False)[0]
+        f2 = lambda d: oracle.edge_idp(pt, ref, oracle.oplus_pr(obs, d), Tcb, K, uv, jac=False)[0]
+        scale = max(1.0, np.abs(J1).max())
+        np.testing.assert_allclose(_numdiff(f0, 1, 1e-7)[:, 0], Jr, rtol=1e-6, atol=1e-6 * scale)
+        np.testing.assert_allclose(_numdiff(f1, 6), J1, rtol=1e-6, atol=1e-6 * scale)
+        np.testing.assert_allclose(_numdiff(f2, 6), J2, rtol=1e-6, atol=1e-6 * scale)
+
+
+def test_edge_idp_zero_at_truth(oracle):
+    p = synth.make_window(n_kf=6, n_pt=40, n_obs=160, noise=False, seed=11)
+    # pixels are float32-rounded -> residual at truth is at the 1e-4 px level
+    for pt_i in range(p.n_pt):
+        for o in range(p.pt_obs_begin[pt_i], p.pt_obs_begin[pt_i + 1]):
+            e, Pc = oracle.edge_idp(p.pt[pt_i], p.kf_pose[p.pt_ref_kf[pt_i]], p.kf_pose[p.obs_kf[o]], p.T_cb, p.K,
+                                    p.obs_uv[o], jac=False)
+            assert np.abs(e).max() < 2e-3 and Pc[2] > 0.5
+
+
+def test_edge_prxyz_and_se3xyz_jacobians(oracle):
+    rng = np.random.default_rng(8)
+    _, _, Tcb = synth.extrinsics()
+    K = synth.EUROC_K
+    for _ in range(10):
+        kf = _rand_pose(rng, 0.3)
+        R = oracle.quat_to_R(kf[3:])
+        Rcb = oracle.quat_to_R(Tcb[3:])
+        # a point in front of the camera
+        Pc = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(2, 6)])
+        Pw = R @ (Rcb.T @ (Pc - Tcb[:3])) + kf[:3]
+        uv = rng.uniform(100, 400, 2)
+        e, Pc2, Jp, Jk = oracle.edge_prxyz(Pw, kf, Tcb, K, uv)
+        np.testing.assert_allclose(Pc2, Pc, atol=1e-12)
+        fp = lambda d: oracle.edge_prxyz(Pw + d, kf, Tcb, K, uv, jac=False)[0]
+        fk = lambda d: oracle.edge_prxyz(Pw, oracle.oplus_pr(kf, d), Tcb, K, uv, jac=False)[0]
+        np.testing.assert_allclose(_numdiff(fp, 3), Jp, rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(_numdiff(fk, 6), Jk, rtol=1e-6, atol=1e-4)
+        # SE3 variant: T_cw with the same camera-frame point
+        T = _rand_pose(rng, 0.3)
+        if T[6] < 0:
+            T[3:] = -T[3:]
+        Rcw = oracle.quat_to_R(T[3:])
+        Pw = Rcw.T @ (Pc - T[:3])
+        e, Pc3, Jp, Jk = oracle.edge_se3xyz(Pw, T, K, uv)
+        np.testing.assert_allclose(Pc3, Pc, atol=1e-12)
+        fp = lambda d: oracle.edge_se3xyz(Pw + d, T, K, uv, jac=False)[0]
+        fk = lambda d: oracle.edge_se3xyz(Pw, oracle.oplus_se3(T, d), K, uv, jac=False)[0]
+        np.testing.assert_allclose(_numdiff(fp, 3), Jp, rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(_numdiff(fk, 6), Jk, rtol=1e-6, atol=1e-4)
+
+
+def _prv_setup(seed):
+    p = synth.make_window(n_kf=4, n_pt=20, n_obs=60, seed=seed)
+    k = 1
+    i, j = p.imu_kf_i[k], p.imu_kf_j[k]
+    bi = p.kf_bias[i].copy()
+    bi[6:] = np.random.default_rng(seed).normal(0, 1e-3, 6)   # non-zero delta biases
+    return p, k, i, j, bi
+
+
+def test_edge_prv_jacobians(oracle):
+    for seed in (21, 22, 23):
+        p, k, i, j, bi = _prv_setup(seed)
+        pi, pj, vi, vj, meas, g = p.kf_pose[i], p.kf_pose[j], p.kf_vel[i], p.kf_vel[j], p.imu_meas[k], p.g_w
+        err = oracle.edge_prv_error(pi, pj, vi, vj, bi, meas, g)
+        J = oracle.edge_prv_jac(pi, pj, vi, vj, bi, meas, g, err)
+        f = [lambda d: oracle.edge_prv_error(oracle.oplus_pr(pi, d), pj, vi, vj, bi, meas, g),
+             lambda d: oracle.edge_prv_error(pi, oracle.oplus_pr(pj, d), vi, vj, bi, meas, g),
+             lambda d: oracle.edge_prv_error(pi, pj, vi + d, vj, bi, meas, g),
+             lambda d: oracle.edge_prv_error(pi, pj, vi, vj + d, bi, meas, g),
+             lambda d: oracle.edge_prv_error(pi, pj, vi, vj, bi + np.concatenate([np.zeros(6), d]), meas, g)]
+        for fk, Jk in zip(f, J):
+            N = _numdiff(fk, Jk.shape[1], 1e-6)
+            # the reference's Jacobians are first-order in the residual (Forster et al.): allow 1e-3 relative
+            np.testing.assert_allclose(N, Jk, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(Jk).max()))
+
+
+def test_prv_and_bias_zero_at_noise_free_truth(oracle):
+    p = synth.make_window(n_kf=6, n_pt=40, n_obs=160, noise=False, seed=12)
+    for k in range(p.n_imu):
+        i, j = p.imu_kf_i[k], p.imu_kf_j[k]
+        e = oracle.edge_prv_error(p.kf_pose[i], p.kf_pose[j], p.kf_vel[i], p.kf_vel[j], p.kf_bias[i], p.imu_meas[k], p.g_w)
+        assert np.abs(e).max() < 1e-9
+        assert np.abs(oracle.edge_bias_error(p.kf_bias[i], p.kf_bias[j])).max() == 0
+
+
+def test_preintegration_closed_form_and_numpy_twin(oracle):
+    # constant omega about z and constant body acceleration: closed forms for dR; dV, dP by the discrete sums
+    w = np.array([0.0, 0.0, 0.4]); a = np.array([0.3, -0.2, 9.0]); dt = 0.005; S = 50
+    meas, cov = oracle.preint([w] * S, [a] * S, [dt] * S)
+    assert abs(meas[0] - S * dt) < 1e-12
+    np.testing.assert_allclose(meas[7:16].reshape(3, 3), synth.so3_exp(w * dt * S), atol=1e-12)
+    dV = sum(synth.so3_exp(w * dt * k) @ a * dt for k in range(S))
+    np.testing.assert_allclose(meas[4:7], dV, atol=1e-12)
+    np.testing.assert_allclose(cov, cov.T, atol=1e-18)
+    assert np.linalg.eigvalsh(cov).min() > 0
+    # the generator's numpy restatement follows the same recursion
+    rng = np.random.default_rng(3)
+    om = rng.normal(0, 0.3, (2, S, 3)); ac = rng.normal(0, 1, (2, S, 3)) + [0, 0, 9.8]
+    dts = np.full((2, S), dt)
+    m_np, c_np = synth.preintegrate(om, ac, dts)
+    for e in range(2):
+        m_c, c_c = oracle.preint(om[e], ac[e], dts[e])
+        np.testing.assert_allclose(m_np[e], m_c, atol=1e-12)
+        np.testing.assert_allclose(c_np[e], c_c, rtol=1e-10, atol=1e-22)
+        np.testing.assert_allclose(oracle.prv_information(c_c), synth.prv_information(c_c), rtol=1e-6)
+
+
+def test_preintegration_bias_jacobians_vs_reintegration(oracle):
+    rng = np.random.default_rng(4)
+    S, dt = 50, 0.005
+    om = rng.normal(0, 0.3, (S, 3)); ac = rng.normal(0, 1, (S, 3)) + [0, 0, 9.8]
+    m0, _ = oracle.preint(om, ac, [dt] * S)
+    JPg, JPa, JVg, JVa, JRg = [m0[16 + 9 * k:25 + 9 * k].reshape(3, 3) for k in range(5)]
+    h = 1e-5
+    for k in range(3):
+        d = np.zeros(3); d[k] = h
+        mg, _ = oracle.preint(om - d, ac, [dt] * S)   # bias +d  ->  corrected sample - d
+        ma, _ = oracle.preint(om, ac - d, [dt] * S)
+        np.testing.assert_allclose((mg[1:4] - m0[1:4]) / h, JPg[:, k], atol=1e-4)
+        np.testing.assert_allclose((ma[1:4] - m0[1:4]) / h, JPa[:, k], atol=1e-4)
+        np.testing.assert_allclose((mg[4:7] - m0[4:7]) / h, JVg[:, k], atol=1e-4)
+        np.testing.assert_allclose((ma[4:7] - m0[4:7]) / h, JVa[:, k], atol=1e-4)
+        dR = m0[7:16].reshape(3, 3).T @ mg[7:16].reshape(3, 3)
+        v = np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]) / 2
+        np.testing.assert_allclose(v / h, JRg[:, k], atol=1e-4)
