@@ -1,0 +1,116 @@
+"""Host-side binding of the HIP backend (mc_slam_amd/csrc/libvislam_ba.so) through its C-ABI.
+
+There is NO CPU fallback: if the shared library is missing or no HIP device is present, construction
+fails loudly.  The library is built in-tree by `python -c "import __graft_entry__ as g; g.build()"`
+(or `make -C mc_slam_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvislam_ba.so")
+_lib = None
+
+EXPORTS = ["vba_create", "vba_destroy", "vba_last_error", "vba_solve", "vba_batch_upload", "vba_batch_run",
+           "vba_batch_download", "vba_set_profile", "vba_get_profile"]
+
+
+def load_library():
+    """dlopen the in-tree HIP library and declare every entry point of include/vislam_ba.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP backend not built: %s is missing (run __graft_entry__.build())" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    PP = C.POINTER(C.POINTER(abi.vba_problem))
+    PR = C.POINTER(C.POINTER(abi.vba_result))
+    lib.vba_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.vba_destroy.argtypes = [C.c_void_p]
+    lib.vba_last_error.argtypes = [C.c_void_p]
+    lib.vba_last_error.restype = C.c_char_p
+    lib.vba_solve.argtypes = [C.c_void_p, C.POINTER(abi.vba_problem), C.POINTER(abi.vba_result), C.c_void_p]
+    lib.vba_batch_upload.argtypes = [C.c_void_p, C.c_int32, PP]
+    lib.vba_batch_run.argtypes = [C.c_void_p, C.c_void_p]
+    lib.vba_batch_download.argtypes = [C.c_void_p, C.c_int32, PP, PR]
+    lib.vba_set_profile.argtypes = [C.c_void_p, C.c_int32]
+    lib.vba_get_profile.argtypes = [C.c_void_p, C.POINTER(abi.vba_profile)]
+    for n in EXPORTS:
+        if n != "vba_last_error":
+            getattr(lib, n).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class LocalBA:
+    """One backend handle = one GPU + one stream (vba_create).  Mirrors how the reference owns one
+    function-local g2o::SparseOptimizer per call (src/Optimizer.cpp:130), but keeps device buffers alive."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.vba_create(device, C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("vba_create(device=%d) failed (rc=%d): no usable HIP device -- the backend has no CPU path"
+                               % (device, rc))
+        self._keep = None
+
+    def close(self):
+        if self.h:
+            self.lib.vba_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, what):
+        return RuntimeError("%s: %s" % (what, self.lib.vba_last_error(self.h).decode()))
+
+    @staticmethod
+    def _stop_ptr(stop):
+        return C.cast(C.pointer(stop), C.c_void_p) if stop is not None else None
+
+    def solve(self, prob: abi.Problem, stop=None):
+        """vba_solve on a COPY of prob: returns (solved copy, Result)."""
+        q = prob.copy()
+        s = q.as_struct()
+        rb = abi.ResultBuf(q.n_obs)
+        if self.lib.vba_solve(self.h, C.byref(s), C.byref(rb.s), self._stop_ptr(stop)) != 0:
+            raise self._err("vba_solve")
+        return q, rb.get()
+
+    # ---- device-resident batch interface -------------------------------------------------------
+    def upload(self, probs):
+        self._probs = [p.copy() for p in probs]
+        self._structs = [p.as_struct() for p in self._probs]
+        n = len(probs)
+        arr = (C.POINTER(abi.vba_problem) * n)(*[C.pointer(s) for s in self._structs])
+        self._parr = arr
+        if self.lib.vba_batch_upload(self.h, n, arr) != 0:
+            raise self._err("vba_batch_upload")
+
+    def run(self, stop=None):
+        if self.lib.vba_batch_run(self.h, self._stop_ptr(stop)) != 0:
+            raise self._err("vba_batch_run")
+
+    def download(self):
+        n = len(self._probs)
+        rbs = [abi.ResultBuf(p.n_obs) for p in self._probs]
+        rarr = (C.POINTER(abi.vba_result) * n)(*[C.pointer(r.s) for r in rbs])
+        if self.lib.vba_batch_download(self.h, n, self._parr, rarr) != 0:
+            raise self._err("vba_batch_download")
+        return self._probs, [r.get() for r in rbs]
+
+    def set_profile(self, on=True):
+        self.lib.vba_set_profile(self.h, 1 if on else 0)
+
+    def get_profile(self):
+        pf = abi.vba_profile()
+        self.lib.vba_get_profile(self.h, C.byref(pf))
+        return {abi.PROF_NAMES[i]: dict(ms=pf.ms[i], launches=pf.launches[i], bytes=pf.bytes[i]) for i in range(7)} | \
+            {"total_ms": pf.total_ms}

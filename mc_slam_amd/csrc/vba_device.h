@@ -1,0 +1,237 @@
+// vba_device.h -- device-side data layout and small Lie-group helpers for the gfx950 local-BA backend.
+//
+// Everything is IEEE double: the reference optimises in double and its IMU
+// information matrices reach 1/(2e-5)^2 = 2.5e9 (src/IMU/imudata.cpp:25), so FP32 Jacobians are not an option.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VBA_NB 32          // block size of the dense reduced-system factorisation
+#define VBA_EREC 40        // doubles per edge record   (320 B)
+#define VBA_PREC 40        // doubles per point record  (320 B)
+#define VBA_IMUH 960       // doubles per IMU edge pair: 30x30 local Hessian + 30 rhs (+ pad)
+#define VBA_TRACE 64
+
+// edge record (variant 2, EdgePRIDP; all Jacobians pre-scaled by sqrt(rho' * invSigma2)):
+//   [0..11]  Bi  : 2x6 Jacobian w.r.t. the observing keyframe's PR   (g2otypes.cpp:139-145)
+//   [12..23] Br  : 2x6 Jacobian w.r.t. the reference keyframe's PR   (g2otypes.cpp:128-134)
+//   [24..29] W   : Bi^T a   (H_pl block of the observing keyframe, a = 2x1 Jacobian w.r.t. rho)
+//   [30..35] g   : -Bi^T r  (b contribution of the observing keyframe)
+// edge record (variants 0,1; XYZ landmarks):
+//   [0..11]  Bi  : 2x6 pose Jacobian
+//   [12..17] A   : 2x3 point Jacobian
+//   [18..19] r   : residual
+// point record (variant 2):  [0] D  [1] bl  [2..7] W0 (ref KF)  [8..13] g0  [14..34] G0 (upper 6x6, row-major packed)  [35] Dinv
+// point record (variants 0,1): [0..5] Hll (sym packed) [6..8] bl [9..14] Dinv (sym packed)
+
+struct WinDesc {
+    int variant, algo;
+    int n_kf, n_free, n_pt, n_obs, n_imu;
+    int pdim, np, nS, nb;
+    int its[2];
+    int kf0, pt0, obs0, imu0;
+    int pair0, n_pairs;
+    int item0;      // offset into the item array
+    int pimu0;      // offset into the pair-imu list
+    int vec0;       // offset into rhs/x vectors (nS slots per window)
+    int part0;      // offset into the chi2 partial array
+    int n_part_lin; // point blocks of this window in the linearise launch
+    int pad0;
+    long long S0;   // offset (doubles) into S
+    double K[4];
+    double Rcb[9], tcb[3], g[3];
+    double inv_bg, inv_ba;
+    double hub_vis, hub_prv, hub_bias;
+    double chi2_th, depth_min, rho_min;
+};
+
+struct WinCtrl {
+    int stage;        // 0,1
+    int it;           // outer iteration inside the stage
+    int active;       // 1 while the stage's optimize() loop is still running for this window
+    int status;
+    int its_done[2];
+    int robust_vis;   // Huber on vision edges (stage 1)
+    int chol_fail;    // set by the factorisation of the current iteration
+    int step_ok;      // 1: K_update must apply the step of this iteration
+    int aborted;      // stop flag seen
+    int n_trace;
+    int n_outliers;
+    // LM state (levenberg.cpp)
+    int lm_trial;     // trials done in the current outer iteration (qmax)
+    int lm_need_trial;// 1: another trial must run in this outer iteration
+    int nbad;
+    int pad;
+    double lambda, ni;
+    double chi_prev;  // GN: preChi2 of the last started iteration.  LM: currentChi
+    double chi_ini;   // LM: iniChi
+    double chi2_vis, chi2_prv, chi2_bias;
+    double trace[VBA_TRACE];
+};
+
+// ------------------------------------------------------------------------------------------------
+// small math (all __device__ __forceinline__, row-major 3x3)
+// ------------------------------------------------------------------------------------------------
+#define DEVI __device__ __forceinline__
+
+DEVI void q2R(const double* q, double* R) {  // q = x,y,z,w  (Eigen::Quaterniond::toRotationMatrix)
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+DEVI void R2q(const double* m, double* q) {  // Eigen quaternion-from-matrix
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        double qq[3];
+        qq[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        qq[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        qq[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2];
+    }
+}
+DEVI void qmul(const double* a, const double* b, double* o) {
+    const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    const double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    const double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    const double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+DEVI void qnorm(double* q) {
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+DEVI void qrot(const double* q, const double* v, double* o) {  // Eigen _transformVector
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux; uy += uy; uz += uz;
+    const double cx = q[1] * uz - q[2] * uy, cy = q[2] * ux - q[0] * uz, cz = q[0] * uy - q[1] * ux;
+    const double r0 = v[0] + q[3] * ux + cx, r1 = v[1] + q[3] * uy + cy, r2 = v[2] + q[3] * uz + cz;
+    o[0] = r0; o[1] = r1; o[2] = r2;
+}
+DEVI void mm3(const double* A, const double* B, double* C) {  // C = A B (C must not alias)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+DEVI void mtm3(const double* A, const double* B, double* C) {  // C = A^T B
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+DEVI void mv3(const double* A, const double* v, double* o) {
+    const double a = A[0] * v[0] + A[1] * v[1] + A[2] * v[2];
+    const double b = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
+    const double c = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+    o[0] = a; o[1] = b; o[2] = c;
+}
+DEVI void mtv3(const double* A, const double* v, double* o) {  // A^T v
+    const double a = A[0] * v[0] + A[3] * v[1] + A[6] * v[2];
+    const double b = A[1] * v[0] + A[4] * v[1] + A[7] * v[2];
+    const double c = A[2] * v[0] + A[5] * v[1] + A[8] * v[2];
+    o[0] = a; o[1] = b; o[2] = c;
+}
+DEVI void hat3(const double* v, double* M) {
+    M[0] = 0; M[1] = -v[2]; M[2] = v[1];
+    M[3] = v[2]; M[4] = 0; M[5] = -v[0];
+    M[6] = -v[1]; M[7] = v[0]; M[8] = 0;
+}
+DEVI double nrm3(const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+// Sophus::SO3::exp (src/IMU/so3.cpp:237-261): quaternion, normalised
+DEVI void so3exp(const double* w, double* q) {
+    const double th = nrm3(w), h = 0.5 * th;
+    double im;
+    if (th < 1e-10) {
+        const double t2 = th * th;
+        im = 0.5 - 0.0208333 * t2 + 0.000260417 * t2 * t2;
+    } else
+        im = sin(h) / th;
+    q[0] = im * w[0]; q[1] = im * w[1]; q[2] = im * w[2]; q[3] = cos(h);
+    qnorm(q);
+}
+// Sophus::SO3::log (so3.cpp:190-228)
+DEVI void so3log(const double* q, double* w) {
+    const double n = nrm3(q), ww = q[3];
+    const double f = (n < 1e-10) ? (2. / ww - 2. * (n * n) / (ww * ww * ww)) : (2 * atan(n / ww) / n);
+    w[0] = f * q[0]; w[1] = f * q[1]; w[2] = f * q[2];
+}
+// SO3::JacobianR / JacobianRInv (so3.cpp:33-72)
+DEVI void so3jr(const double* w, double* J) {
+    const double th = nrm3(w);
+    J[0] = 1; J[1] = 0; J[2] = 0; J[3] = 0; J[4] = 1; J[5] = 0; J[6] = 0; J[7] = 0; J[8] = 1;
+    if (th < 0.00001) return;
+    const double k[3] = {w[0] / th, w[1] / th, w[2] / th};
+    double K[9], K2[9];
+    hat3(k, K);
+    mm3(K, K, K2);
+    const double a = (1 - cos(th)) / th, b = 1 - sin(th) / th;
+#pragma unroll
+    for (int i = 0; i < 9; i++) J[i] = J[i] - a * K[i] + b * K2[i];
+}
+DEVI void so3jrinv(const double* w, double* J) {
+    const double th = nrm3(w);
+    J[0] = 1; J[1] = 0; J[2] = 0; J[3] = 0; J[4] = 1; J[5] = 0; J[6] = 0; J[7] = 0; J[8] = 1;
+    if (th < 0.00001) return;
+    const double k[3] = {w[0] / th, w[1] / th, w[2] / th};
+    double K[9], K2[9], W[9];
+    hat3(k, K);
+    hat3(w, W);
+    mm3(K, K, K2);
+    const double c = 1.0 - (1.0 + cos(th)) * th / (2.0 * sin(th));
+#pragma unroll
+    for (int i = 0; i < 9; i++) J[i] = J[i] + 0.5 * W[i] + c * K2[i];
+}
+// SO3 product with Sophus' normalisation pattern (so3.cpp:93-96,127-133)
+DEVI void so3mul(const double* a, const double* b, double* o) {
+    double t[4] = {a[0], a[1], a[2], a[3]};
+    qnorm(t);
+    double r[4];
+    qmul(t, b, r);
+    qnorm(r);
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+}
+DEVI void so3inv(const double* a, double* o) {
+    o[0] = -a[0]; o[1] = -a[1]; o[2] = -a[2]; o[3] = a[3];
+    qnorm(o);
+}
+// Huber (robust_kernel_impl.cpp:78-91): returns rho(e), sets *w = rho'(e)
+DEVI double huber(double e, double delta, double* w) {
+    const double dsqr = delta * delta;
+    if (e <= dsqr) { *w = 1.0; return e; }
+    const double s = sqrt(e);
+    *w = delta / s;
+    return 2 * s * delta - dsqr;
+}
+
+// deterministic block-wide sum of one double per thread (fixed tree order); result valid in thread 0
+template <int NT>
+DEVI double block_sum(double v, double* sm) {
+    const int t = threadIdx.x;
+    sm[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (t < s) sm[t] += sm[t + s];
+        __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
+}

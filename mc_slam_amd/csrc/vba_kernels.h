@@ -1,0 +1,925 @@
+// vba_kernels.h -- hand-written HIP kernels (gfx950, wave64) of the local-BA hot path.
+//
+// One launch = one phase of one outer iteration for EVERY window of the batch (lock-step); a window whose
+// optimize() loop has terminated makes its workgroups exit at the first instruction.  All reductions use a
+// fixed order (no floating-point atomics): results are bit-reproducible run to run.
+#pragma once
+#include "vba_device.h"
+
+struct Batch {
+    const WinDesc* desc;
+    WinCtrl* ctrl;
+    int n_win;
+    // keyframe state: working copy, uploaded initial copy, LM backup, and the R|t cache the edges read
+    double *pose, *vel, *bias, *kfR;
+    const double *pose0, *vel0, *bias0;
+    double *pose_bk, *vel_bk, *bias_bk;
+    // landmarks
+    double *pt;
+    const double* pt0;
+    double* pt_bk;
+    const int *pt_ref, *pt_obs_begin;
+    // observations (CSR by point)
+    const int *obs_kf, *obs_pt;
+    const double *obs_uv, *obs_w;
+    unsigned char* lvl;
+    double *chi2_e, *depth_e;
+    double *erec, *prec;
+    // IMU factors
+    const int *imu_i, *imu_j;
+    const double *imu_meas, *imu_info;
+    double *imuH, *imu_chi;  // imu_chi: [4] per edge: robust prv, robust bias, raw prv, raw bias
+    // reduced system
+    double *S, *vec, *bpose;
+    int* var_act;
+    // structure (g2o buildStructure analogue, built on the host at upload)
+    const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
+    double* part;
+    const volatile int* stop_word;
+    unsigned char* out_outlier;
+    double* out_chi2;
+};
+
+#define LIN_FULL 0
+#define LIN_ERR 1
+
+// ------------------------------------------------------------------------------------------------
+// K_reset: working state <- uploaded state, R|t cache, control block
+// ------------------------------------------------------------------------------------------------
+DEVI void kf_cache(const Batch& B, const WinDesc& d, int a) {
+    const double* T = B.pose + 7 * (size_t)(d.kf0 + a);
+    double* C = B.kfR + 12 * (size_t)(d.kf0 + a);
+    double R[9];
+    q2R(T + 3, R);
+#pragma unroll
+    for (int i = 0; i < 9; i++) C[i] = R[i];
+    C[9] = T[0]; C[10] = T[1]; C[11] = T[2];
+}
+
+__global__ void __launch_bounds__(64) k_reset(Batch B) {
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t < d.n_kf) {
+        const size_t k = d.kf0 + t;
+        for (int i = 0; i < 7; i++) B.pose[7 * k + i] = B.pose0[7 * k + i];
+        for (int i = 0; i < 3; i++) B.vel[3 * k + i] = B.vel0[3 * k + i];
+        for (int i = 0; i < 12; i++) B.bias[12 * k + i] = B.bias0[12 * k + i];
+        kf_cache(B, d, t);
+    }
+    if (t < d.n_pt) {
+        const size_t p = d.pt0 + t;
+        for (int i = 0; i < 3; i++) B.pt[3 * p + i] = B.pt0[3 * p + i];
+    }
+    if (t < d.n_obs) {
+        B.lvl[d.obs0 + t] = 0;
+        B.chi2_e[d.obs0 + t] = 0.0;
+    }
+    if (t == 0) {
+        WinCtrl& c = B.ctrl[w];
+        c.stage = 0; c.it = 0; c.active = 0; c.status = 0;
+        c.its_done[0] = c.its_done[1] = 0;
+        c.robust_vis = 1; c.chol_fail = 0; c.step_ok = 0; c.aborted = 0;
+        c.n_trace = 0; c.n_outliers = 0;
+        c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0;
+        c.lambda = 0; c.ni = 2; c.chi_prev = 0; c.chi_ini = 0;
+        c.chi2_vis = c.chi2_prv = c.chi2_bias = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_stage: initializeOptimization(level) -- active set of the stage (sparse_optimizer.cpp:199-267)
+//   phase 0: clear var_act, arm the control block.  phase 1: mark variables touched by an active edge.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_stage_clear(Batch B, int stage) {
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    WinCtrl& c = B.ctrl[w];
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t < d.nS) B.var_act[d.vec0 + t] = 0;
+    if (t == 0) {
+        const int stop = B.stop_word ? *B.stop_word : 0;
+        if (stage == 0) {
+            if (stop) { c.aborted = 1; c.status = 2; c.active = 0; }  // src/Optimizer.cpp:453-455
+            else c.active = 1;
+        } else {
+            if (c.aborted || stop) {  // :462-470 -- skip stage 2
+                if (!c.aborted) { c.aborted = 1; c.status = 1; }
+                c.active = 0;
+            } else
+                c.active = 1;
+            c.robust_vis = 0;  // e->setRobustKernel(0) on every vision edge, :489
+        }
+        c.stage = stage; c.it = 0; c.chol_fail = 0; c.step_ok = 0;
+        c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0; c.ni = 2;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_stage_mark(Batch B) {
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    int* va = B.var_act + d.vec0;
+    if (t < d.n_obs && !B.lvl[d.obs0 + t]) {
+        const int kf = B.obs_kf[d.obs0 + t];
+        if (kf < d.n_free)
+            for (int i = 0; i < 6; i++) va[kf * d.pdim + i] = 1;
+        if (d.variant == 2) {
+            const int rf = B.pt_ref[d.pt0 + B.obs_pt[d.obs0 + t]];
+            if (rf < d.n_free)
+                for (int i = 0; i < 6; i++) va[rf * d.pdim + i] = 1;
+        }
+    }
+    if (t < d.n_imu) {
+        const int i = B.imu_i[d.imu0 + t], j = B.imu_j[d.imu0 + t];
+        if (i < d.n_free || j < d.n_free) {  // allVerticesFixed edges are dropped
+            if (i < d.n_free)
+                for (int k = 0; k < 15; k++) va[i * 15 + k] = 1;
+            if (j < d.n_free)
+                for (int k = 0; k < 15; k++) va[j * 15 + k] = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_lin: residuals + analytic Jacobians + Huber + per-landmark products, one thread per landmark
+//        (blocks [0, nblk_pt)), and one workgroup per IMU edge pair (blocks [nblk_pt, nblk_pt + n_imu)).
+// Replaces computeActiveErrors (sparse_optimizer.cpp:61-88) + the vision/IMU part of buildSystem
+// (block_solver.hpp:502-560); Jacobians never reach HBM unreduced: only their products do.
+// ------------------------------------------------------------------------------------------------
+DEVI void lin_point_idp(const Batch& B, const WinDesc& d, const WinCtrl& c, int p, int mode, double& chi) {
+    const size_t gp = d.pt0 + p;
+    double rho = B.pt[3 * gp];
+    const double xb = B.pt[3 * gp + 1], yb = B.pt[3 * gp + 2];
+    if (rho < 1e-6) rho = 1e-6;  // g2otypes.cpp:42-47
+    const double dd = 1.0 / rho;
+    const double P0[3] = {xb * dd, yb * dd, dd};
+    const int rf = B.pt_ref[gp];
+    const double* C0 = B.kfR + 12 * (size_t)(d.kf0 + rf);
+    double R0[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) R0[i] = C0[i];
+    const double t0[3] = {C0[9], C0[10], C0[11]};
+    // c0 = Rcb^T P0 ; b0 = Rcb^T (P0 - tcb) (landmark in the reference body frame); Xw = R0 b0 + t0
+    double c0[3], b0[3], y[3], Xw[3], tb[3];
+    mtv3(d.Rcb, P0, c0);
+    mtv3(d.Rcb, d.tcb, tb);
+    b0[0] = c0[0] - tb[0]; b0[1] = c0[1] - tb[1]; b0[2] = c0[2] - tb[2];
+    mv3(R0, b0, Xw);
+    Xw[0] += t0[0]; Xw[1] += t0[1]; Xw[2] += t0[2];
+    mv3(R0, c0, y);  // Rcic0 P0 = (Rcb Ri^T) y
+    double Hb[9], N0[9];
+    hat3(b0, Hb);
+    mm3(R0, Hb, N0);  // Rcic0 hat(P0 - tcb) Rcb = (Rcb Ri^T) R0 hat(b0)
+    const bool ref_free = rf < d.n_free;
+    const double fx = d.K[0], fy = d.K[1], cx = d.K[2], cy = d.K[3];
+
+    double D = 0, bl = 0, W0[6] = {0, 0, 0, 0, 0, 0}, g0[6] = {0, 0, 0, 0, 0, 0}, G0[21];
+#pragma unroll
+    for (int i = 0; i < 21; i++) G0[i] = 0;
+
+    const int* ob = B.pt_obs_begin + d.pt0 + (&d - B.desc);  // CSR row of this window (n_pt + 1 entries)
+    const int o0 = ob[p], o1 = ob[p + 1];
+    for (int o = o0; o < o1; o++) {
+        const size_t go = d.obs0 + o;
+        const int kf = B.obs_kf[go];
+        const double* Ci = B.kfR + 12 * (size_t)(d.kf0 + kf);
+        double Ri[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Ri[i] = Ci[i];
+        const double v[3] = {Xw[0] - Ci[9], Xw[1] - Ci[10], Xw[2] - Ci[11]};
+        double ta[3], Pc[3];
+        mtv3(Ri, v, ta);  // landmark in the observing body frame
+        mv3(d.Rcb, ta, Pc);
+        Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
+        B.depth_e[go] = Pc[2];
+        double* rec = B.erec + VBA_EREC * go;
+        if (B.lvl[go]) {
+            if (mode == LIN_FULL)
+                for (int i = 0; i < 36; i++) rec[i] = 0.0;
+            continue;
+        }
+        const double iz = 1.0 / Pc[2];
+        const double ex = B.obs_uv[2 * go] - (Pc[0] * iz * fx + cx);
+        const double ey = B.obs_uv[2 * go + 1] - (Pc[1] * iz * fy + cy);
+        const double wgt = B.obs_w[go];
+        const double s = ex * (wgt * ex) + ey * (wgt * ey);
+        B.chi2_e[go] = s;
+        double rw = 1.0;
+        if (c.robust_vis) chi += huber(s, d.hub_vis, &rw);
+        else chi += s;
+        if (mode != LIN_FULL) continue;
+        const double sc = sqrt(rw * wgt);
+        // Jpi = [fx/z 0 -x/z*fx/z ; 0 fy/z -y/z*fy/z]   (g2otypes.cpp:112-121)
+        const double Jp[6] = {fx * iz, 0.0, -Pc[0] * iz * fx * iz, 0.0, fy * iz, -Pc[1] * iz * fy * iz};
+        double Jc[6], JA[6];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                Jc[3 * r + k] = Jp[3 * r] * d.Rcb[k] + Jp[3 * r + 1] * d.Rcb[3 + k] + Jp[3 * r + 2] * d.Rcb[6 + k];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)  // JA = Jc Ri^T
+                JA[3 * r + k] = Jc[3 * r] * Ri[3 * k] + Jc[3 * r + 1] * Ri[3 * k + 1] + Jc[3 * r + 2] * Ri[3 * k + 2];
+        double a[2], Br[12], Bi[12];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            a[r] = sc * dd * (JA[3 * r] * y[0] + JA[3 * r + 1] * y[1] + JA[3 * r + 2] * y[2]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double jan = JA[3 * r] * N0[k] + JA[3 * r + 1] * N0[3 + k] + JA[3 * r + 2] * N0[6 + k];
+                Br[6 * r + k] = ref_free ? -sc * JA[3 * r + k] : 0.0;
+                Br[6 * r + 3 + k] = ref_free ? sc * jan : 0.0;
+            }
+            // -Jc hat(ta): row r of Jc crossed with ta
+            const double j0 = Jc[3 * r], j1 = Jc[3 * r + 1], j2 = Jc[3 * r + 2];
+            const double h0 = j1 * ta[2] - j2 * ta[1], h1 = j2 * ta[0] - j0 * ta[2], h2 = j0 * ta[1] - j1 * ta[0];
+            const bool of = kf < d.n_free;
+            Bi[6 * r] = of ? sc * JA[3 * r] : 0.0;
+            Bi[6 * r + 1] = of ? sc * JA[3 * r + 1] : 0.0;
+            Bi[6 * r + 2] = of ? sc * JA[3 * r + 2] : 0.0;
+            // (Jc hat(ta))_k = sum_m Jc_m hat(ta)_{mk} = (Jc x ... ) ; -Jc hat(ta) = -(j x ta)^T ... see note
+            Bi[6 * r + 3] = of ? -sc * h0 : 0.0;
+            Bi[6 * r + 4] = of ? -sc * h1 : 0.0;
+            Bi[6 * r + 5] = of ? -sc * h2 : 0.0;
+        }
+        const double r0 = sc * ex, r1 = sc * ey;
+        D += a[0] * a[0] + a[1] * a[1];
+        bl -= a[0] * r0 + a[1] * r1;
+        int gi = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            W0[i] += Br[i] * a[0] + Br[6 + i] * a[1];
+            g0[i] -= Br[i] * r0 + Br[6 + i] * r1;
+#pragma unroll
+            for (int j = i; j < 6; j++) G0[gi++] += Br[i] * Br[j] + Br[6 + i] * Br[6 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) { rec[i] = Bi[i]; rec[12 + i] = Br[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            rec[24 + i] = Bi[i] * a[0] + Bi[6 + i] * a[1];
+            rec[30 + i] = -(Bi[i] * r0 + Bi[6 + i] * r1);
+        }
+    }
+    if (mode == LIN_FULL) {
+        double* pr = B.prec + VBA_PREC * gp;
+        pr[0] = D; pr[1] = bl;
+#pragma unroll
+        for (int i = 0; i < 6; i++) { pr[2 + i] = W0[i]; pr[8 + i] = g0[i]; }
+#pragma unroll
+        for (int i = 0; i < 21; i++) pr[14 + i] = G0[i];
+        pr[35] = (D > 0.0) ? 1.0 / D : 0.0;
+    }
+}
+
+// EdgeNavStatePRV + EdgeNavStateBias of one keyframe pair (the fused 15-D IMU factor): error, chi2, and in
+// LIN_FULL mode the 30x30 local Hessian J^T (rho' Omega) J and rhs in local order
+// [PR_i V_i B_i | PR_j V_j B_j].  One 64-thread workgroup; lane 0 evaluates the Lie-group part.
+DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm) {
+    const size_t gk = d.imu0 + k;
+    const int i = B.imu_i[gk], j = B.imu_j[gk];
+    double* J = sm;            // 9 x 30
+    double* Om = sm + 270;     // 9 x 9 weighted information
+    double* T = sm + 351;      // 9 x 30 = Om J
+    double* er = sm + 621;     // 9 err + 6 bias err + 2 weights(bias wg, wa scaled)
+    const int t = threadIdx.x;
+    if (i >= d.n_free && j >= d.n_free) return;  // edge between two fixed keyframes: not in the active set
+    const double* meas = B.imu_meas + 61 * gk;
+    if (t == 0) {
+        const double* Ti = B.pose + 7 * (size_t)(d.kf0 + i);
+        const double* Tj = B.pose + 7 * (size_t)(d.kf0 + j);
+        const double* Vi = B.vel + 3 * (size_t)(d.kf0 + i);
+        const double* Vj = B.vel + 3 * (size_t)(d.kf0 + j);
+        const double* bi = B.bias + 12 * (size_t)(d.kf0 + i);
+        const double* bj = B.bias + 12 * (size_t)(d.kf0 + j);
+        const double dT = meas[0], dT2 = dT * dT;
+        const double *dP = meas + 1, *dV = meas + 4, *dRm = meas + 7;
+        const double *JPg = meas + 16, *JPa = meas + 25, *JVg = meas + 34, *JVa = meas + 43, *JRg = meas + 52;
+        const double *dbg = bi + 6, *dba = bi + 9;
+        double Ri[9], Rj[9];
+        q2R(Ti + 3, Ri);
+        q2R(Tj + 3, Rj);
+        // residuals (g2otypes.cpp:207-215)
+        double vP[3], vV[3], rvP[3], rvV[3], c1[3], c2[3], e[9];
+        for (int m = 0; m < 3; m++) {
+            vP[m] = Tj[m] - Ti[m] - Vi[m] * dT - 0.5 * d.g[m] * dT2;
+            vV[m] = Vj[m] - Vi[m] - d.g[m] * dT;
+        }
+        double qiT[4];
+        so3inv(Ti + 3, qiT);
+        qrot(qiT, vP, rvP);
+        qrot(qiT, vV, rvV);
+        mv3(JPg, dbg, c1); mv3(JPa, dba, c2);
+        for (int m = 0; m < 3; m++) e[m] = rvP[m] - (dP[m] + c1[m] + c2[m]);
+        mv3(JVg, dbg, c1); mv3(JVa, dba, c2);
+        for (int m = 0; m < 3; m++) e[6 + m] = rvV[m] - (dV[m] + c1[m] + c2[m]);
+        double wv[3], qd[4], qR[4], qA[4], qAi[4], qB[4], qC[4];
+        mv3(JRg, dbg, wv);
+        so3exp(wv, qd);
+        R2q(dRm, qR);
+        qnorm(qR);
+        so3mul(qR, qd, qA);
+        so3inv(qA, qAi);
+        so3mul(qAi, qiT, qB);
+        so3mul(qB, Tj + 3, qC);
+        so3log(qC, e + 3);
+        const double* info = B.imu_info + 81 * gk;
+        double s = 0;
+        for (int a = 0; a < 9; a++) {
+            double tt = 0;
+            for (int b = 0; b < 9; b++) tt += info[9 * a + b] * e[b];
+            s += e[a] * tt;
+        }
+        double rw, rwb;
+        const double rob = huber(s, d.hub_prv, &rw);
+        double eb[6];
+        for (int m = 0; m < 3; m++) {
+            eb[m] = (bj[m] + bj[6 + m]) - (bi[m] + bi[6 + m]);
+            eb[3 + m] = (bj[3 + m] + bj[9 + m]) - (bi[3 + m] + bi[9 + m]);
+        }
+        const double wg = d.inv_bg / dT, wa = d.inv_ba / dT;
+        const double sb = wg * (eb[0] * eb[0] + eb[1] * eb[1] + eb[2] * eb[2]) + wa * (eb[3] * eb[3] + eb[4] * eb[4] + eb[5] * eb[5]);
+        const double robb = huber(sb, d.hub_bias, &rwb);
+        double* ch = B.imu_chi + 4 * gk;
+        ch[0] = rob; ch[1] = robb; ch[2] = s; ch[3] = sb;
+        if (mode == LIN_FULL) {
+            for (int a = 0; a < 9; a++) er[a] = e[a];
+            for (int a = 0; a < 6; a++) er[9 + a] = eb[a];
+            er[15] = rwb * wg; er[16] = rwb * wa;
+            for (int a = 0; a < 81; a++) Om[a] = rw * info[a];
+            for (int a = 0; a < 270; a++) J[a] = 0.0;
+            // Jacobians (g2otypes.cpp:296-359); local columns: PR_i 0..5, V_i 6..8, B_i 9..14, PR_j 15..20, V_j 21..23
+            double RiT[9], RjT[9], JrI[9], H1[9], H2[9], T1[9], T2[9];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) { RiT[3 * a + b] = Ri[3 * b + a]; RjT[3 * a + b] = Rj[3 * b + a]; }
+            so3jrinv(e + 3, JrI);
+            double mP[3], mV[3];
+            mv3(RiT, vP, mP);
+            mv3(RiT, vV, mV);
+            hat3(mP, H1);
+            hat3(mV, H2);
+            mm3(JrI, RjT, T1);
+            mm3(T1, Ri, T2);  // JrInv Rj^T Ri
+            double qe[4], qei[4], ExpT[9], JrB[9], T3[9];
+            so3exp(e + 3, qe);
+            so3inv(qe, qei);
+            q2R(qei, ExpT);
+            so3jr(wv, JrB);
+            mm3(JrI, ExpT, T1);
+            mm3(T1, JrB, T3);
+            mm3(T3, JRg, T1);  // JrInv Exp(rphi)^T Jr(JRg dbg) JRg
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    const int q = 3 * a + b;
+                    J[(0 + a) * 30 + 0 + b] = -RiT[q];            // d rP / d P_i
+                    J[(0 + a) * 30 + 3 + b] = H1[q];              // d rP / d phi_i
+                    J[(3 + a) * 30 + 3 + b] = -T2[q];             // d rphi / d phi_i
+                    J[(6 + a) * 30 + 3 + b] = H2[q];              // d rV / d phi_i
+                    J[(0 + a) * 30 + 6 + b] = -RiT[q] * dT;       // d rP / d V_i
+                    J[(6 + a) * 30 + 6 + b] = -RiT[q];            // d rV / d V_i
+                    J[(0 + a) * 30 + 9 + b] = -JPg[q];            // d rP / d dbg_i
+                    J[(0 + a) * 30 + 12 + b] = -JPa[q];           // d rP / d dba_i
+                    J[(3 + a) * 30 + 9 + b] = -T1[q];             // d rphi / d dbg_i
+                    J[(6 + a) * 30 + 9 + b] = -JVg[q];
+                    J[(6 + a) * 30 + 12 + b] = -JVa[q];
+                    J[(0 + a) * 30 + 15 + b] = RiT[q];            // d rP / d P_j
+                    J[(3 + a) * 30 + 18 + b] = JrI[q];            // d rphi / d phi_j
+                    J[(6 + a) * 30 + 21 + b] = RiT[q];            // d rV / d V_j
+                }
+        }
+    }
+    if (mode != LIN_FULL) return;
+    __syncthreads();
+    for (int q = t; q < 270; q += 64) {  // T = Om J
+        const int a = q / 30, col = q % 30;
+        double s = 0;
+#pragma unroll
+        for (int b = 0; b < 9; b++) s += Om[9 * a + b] * J[b * 30 + col];
+        T[q] = s;
+    }
+    __syncthreads();
+    double* H = B.imuH + VBA_IMUH * gk;
+    for (int q = t; q < 900; q += 64) {  // H = J^T T  (+ bias edge: -I/+I Jacobians on B_i (9..14), B_j (24..29))
+        const int r = q / 30, col = q % 30;
+        double s = 0;
+#pragma unroll
+        for (int a = 0; a < 9; a++) s += J[a * 30 + r] * T[a * 30 + col];
+        const int rb = (r >= 9 && r < 15) ? r - 9 : ((r >= 24) ? r - 24 : -1);
+        const int cb = (col >= 9 && col < 15) ? col - 9 : ((col >= 24) ? col - 24 : -1);
+        if (rb >= 0 && rb == cb) {
+            const double wq = (rb < 3) ? er[15] : er[16];
+            const double sr = (r < 15) ? -1.0 : 1.0, scn = (col < 15) ? -1.0 : 1.0;
+            s += sr * scn * wq;
+        }
+        H[q] = s;
+    }
+    if (t < 30) {  // rhs = -J^T Om e  (+ bias edge)
+        double s = 0;
+        for (int a = 0; a < 9; a++) s -= T[a * 30 + t] * er[a];
+        const int rb = (t >= 9 && t < 15) ? t - 9 : ((t >= 24) ? t - 24 : -1);
+        if (rb >= 0) {
+            const double wq = (rb < 3) ? er[15] : er[16];
+            const double sr = (t < 15) ? -1.0 : 1.0;
+            s -= sr * wq * er[9 + rb];
+        }
+        H[900 + t] = s;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_lin(Batch B, int nblk_pt, int mode) {
+    __shared__ double sm[640];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;
+    if ((int)blockIdx.x < nblk_pt) {
+        const int p = blockIdx.x * 64 + threadIdx.x;
+        if ((int)blockIdx.x * 64 >= d.n_pt) return;
+        double chi = 0.0;
+        if (p < d.n_pt) lin_point_idp(B, d, c, p, mode, chi);
+        const double tot = block_sum<64>(chi, sm);
+        if (threadIdx.x == 0) B.part[d.part0 + blockIdx.x] = tot;
+    } else {
+        const int k = blockIdx.x - nblk_pt;
+        if (k >= d.n_imu) return;
+        lin_imu(B, d, k, mode, sm);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_ctrl: one workgroup per window.  Sums the robust chi2 in a fixed order and runs the outer-loop
+// logic of OptimizationAlgorithmGaussNewton::solve (gauss_newton.cpp:50-105) as driven by
+// SparseOptimizer::optimize (sparse_optimizer.cpp:354-419).  final != 0: evaluation after the last iteration.
+// ------------------------------------------------------------------------------------------------
+DEVI double window_chi2(const Batch& B, const WinDesc& d, double* sm) {
+    const int t = threadIdx.x;
+    double s = 0;
+    for (int k = t; k < d.n_imu; k += 64) {
+        const int i = B.imu_i[d.imu0 + k], j = B.imu_j[d.imu0 + k];
+        if (i < d.n_free || j < d.n_free) s += B.imu_chi[4 * (size_t)(d.imu0 + k)] + B.imu_chi[4 * (size_t)(d.imu0 + k) + 1];
+    }
+    for (int k = t; k < d.n_part_lin; k += 64) s += B.part[d.part0 + k];
+    return block_sum<64>(s, sm);
+}
+
+__global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval) {
+    __shared__ double sm[64];
+    const int w = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;
+    const double cur = window_chi2(B, d, sm);
+    if (threadIdx.x != 0) return;
+    const int st = c.stage, it = c.it;
+    if (c.n_trace < VBA_TRACE) c.trace[c.n_trace++] = cur;
+    int active = 1;
+    if (it >= 1) {
+        c.its_done[st] = it;  // iterations 0..it-1 have run (++cjIterations)
+        if (c.chol_fail) { c.status = -2; active = 0; }
+        if (fabs(c.chi_prev - cur) < 1e-3) active = 0;  // Terminate, gauss_newton.cpp:97
+    }
+    c.chi_prev = cur;
+    if (final_eval || it >= d.its[st]) active = 0;
+    if (active && B.stop_word && *B.stop_word) {  // terminate() before each iteration, sparse_optimizer.cpp:376
+        c.aborted = 1;
+        if (st == 0) c.status = 1;
+        active = 0;
+    }
+    c.active = active;
+    c.chol_fail = 0;
+    c.step_ok = active;
+    c.it = it + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_schur: one workgroup per keyframe block pair (a <= b).  Gathers, in a fixed order, every landmark
+// observed from both keyframes: S_ab = H_ab - sum_l W_al Dinv_l W_bl^T (block_solver.hpp:373-430), adds the
+// IMU blocks, writes the pdim x pdim block (and its mirror) exactly once.  Diagonal pairs also produce the
+// reduced right-hand side (:436-439), the unreduced b_p and the H_pp diagonal (for LM's lambda init).
+// ------------------------------------------------------------------------------------------------
+DEVI double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
+    __shared__ double blk[15 * 15 + 16];
+    __shared__ double sh_r[6], sh_b[6], sh_h[6];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;
+    const int pr = blockIdx.x;
+    if (pr >= d.n_pairs) return;
+    const int t = threadIdx.x;
+    const int a = B.pair_a[d.pair0 + pr], b = B.pair_b[d.pair0 + pr];
+    const bool diag = (a == b);
+    const double lambda = (d.algo == 1) ? c.lambda : 0.0;
+    double acc[36], rhs[6], bp[6], hd[6];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) rhs[i] = bp[i] = hd[i] = 0;
+    const int ib = B.item_begin[d.pair0 + w + pr], ie = B.item_begin[d.pair0 + w + pr + 1];
+    for (int it = ib + t; it < ie; it += 64) {
+        const int* itm = B.items + 3 * (size_t)(d.item0 + it);
+        const int p = itm[0], sa = itm[1], sb = itm[2];
+        const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + p);
+        const double Dl = pr_[0];
+        const double Dinv = (d.algo == 1) ? ((Dl + lambda) != 0.0 ? 1.0 / (Dl + lambda) : 0.0) : pr_[35];
+        double WA[6], WB[6];
+        const double* ra = (sa >= 0) ? B.erec + VBA_EREC * (size_t)(d.obs0 + sa) : nullptr;
+        const double* rb = (sb >= 0) ? B.erec + VBA_EREC * (size_t)(d.obs0 + sb) : nullptr;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            WA[i] = ra ? ra[24 + i] : pr_[2 + i];
+            WB[i] = rb ? rb[24 + i] : pr_[2 + i];
+        }
+        if (diag) {
+            // same slot on both sides: direct term G (H_pp diagonal block) and the rhs pieces
+            if (sa < 0) {
+                int gi = 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = i; j < 6; j++) {
+                        const double g = pr_[14 + gi++];
+                        acc[6 * i + j] += g;
+                        if (j != i) acc[6 * j + i] += g;
+                        if (j == i) hd[i] += g;
+                    }
+#pragma unroll
+                for (int i = 0; i < 6; i++) bp[i] += pr_[8 + i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) acc[6 * i + j] += ra[i] * ra[j] + ra[6 + i] * ra[6 + j];
+                    hd[i] += ra[i] * ra[i] + ra[6 + i] * ra[6 + i];
+                    bp[i] += ra[30 + i];
+                }
+            }
+            const double bl = pr_[1];
+#pragma unroll
+            for (int i = 0; i < 6; i++) rhs[i] -= WA[i] * (Dinv * bl);
+        } else if (sa < 0 && sb >= 0) {  // a = reference KF, b = observer: Br^T Bi of edge sb
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) acc[6 * i + j] += rb[12 + i] * rb[j] + rb[18 + i] * rb[6 + j];
+        } else if (sa >= 0 && sb < 0) {  // a = observer, b = reference KF: Bi^T Br of edge sa
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) acc[6 * i + j] += ra[i] * ra[12 + j] + ra[6 + i] * ra[18 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const double wd = WA[i] * Dinv;
+#pragma unroll
+            for (int j = 0; j < 6; j++) acc[6 * i + j] -= wd * WB[j];
+        }
+    }
+    // fixed-order wave reduction
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = wave_sum(acc[i]);
+    if (diag) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) { rhs[i] = wave_sum(rhs[i]); bp[i] = wave_sum(bp[i]); hd[i] = wave_sum(hd[i]); }
+    }
+    const int P = d.pdim;
+    for (int q = t; q < P * P; q += 64) blk[q] = 0.0;
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) blk[i * P + j] = acc[6 * i + j];
+            sh_r[i] = rhs[i]; sh_b[i] = bp[i]; sh_h[i] = hd[i];
+        }
+    }
+    __syncthreads();
+    // IMU blocks + rhs
+    const int qb = B.pimu_begin[d.pair0 + w + pr], qe = B.pimu_begin[d.pair0 + w + pr + 1];
+    double* vec = B.vec + d.vec0;
+    double* bpose = B.bpose + d.vec0;
+    const int* va = B.var_act + d.vec0;
+    double* S = B.S + d.S0;
+    const int n = d.nS;
+    for (int q = t; q < P * P; q += 64) {
+        const int r = q / P, col = q % P;
+        double s = blk[q];
+        for (int m = qb; m < qe; m++) {
+            const int k = B.pimu[2 * (size_t)(d.pimu0 + m)], role = B.pimu[2 * (size_t)(d.pimu0 + m) + 1];
+            const double* H = B.imuH + VBA_IMUH * (size_t)(d.imu0 + k);
+            const int ro = (role & 1) ? 15 : 0, co = (role & 2) ? 15 : 0;  // bit0: a is j ; bit1: b is j
+            s += H[(ro + r) * 30 + co + col];
+        }
+        const int gr = a * P + r, gc = b * P + col;
+        if (diag) {
+            if (!va[gr] || !va[gc]) s = (r == col) ? 1.0 : 0.0;  // vertex outside the index mapping
+            else if (r == col) s += lambda;                       // setLambda, block_solver.hpp:564-589
+        }
+        S[(size_t)gr * n + gc] = s;
+        if (!diag) S[(size_t)gc * n + gr] = s;
+    }
+    if (diag && t < P) {
+        double s = 0.0, sb = 0.0, h = 0.0;
+        if (t < 6) { s = sh_r[t]; sb = sh_b[t]; h = sh_h[t]; }
+        for (int m = qb; m < qe; m++) {
+            const int k = B.pimu[2 * (size_t)(d.pimu0 + m)], role = B.pimu[2 * (size_t)(d.pimu0 + m) + 1];
+            const double* H = B.imuH + VBA_IMUH * (size_t)(d.imu0 + k);
+            const int ro = (role & 1) ? 15 : 0;
+            sb += H[900 + ro + t];
+            h += H[(ro + t) * 30 + ro + t];
+        }
+        const int gr = a * P + t;
+        const bool act = va[gr] != 0;
+        vec[gr] = act ? (sb + s) : 0.0;   // reduced rhs = b_p - sum W Dinv b_l
+        bpose[gr] = act ? sb : 0.0;       // unreduced b_p (LM computeScale)
+        bpose[n + gr] = act ? h : 0.0;    // H_pp diagonal (LM computeLambdaInit)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense reduced-system factorisation S = L L^T, right-looking, NB = 32, lock-step launches.
+// Restates LinearSolverEigen::solve (linear_solver_eigen.h:94-124) on the dense reduced system; the
+// right-hand side rides along as an extra row (forward substitution for free).
+// k_chol_panel(k): every workgroup factors the diagonal block redundantly in LDS, workgroup 0 stores it
+//                  and y_k; workgroup j>=0 solves two 32-row panels below it and updates their rhs rows.
+// k_chol_syrk(k) : trailing update A_ij -= L_ik L_jk^T on 32x32 tiles, j <= i.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_chol_panel(Batch B, int k) {
+    __shared__ double Lk[32][33];
+    __shared__ double yk[32];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;
+    if (k >= d.nb) return;
+    const int n = d.nS, t = threadIdx.x;
+    double* S = B.S + d.S0;
+    double* vec = B.vec + d.vec0;
+    const int m = d.nb - k - 1;                 // panel block rows below the diagonal
+    const int j = blockIdx.x;
+    if (j > 0 && 2 * j >= m) return;            // block j handles panel rows 2j, 2j+1
+    const size_t dk = (size_t)k * 32;
+    for (int q = t; q < 1024; q += 64) {
+        const int r = q >> 5, col = q & 31;
+        Lk[r][col] = (col <= r) ? S[(dk + r) * n + dk + col] : 0.0;
+    }
+    if (t < 32) yk[t] = vec[dk + t];
+    __syncthreads();
+    // factor the diagonal block (lanes 0..31 own one row each)
+    bool bad = false;
+    for (int cc = 0; cc < 32; cc++) {
+        const double piv = Lk[cc][cc];
+        if (!(piv > 0.0)) bad = true;  // also catches NaN
+        const double dg = sqrt(piv);
+        __syncthreads();
+        if (t < 32 && t >= cc) Lk[t][cc] = (t == cc) ? dg : Lk[t][cc] / dg;
+        __syncthreads();
+        if (t < 32 && t > cc) {
+            const double l = Lk[t][cc];
+            for (int c2 = cc + 1; c2 <= t; c2++) Lk[t][c2] -= l * Lk[c2][cc];
+        }
+        __syncthreads();
+    }
+    // y_k = L_kk^-1 r_k
+    for (int cc = 0; cc < 32; cc++) {
+        if (t == cc) yk[cc] = yk[cc] / Lk[cc][cc];
+        __syncthreads();
+        if (t < 32 && t > cc) yk[t] -= Lk[t][cc] * yk[cc];
+        __syncthreads();
+    }
+    if (j == 0) {
+        for (int q = t; q < 1024; q += 64) {
+            const int r = q >> 5, col = q & 31;
+            if (col <= r) S[(dk + r) * n + dk + col] = Lk[r][col];
+        }
+        if (t < 32) vec[dk + t] = yk[t];
+        if (t == 0 && bad) c.chol_fail = 1;
+    }
+    // panel rows: lanes 0..31 -> block row k+1+2j, lanes 32..63 -> k+2+2j
+    const int pi = 2 * j + (t >> 5);
+    if (pi < m) {
+        const int r = t & 31;
+        const size_t row = ((size_t)(k + 1 + pi)) * 32 + r;
+        double* A = S + row * n + dk;
+        double x[32];
+#pragma unroll
+        for (int cc = 0; cc < 32; cc++) x[cc] = A[cc];
+        double ry = vec[row];
+#pragma unroll
+        for (int cc = 0; cc < 32; cc++) {
+            double s = x[cc];
+#pragma unroll
+            for (int q = 0; q < cc; q++) s -= x[q] * Lk[cc][q];
+            s /= Lk[cc][cc];
+            x[cc] = s;
+            ry -= s * yk[cc];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 32; cc++) A[cc] = x[cc];
+        vec[row] = ry;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_chol_syrk(Batch B, int k) {
+    __shared__ double Li[32][33];
+    __shared__ double Lj[32][33];
+    const int w = blockIdx.z;
+    const WinDesc& d = B.desc[w];
+    if (!B.ctrl[w].active) return;
+    const int m = d.nb - k - 1;
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bi >= m || bj > bi) return;
+    const int n = d.nS, t = threadIdx.x;
+    double* S = B.S + d.S0;
+    const size_t ri = ((size_t)(k + 1 + bi)) * 32, rj = ((size_t)(k + 1 + bj)) * 32, ck = (size_t)k * 32;
+    for (int q = t; q < 1024; q += 64) {
+        const int r = q >> 5, col = q & 31;
+        Li[r][col] = S[(ri + r) * n + ck + col];
+        Lj[r][col] = S[(rj + r) * n + ck + col];
+    }
+    __syncthreads();
+    const int r = t & 31, h = t >> 5;
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.0;
+    for (int kk = 0; kk < 32; kk++) {
+        const double av = Li[r][kk];
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] += av * Lj[h * 16 + q][kk];
+    }
+    double* A = S + (ri + r) * n + rj + h * 16;
+#pragma unroll
+    for (int q = 0; q < 16; q++) A[q] -= acc[q];
+}
+
+// K_trsv: L^T x = y, one 256-thread workgroup per window, block column by block column from the bottom.
+__global__ void __launch_bounds__(256) k_trsv(Batch B) {
+    extern __shared__ double xs[];  // nS doubles + 8*32 partials + 32*33 diag block
+    const int w = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    if (!B.ctrl[w].active) return;
+    const int n = d.nS, t = threadIdx.x;
+    double* part = xs + n;
+    double* Lk = part + 256;
+    const double* S = B.S + d.S0;
+    double* vec = B.vec + d.vec0;
+    for (int q = t; q < n; q += 256) xs[q] = vec[q];
+    __syncthreads();
+    const int cc = t & 31, rl = t >> 5;
+    for (int k = d.nb - 1; k >= 0; k--) {
+        const size_t dk = (size_t)k * 32;
+        double s = 0.0;
+        for (int r = (k + 1) * 32 + rl; r < n; r += 8) s += S[(size_t)r * n + dk + cc] * xs[r];
+        part[rl * 32 + cc] = s;
+        for (int q = t; q < 1024; q += 256) Lk[(q >> 5) * 33 + (q & 31)] = S[(dk + (q >> 5)) * n + dk + (q & 31)];
+        __syncthreads();
+        if (t < 32) {
+            double v = xs[dk + t];
+            for (int q = 0; q < 8; q++) v -= part[q * 32 + t];
+            xs[dk + t] = v;
+        }
+        __syncthreads();
+        for (int c2 = 31; c2 >= 0; c2--) {  // L_kk^T x_k = v
+            if (t == c2) xs[dk + c2] = xs[dk + c2] / Lk[c2 * 33 + c2];
+            __syncthreads();
+            if (t < c2) xs[dk + t] -= Lk[c2 * 33 + t] * xs[dk + c2];
+            __syncthreads();
+        }
+    }
+    for (int q = t; q < n; q += 256) vec[q] = xs[q];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_update: landmark back-substitution x_l = Dinv (b_l - W^T x_p) (block_solver.hpp:461-481) fused with the
+// vertex retractions (SparseOptimizer::update -> oplusImpl): blocks [0,nblk_pt) landmarks, then keyframes.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const WinCtrl& c = B.ctrl[w];
+    if (!c.active || c.chol_fail) return;
+    const double* x = B.vec + d.vec0;
+    const int P = d.pdim;
+    if ((int)blockIdx.x < nblk_pt) {
+        const int p = blockIdx.x * 64 + threadIdx.x;
+        if (p >= d.n_pt) return;
+        const size_t gp = d.pt0 + p;
+        const double* pr = B.prec + VBA_PREC * gp;
+        const double D = pr[0];
+        if (!(D > 0.0)) return;  // landmark outside the active set
+        double cl = pr[1];
+        const int rf = B.pt_ref[gp];
+        if (rf < d.n_free)
+#pragma unroll
+            for (int i = 0; i < 6; i++) cl -= pr[2 + i] * x[rf * P + i];
+        const int* ob = B.pt_obs_begin + d.pt0 + w;
+        for (int o = ob[p]; o < ob[p + 1]; o++) {
+            const size_t go = d.obs0 + o;
+            const int kf = B.obs_kf[go];
+            if (kf >= d.n_free) continue;
+            const double* rec = B.erec + VBA_EREC * go;
+#pragma unroll
+            for (int i = 0; i < 6; i++) cl -= rec[24 + i] * x[kf * P + i];
+        }
+        const double lam = (d.algo == 1) ? c.lambda : 0.0;
+        double rho = B.pt[3 * gp] + cl / (D + lam);
+        if (rho < 1e-6) rho = 1e-6;  // VertexIDP::oplusImpl, g2otypes.h:50-55
+        B.pt[3 * gp] = rho;
+    } else {
+        const int a = (blockIdx.x - nblk_pt) * 64 + threadIdx.x;
+        if (a >= d.n_free) return;
+        const int* va = B.var_act + d.vec0;
+        const double* dx = x + a * P;
+        const size_t gk = d.kf0 + a;
+        if (va[a * P]) {  // NavState::IncSmallPR, NavState.cpp:63-70
+            double* T = B.pose + 7 * gk;
+            T[0] += dx[0]; T[1] += dx[1]; T[2] += dx[2];
+            double dq[4], qn[4];
+            so3exp(dx + 3, dq);
+            so3mul(T + 3, dq, qn);
+            T[3] = qn[0]; T[4] = qn[1]; T[5] = qn[2]; T[6] = qn[3];
+            kf_cache(B, d, a);
+        }
+        if (P == 15) {
+            if (va[a * P + 6])
+                for (int i = 0; i < 3; i++) B.vel[3 * gk + i] += dx[6 + i];
+            if (va[a * P + 9])
+                for (int i = 0; i < 6; i++) B.bias[12 * gk + 6 + i] += dx[9 + i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_classify: outlier pass between the stages (src/Optimizer.cpp:475-490): chi2 from the stored error,
+// depth and rho at the current estimate.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_classify(Batch B) {
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;  // bDoMore == false (latched by k_stage_clear(1)) or aborted on entry
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    if (o >= d.n_obs) return;
+    const size_t go = d.obs0 + o;
+    bool bad = (B.chi2_e[go] > d.chi2_th) || !(B.depth_e[go] > d.depth_min);
+    if (d.variant == 2 && B.pt[3 * (size_t)(d.pt0 + B.obs_pt[go])] < d.rho_min) bad = true;
+    if (bad) B.lvl[go] = 1;
+}
+
+// K_final: erase list + chi2 of the level-0 edges at the final estimates (src/Optimizer.cpp:496-517)
+__global__ void __launch_bounds__(64) k_final_edges(Batch B) {
+    __shared__ double sm[64];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    if ((int)blockIdx.x * 64 >= d.n_obs) return;
+    double chi = 0.0, cnt = 0.0;
+    if (o < d.n_obs) {
+        const size_t go = d.obs0 + o;
+        const double s = B.chi2_e[go];
+        bool bad = (s > d.chi2_th) || !(B.depth_e[go] > d.depth_min);
+        if (d.variant == 2 && (B.pt[3 * (size_t)(d.pt0 + B.obs_pt[go])] < d.rho_min || B.lvl[go])) bad = true;
+        B.out_outlier[go] = bad ? 1 : 0;
+        B.out_chi2[go] = s;
+        if (!B.lvl[go]) chi = s;
+        cnt = bad ? 1.0 : 0.0;
+    }
+    const double tc = block_sum<64>(chi, sm);
+    const double tn = block_sum<64>(cnt, sm);
+    if (threadIdx.x == 0) {
+        B.part[d.part0 + 2 * blockIdx.x] = tc;
+        B.part[d.part0 + 2 * blockIdx.x + 1] = tn;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_final_sum(Batch B) {
+    __shared__ double sm[64];
+    const int w = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    WinCtrl& c = B.ctrl[w];
+    const int t = threadIdx.x;
+    const int nblk = (d.n_obs + 63) / 64;
+    double s = 0, nn = 0, sp = 0, sbias = 0;
+    for (int k = t; k < nblk; k += 64) { s += B.part[d.part0 + 2 * k]; nn += B.part[d.part0 + 2 * k + 1]; }
+    for (int k = t; k < d.n_imu; k += 64) {
+        const int i = B.imu_i[d.imu0 + k], j = B.imu_j[d.imu0 + k];
+        if (i < d.n_free || j < d.n_free) { sp += B.imu_chi[4 * (size_t)(d.imu0 + k) + 2]; sbias += B.imu_chi[4 * (size_t)(d.imu0 + k) + 3]; }
+    }
+    s = block_sum<64>(s, sm);
+    nn = block_sum<64>(nn, sm);
+    sp = block_sum<64>(sp, sm);
+    sbias = block_sum<64>(sbias, sm);
+    if (t == 0) {
+        if (c.status == 2) { c.n_outliers = 0; return; }
+        c.chi2_vis = s; c.chi2_prv = sp; c.chi2_bias = sbias; c.n_outliers = (int)(nn + 0.5);
+    }
+}

@@ -1,0 +1,614 @@
+// vislam_ba.hip -- C-ABI (include/vislam_ba.h) of the MI355X local-BA backend: handle, upload (H2D +
+// structure build), the lock-step launch schedule of the two-stage solve, download.
+//
+// Host-side control flow restated from src/Optimizer.cpp:453-517 (two-stage protocol) and
+// Thirdparty/g2o/g2o/core/sparse_optimizer.cpp:354-419 (optimize loop); all per-iteration decisions are taken
+// on the device (k_ctrl_*), the host only enqueues.  No CPU fallback exists: without a HIP device every entry
+// point fails with an error.
+#include "../../include/vislam_ba.h"
+#include "vba_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+enum {
+    BUF_DESC, BUF_CTRL, BUF_POSE, BUF_VEL, BUF_BIAS, BUF_KFR, BUF_POSE0, BUF_VEL0, BUF_BIAS0, BUF_POSEBK, BUF_VELBK,
+    BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
+    BUF_CHI2E, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
+    BUF_S, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
+    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_N
+};
+
+struct ProfEvt {
+    int cls;
+    hipEvent_t a, b;
+};
+
+struct Handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    DevBuf buf[BUF_N];
+    Batch B;
+    std::vector<WinDesc> desc;
+    std::vector<WinCtrl> hctrl;
+    int n_win = 0;
+    // launch geometry (maxima over the batch)
+    int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
+    int max_nS = 0, max_its[2] = {0, 0};
+    int algo = 0, variant = 2;
+    volatile int* stop_host = nullptr;  // pinned, device-visible
+    int* stop_dev = nullptr;
+    bool profile = false;
+    std::vector<ProfEvt> evts;
+    std::vector<hipEvent_t> evt_pool;
+    size_t evt_used = 0;
+    vba_profile prof;
+    bool uploaded = false;
+    bool ran = false;
+};
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(_e);                         \
+            return -1;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+int fail(Handle* h, const std::string& m) {
+    h->err = m;
+    return -1;
+}
+
+template <typename T>
+T* dp(Handle* h, int id) {
+    return reinterpret_cast<T*>(h->buf[id].p);
+}
+
+hipEvent_t get_evt(Handle* h) {
+    if (h->evt_used == h->evt_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        h->evt_pool.push_back(e);
+    }
+    return h->evt_pool[h->evt_used++];
+}
+
+struct ProfScope {
+    Handle* h;
+    ProfEvt e;
+    bool on;
+    ProfScope(Handle* hh, int cls) : h(hh), on(hh->profile) {
+        if (on) {
+            e.cls = cls;
+            e.a = get_evt(h);
+            e.b = get_evt(h);
+            (void)hipEventRecord(e.a, h->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(e.b, h->stream);
+            h->evts.push_back(e);
+        }
+    }
+};
+
+// ---- structure build (g2o BlockSolver::buildStructure analogue, block_solver.hpp:143-295) -------------
+struct Structure {
+    std::vector<int> pair_a, pair_b, item_begin, items, pimu_begin, pimu, obs_pt;
+};
+
+int build_structure(Handle* h, const vba_problem* P, Structure& st) {
+    const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2;
+    auto pidx = [nf](int a, int b) { return a * nf - a * (a - 1) / 2 + (b - a); };
+    st.pair_a.resize(npairs);
+    st.pair_b.resize(npairs);
+    for (int a = 0; a < nf; a++)
+        for (int b = a; b < nf; b++) {
+            st.pair_a[pidx(a, b)] = a;
+            st.pair_b[pidx(a, b)] = b;
+        }
+    st.obs_pt.resize(P->n_obs);
+    std::vector<int> cnt(npairs + 1, 0);
+    std::vector<std::pair<int, int>> sl;  // (kf, slot) of one landmark, free keyframes only
+    const bool idp = P->variant == VBA_VARIANT_PRV_IDP;
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<int> fill;
+        if (pass == 1) {
+            st.item_begin.assign(npairs + 1, 0);
+            for (int i = 0; i < npairs; i++) st.item_begin[i + 1] = st.item_begin[i] + cnt[i];
+            st.items.resize(3 * (size_t)st.item_begin[npairs]);
+            fill.assign(st.item_begin.begin(), st.item_begin.end() - 1);
+        }
+        for (int p = 0; p < P->n_pt; p++) {
+            sl.clear();
+            const int o0 = P->pt_obs_begin[p], o1 = P->pt_obs_begin[p + 1];
+            if (o0 > o1 || o0 < 0 || o1 > P->n_obs) return fail(h, "pt_obs_begin is not a valid CSR");
+            if (idp) {
+                const int rf = P->pt_ref_kf[p];
+                if (rf < 0 || rf >= P->n_kf) return fail(h, "pt_ref_kf out of range");
+                if (rf < nf) sl.push_back({rf, -1});
+            }
+            for (int o = o0; o < o1; o++) {
+                const int kf = P->obs_kf[o];
+                if (kf < 0 || kf >= P->n_kf) return fail(h, "obs_kf out of range");
+                if (idp && kf == P->pt_ref_kf[p]) return fail(h, "observation from the reference keyframe is not an edge");
+                st.obs_pt[o] = p;
+                if (kf < nf) sl.push_back({kf, o});
+            }
+            std::sort(sl.begin(), sl.end());
+            for (size_t i = 1; i < sl.size(); i++)
+                if (sl[i].first == sl[i - 1].first) return fail(h, "a landmark is observed twice from one keyframe");
+            for (size_t i1 = 0; i1 < sl.size(); i1++)
+                for (size_t i2 = i1; i2 < sl.size(); i2++) {
+                    const int pi = pidx(sl[i1].first, sl[i2].first);
+                    if (pass == 0) cnt[pi]++;
+                    else {
+                        int* it = &st.items[3 * (size_t)fill[pi]++];
+                        it[0] = p; it[1] = sl[i1].second; it[2] = sl[i2].second;
+                    }
+                }
+        }
+    }
+    // IMU edges per block pair
+    std::vector<std::vector<std::pair<int, int>>> pl(npairs);
+    const int nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
+    for (int k = 0; k < nimu; k++) {
+        const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
+        if (i < 0 || j < 0 || i >= P->n_kf || j >= P->n_kf || i == j) return fail(h, "imu keyframe index out of range");
+        if (i < nf) pl[pidx(i, i)].push_back({k, 0});
+        if (j < nf) pl[pidx(j, j)].push_back({k, 3});
+        if (i < nf && j < nf) {
+            if (i < j) pl[pidx(i, j)].push_back({k, 2});
+            else pl[pidx(j, i)].push_back({k, 1});
+        }
+    }
+    st.pimu_begin.assign(npairs + 1, 0);
+    for (int i = 0; i < npairs; i++) {
+        st.pimu_begin[i + 1] = st.pimu_begin[i] + (int)pl[i].size();
+        for (auto& e : pl[i]) { st.pimu.push_back(e.first); st.pimu.push_back(e.second); }
+    }
+    return 0;
+}
+
+template <typename T>
+int h2d(Handle* h, int id, const std::vector<T>& v) {
+    HIPCHK(h, h->buf[id].ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
+    if (!v.empty()) HIPCHK(h, hipMemcpyAsync(h->buf[id].p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+int dalloc(Handle* h, int id, size_t bytes) {
+    HIPCHK(h, h->buf[id].ensure(std::max<size_t>(bytes, 16)));
+    return 0;
+}
+
+void quat_to_R_host(const double* q, double* R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+int do_upload(Handle* h, int n, vba_problem* const* probs) {
+    if (n <= 0) return fail(h, "empty batch");
+    HIPCHK(h, hipSetDevice(h->device));
+    h->uploaded = false;
+    h->n_win = n;
+    h->desc.assign(n, WinDesc());
+    std::vector<double> pose, vel, bias, pt, uv, ow, meas, info;
+    std::vector<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
+    size_t S_tot = 0;
+    int kf0 = 0, pt0 = 0, obs0 = 0, imu0 = 0, pair0 = 0, item0 = 0, pimu0 = 0, vec0 = 0, part0 = 0;
+    h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
+    h->max_its[0] = h->max_its[1] = 0;
+    for (int w = 0; w < n; w++) {
+        const vba_problem* P = probs[w];
+        if (!P) return fail(h, "null problem");
+        if (P->variant != VBA_VARIANT_PRV_IDP || P->algo != VBA_ALGO_GN)
+            return fail(h, "this build of the HIP backend implements variant 2 (PR/V/Bias + IDP) with Gauss-Newton");
+        if (P->n_kf_free <= 0 || P->n_kf_free > P->n_kf || P->n_pt < 0 || P->n_obs < 0) return fail(h, "bad sizes");
+        if (w > 0 && (P->variant != probs[0]->variant || P->algo != probs[0]->algo)) return fail(h, "mixed batch");
+        if (P->its_stage1 > 30 || P->its_stage2 > 30 || P->its_stage1 < 0 || P->its_stage2 < 0) return fail(h, "its out of range");
+        WinDesc& d = h->desc[w];
+        d.variant = P->variant; d.algo = P->algo;
+        d.n_kf = P->n_kf; d.n_free = P->n_kf_free; d.n_pt = P->n_pt; d.n_obs = P->n_obs;
+        d.n_imu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
+        d.pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
+        d.np = d.pdim * d.n_free;
+        d.nS = ((d.np + VBA_NB - 1) / VBA_NB) * VBA_NB;
+        d.nb = d.nS / VBA_NB;
+        d.its[0] = P->its_stage1; d.its[1] = P->its_stage2;
+        d.kf0 = kf0; d.pt0 = pt0; d.obs0 = obs0; d.imu0 = imu0;
+        d.pair0 = pair0; d.n_pairs = d.n_free * (d.n_free + 1) / 2;
+        d.item0 = item0; d.pimu0 = pimu0; d.vec0 = vec0; d.part0 = part0;
+        d.n_part_lin = (d.n_pt + 63) / 64;
+        d.S0 = (long long)S_tot;
+        for (int i = 0; i < 4; i++) d.K[i] = P->K[i];
+        quat_to_R_host(P->T_cb + 3, d.Rcb);
+        for (int i = 0; i < 3; i++) { d.tcb[i] = P->T_cb[i]; d.g[i] = P->g_w[i]; }
+        d.inv_bg = P->inv_bg_rw2; d.inv_ba = P->inv_ba_rw2;
+        d.hub_vis = P->huber_vis; d.hub_prv = P->huber_prv; d.hub_bias = P->huber_bias;
+        d.chi2_th = P->chi2_th; d.depth_min = P->depth_min; d.rho_min = P->rho_min;
+        Structure st;
+        if (build_structure(h, P, st)) return -1;
+        pose.insert(pose.end(), P->kf_pose, P->kf_pose + 7 * (size_t)d.n_kf);
+        if (P->kf_vel) vel.insert(vel.end(), P->kf_vel, P->kf_vel + 3 * (size_t)d.n_kf);
+        else vel.insert(vel.end(), 3 * (size_t)d.n_kf, 0.0);
+        if (P->kf_bias) bias.insert(bias.end(), P->kf_bias, P->kf_bias + 12 * (size_t)d.n_kf);
+        else bias.insert(bias.end(), 12 * (size_t)d.n_kf, 0.0);
+        pt.insert(pt.end(), P->pt, P->pt + 3 * (size_t)d.n_pt);
+        if (P->pt_ref_kf) ptref.insert(ptref.end(), P->pt_ref_kf, P->pt_ref_kf + d.n_pt);
+        else ptref.insert(ptref.end(), d.n_pt, 0);
+        ptobs.insert(ptobs.end(), P->pt_obs_begin, P->pt_obs_begin + d.n_pt + 1);
+        obskf.insert(obskf.end(), P->obs_kf, P->obs_kf + d.n_obs);
+        obspt.insert(obspt.end(), st.obs_pt.begin(), st.obs_pt.end());
+        uv.insert(uv.end(), P->obs_uv, P->obs_uv + 2 * (size_t)d.n_obs);
+        ow.insert(ow.end(), P->obs_w, P->obs_w + d.n_obs);
+        if (d.n_imu) {
+            imui.insert(imui.end(), P->imu_kf_i, P->imu_kf_i + d.n_imu);
+            imuj.insert(imuj.end(), P->imu_kf_j, P->imu_kf_j + d.n_imu);
+            meas.insert(meas.end(), P->imu_meas, P->imu_meas + 61 * (size_t)d.n_imu);
+            info.insert(info.end(), P->imu_info_prv, P->imu_info_prv + 81 * (size_t)d.n_imu);
+        }
+        pair_a.insert(pair_a.end(), st.pair_a.begin(), st.pair_a.end());
+        pair_b.insert(pair_b.end(), st.pair_b.begin(), st.pair_b.end());
+        item_begin.insert(item_begin.end(), st.item_begin.begin(), st.item_begin.end());
+        items.insert(items.end(), st.items.begin(), st.items.end());
+        pimu_begin.insert(pimu_begin.end(), st.pimu_begin.begin(), st.pimu_begin.end());
+        pimu.insert(pimu.end(), st.pimu.begin(), st.pimu.end());
+        kf0 += d.n_kf; pt0 += d.n_pt; obs0 += d.n_obs; imu0 += d.n_imu;
+        pair0 += d.n_pairs; item0 += (int)(st.items.size() / 3); pimu0 += (int)(st.pimu.size() / 2);
+        vec0 += d.nS;
+        const int obs_blk = (d.n_obs + 63) / 64;
+        part0 += std::max(d.n_part_lin, 2 * obs_blk) + 2;
+        S_tot += (size_t)d.nS * d.nS;
+        h->max_pt_blk = std::max(h->max_pt_blk, d.n_part_lin);
+        h->max_imu = std::max(h->max_imu, d.n_imu);
+        h->max_pairs = std::max(h->max_pairs, d.n_pairs);
+        h->max_nb = std::max(h->max_nb, d.nb);
+        h->max_obs_blk = std::max(h->max_obs_blk, obs_blk);
+        h->max_kf_blk = std::max(h->max_kf_blk, (d.n_kf + 63) / 64);
+        h->max_ns_blk = std::max(h->max_ns_blk, (d.nS + 63) / 64);
+        h->max_nS = std::max(h->max_nS, d.nS);
+        h->max_its[0] = std::max(h->max_its[0], d.its[0]);
+        h->max_its[1] = std::max(h->max_its[1], d.its[1]);
+    }
+    h->algo = probs[0]->algo;
+    h->variant = probs[0]->variant;
+    // pads of S: identity on the padded diagonal, written once (the solve never touches them)
+    if (h2d(h, BUF_DESC, h->desc)) return -1;
+    if (dalloc(h, BUF_CTRL, sizeof(WinCtrl) * n)) return -1;
+    if (h2d(h, BUF_POSE0, pose) || h2d(h, BUF_VEL0, vel) || h2d(h, BUF_BIAS0, bias) || h2d(h, BUF_PT0, pt)) return -1;
+    if (dalloc(h, BUF_POSE, pose.size() * 8) || dalloc(h, BUF_VEL, vel.size() * 8) || dalloc(h, BUF_BIAS, bias.size() * 8)) return -1;
+    if (dalloc(h, BUF_POSEBK, pose.size() * 8) || dalloc(h, BUF_VELBK, vel.size() * 8) || dalloc(h, BUF_BIASBK, bias.size() * 8)) return -1;
+    if (dalloc(h, BUF_KFR, (size_t)kf0 * 12 * 8) || dalloc(h, BUF_PT, pt.size() * 8) || dalloc(h, BUF_PTBK, pt.size() * 8)) return -1;
+    if (h2d(h, BUF_PTREF, ptref) || h2d(h, BUF_PTOBS, ptobs) || h2d(h, BUF_OBSKF, obskf) || h2d(h, BUF_OBSPT, obspt)) return -1;
+    if (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow)) return -1;
+    if (dalloc(h, BUF_LVL, (size_t)obs0) || dalloc(h, BUF_CHI2E, (size_t)obs0 * 8) || dalloc(h, BUF_DEPTH, (size_t)obs0 * 8)) return -1;
+    if (dalloc(h, BUF_EREC, (size_t)obs0 * VBA_EREC * 8) || dalloc(h, BUF_PREC, (size_t)pt0 * VBA_PREC * 8)) return -1;
+    if (h2d(h, BUF_IMUI, imui) || h2d(h, BUF_IMUJ, imuj) || h2d(h, BUF_IMUMEAS, meas) || h2d(h, BUF_IMUINFO, info)) return -1;
+    if (dalloc(h, BUF_IMUH, (size_t)imu0 * VBA_IMUH * 8) || dalloc(h, BUF_IMUCHI, (size_t)imu0 * 4 * 8)) return -1;
+    if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
+    if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
+    if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b) || h2d(h, BUF_ITEMBEG, item_begin) || h2d(h, BUF_ITEMS, items)) return -1;
+    if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu)) return -1;
+    if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
+    // S: zero everything once, identity on the pads
+    HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf[BUF_VEC].p, 0, (size_t)vec0 * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf[BUF_BPOSE].p, 0, (size_t)vec0 * 16, h->stream));
+    {
+        std::vector<double> one(1, 1.0);
+        for (int w = 0; w < n; w++) {
+            const WinDesc& d = h->desc[w];
+            for (int i = d.np; i < d.nS; i++)
+                HIPCHK(h, hipMemcpyAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)i * d.nS + i, one.data(), 8, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    Batch& B = h->B;
+    B.desc = dp<WinDesc>(h, BUF_DESC); B.ctrl = dp<WinCtrl>(h, BUF_CTRL); B.n_win = n;
+    B.pose = dp<double>(h, BUF_POSE); B.vel = dp<double>(h, BUF_VEL); B.bias = dp<double>(h, BUF_BIAS); B.kfR = dp<double>(h, BUF_KFR);
+    B.pose0 = dp<double>(h, BUF_POSE0); B.vel0 = dp<double>(h, BUF_VEL0); B.bias0 = dp<double>(h, BUF_BIAS0);
+    B.pose_bk = dp<double>(h, BUF_POSEBK); B.vel_bk = dp<double>(h, BUF_VELBK); B.bias_bk = dp<double>(h, BUF_BIASBK);
+    B.pt = dp<double>(h, BUF_PT); B.pt0 = dp<double>(h, BUF_PT0); B.pt_bk = dp<double>(h, BUF_PTBK);
+    B.pt_ref = dp<int>(h, BUF_PTREF); B.pt_obs_begin = dp<int>(h, BUF_PTOBS);
+    B.obs_kf = dp<int>(h, BUF_OBSKF); B.obs_pt = dp<int>(h, BUF_OBSPT);
+    B.obs_uv = dp<double>(h, BUF_OBSUV); B.obs_w = dp<double>(h, BUF_OBSW);
+    B.lvl = dp<unsigned char>(h, BUF_LVL); B.chi2_e = dp<double>(h, BUF_CHI2E); B.depth_e = dp<double>(h, BUF_DEPTH);
+    B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC);
+    B.imu_i = dp<int>(h, BUF_IMUI); B.imu_j = dp<int>(h, BUF_IMUJ);
+    B.imu_meas = dp<double>(h, BUF_IMUMEAS); B.imu_info = dp<double>(h, BUF_IMUINFO);
+    B.imuH = dp<double>(h, BUF_IMUH); B.imu_chi = dp<double>(h, BUF_IMUCHI);
+    B.S = dp<double>(h, BUF_S); B.vec = dp<double>(h, BUF_VEC); B.bpose = dp<double>(h, BUF_BPOSE);
+    B.var_act = dp<int>(h, BUF_VARACT);
+    B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
+    B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS);
+    B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
+    B.part = dp<double>(h, BUF_PART);
+    B.stop_word = h->stop_dev;
+    B.out_outlier = dp<unsigned char>(h, BUF_OUTL); B.out_chi2 = dp<double>(h, BUF_OUTCHI);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->uploaded = true;
+    h->ran = false;
+    return 0;
+}
+
+// ---- the launch schedule ------------------------------------------------------------------------------
+void enqueue_solve_iteration(Handle* h) {
+    const Batch& B = h->B;
+    const int n = h->n_win;
+    {
+        ProfScope ps(h, VBA_PROF_SCHUR);
+        hipLaunchKernelGGL(k_schur, dim3(h->max_pairs, n), dim3(64), 0, h->stream, B, h->max_pairs);
+    }
+    {
+        ProfScope ps(h, VBA_PROF_FACTOR);
+        for (int k = 0; k < h->max_nb; k++) {
+            const int m = h->max_nb - k - 1;
+            hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (m + 1) / 2), n), dim3(64), 0, h->stream, B, k);
+            if (m > 0) hipLaunchKernelGGL(k_chol_syrk, dim3(m, m, n), dim3(64), 0, h->stream, B, k);
+        }
+    }
+    {
+        ProfScope ps(h, VBA_PROF_TRSV);
+        const size_t shm = ((size_t)h->max_nS + 256 + 32 * 33) * sizeof(double);
+        hipLaunchKernelGGL(k_trsv, dim3(n), dim3(256), shm, h->stream, B);
+    }
+    {
+        ProfScope ps(h, VBA_PROF_UPDATE);
+        hipLaunchKernelGGL(k_update, dim3(h->max_pt_blk + h->max_kf_blk, n), dim3(64), 0, h->stream, B, h->max_pt_blk);
+    }
+}
+
+void enqueue_lin(Handle* h, int mode) {
+    ProfScope ps(h, VBA_PROF_LINEARIZE);
+    hipLaunchKernelGGL(k_lin, dim3(h->max_pt_blk + h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
+}
+
+int do_run(Handle* h, const volatile int* stop_flag) {
+    if (!h->uploaded) return fail(h, "vba_batch_run before vba_batch_upload");
+    HIPCHK(h, hipSetDevice(h->device));
+    const Batch& B = h->B;
+    const int n = h->n_win;
+    *h->stop_host = (stop_flag && *stop_flag) ? 1 : 0;
+    h->evts.clear();
+    h->evt_used = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    if (h->profile) {
+        ev_begin = get_evt(h);
+        ev_end = get_evt(h);
+        (void)hipEventRecord(ev_begin, h->stream);
+    }
+    const int big_blk = std::max(std::max(h->max_kf_blk, h->max_pt_blk), h->max_obs_blk);
+    {
+        ProfScope ps(h, VBA_PROF_MISC);
+        hipLaunchKernelGGL(k_reset, dim3(big_blk, n), dim3(64), 0, h->stream, B);
+    }
+    for (int stage = 0; stage < 2; stage++) {
+        {
+            ProfScope ps(h, VBA_PROF_MISC);
+            hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, n), dim3(64), 0, h->stream, B, stage);
+            if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, n), dim3(64), 0, h->stream, B);
+            hipLaunchKernelGGL(k_stage_mark, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
+        }
+        for (int it = 0; it < h->max_its[stage]; it++) {
+            enqueue_lin(h, LIN_FULL);
+            {
+                ProfScope ps(h, VBA_PROF_CONTROL);
+                hipLaunchKernelGGL(k_ctrl_gn, dim3(n), dim3(64), 0, h->stream, B, 0);
+            }
+            enqueue_solve_iteration(h);
+        }
+        enqueue_lin(h, LIN_ERR);
+        {
+            ProfScope ps(h, VBA_PROF_CONTROL);
+            hipLaunchKernelGGL(k_ctrl_gn, dim3(n), dim3(64), 0, h->stream, B, 1);
+        }
+    }
+    {
+        ProfScope ps(h, VBA_PROF_MISC);
+        hipLaunchKernelGGL(k_final_edges, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
+        hipLaunchKernelGGL(k_final_sum, dim3(n), dim3(64), 0, h->stream, B);
+    }
+    if (h->profile) (void)hipEventRecord(ev_end, h->stream);
+    HIPCHK(h, hipGetLastError());
+    // wait, forwarding the caller's stop flag (g2o forceStopFlag) into the device-visible word
+    hipEvent_t done = get_evt(h);
+    HIPCHK(h, hipEventRecord(done, h->stream));
+    if (stop_flag) {
+        while (hipEventQuery(done) == hipErrorNotReady) {
+            if (*stop_flag) *h->stop_host = 1;
+            std::this_thread::yield();
+        }
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->hctrl.resize(n);
+    HIPCHK(h, hipMemcpy(h->hctrl.data(), B.ctrl, sizeof(WinCtrl) * n, hipMemcpyDeviceToHost));
+    if (h->profile) {
+        vba_profile& pf = h->prof;
+        memset(&pf, 0, sizeof pf);
+        for (auto& e : h->evts) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e.a, e.b);
+            pf.ms[e.cls] += ms;
+            pf.launches[e.cls] += 1;
+        }
+        float tot = 0;
+        (void)hipEventElapsedTime(&tot, ev_begin, ev_end);
+        pf.total_ms = tot;
+        // algorithmic bytes: 32 B observation record + 36 B landmark per linearisation pass;
+        // reduced system written once and read once per solve
+        for (int w = 0; w < n; w++) {
+            const WinDesc& d = h->desc[w];
+            const WinCtrl& c = h->hctrl[w];
+            double passes = 0, solves = 0;
+            for (int s = 0; s < 2; s++)
+                if (c.its_done[s] > 0) { passes += c.its_done[s] + 1; solves += c.its_done[s]; }
+            pf.bytes[VBA_PROF_LINEARIZE] += passes * (32.0 * d.n_obs + 36.0 * d.n_pt + 432.0 * d.n_free);
+            pf.bytes[VBA_PROF_SCHUR] += solves * ((double)d.np * d.np * 8.0);
+            pf.bytes[VBA_PROF_FACTOR] += solves * ((double)d.np * d.np * 8.0);
+        }
+    }
+    h->ran = true;
+    return 0;
+}
+
+int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* out) {
+    if (!h->ran) return fail(h, "vba_batch_download before vba_batch_run");
+    if (n != h->n_win) return fail(h, "window count mismatch");
+    HIPCHK(h, hipSetDevice(h->device));
+    const Batch& B = h->B;
+    for (int w = 0; w < n; w++) {
+        const WinDesc& d = h->desc[w];
+        const WinCtrl& c = h->hctrl[w];
+        vba_problem* P = inout ? inout[w] : nullptr;
+        vba_result* R = out ? out[w] : nullptr;
+        if (P && c.status != VBA_ABORTED_BEFORE) {
+            HIPCHK(h, hipMemcpy(P->kf_pose, B.pose + 7 * (size_t)d.kf0, 56 * (size_t)d.n_free, hipMemcpyDeviceToHost));
+            if (d.pdim == 15) {
+                if (P->kf_vel) HIPCHK(h, hipMemcpy(P->kf_vel, B.vel + 3 * (size_t)d.kf0, 24 * (size_t)d.n_free, hipMemcpyDeviceToHost));
+                if (P->kf_bias) HIPCHK(h, hipMemcpy(P->kf_bias, B.bias + 12 * (size_t)d.kf0, 96 * (size_t)d.n_free, hipMemcpyDeviceToHost));
+            }
+            if (d.n_pt) HIPCHK(h, hipMemcpy(P->pt, B.pt + 3 * (size_t)d.pt0, 24 * (size_t)d.n_pt, hipMemcpyDeviceToHost));
+        }
+        if (R) {
+            R->chi2_vis = c.chi2_vis; R->chi2_prv = c.chi2_prv; R->chi2_bias = c.chi2_bias;
+            R->its_done[0] = c.its_done[0]; R->its_done[1] = c.its_done[1];
+            R->n_outliers = c.n_outliers; R->status = c.status;
+            R->n_trace = c.n_trace;
+            for (int i = 0; i < c.n_trace && i < VBA_TRACE_MAX; i++) R->chi2_trace[i] = c.trace[i];
+            R->lambda_final = c.lambda;
+            if (c.status != VBA_ABORTED_BEFORE && d.n_obs) {
+                if (R->obs_outlier) HIPCHK(h, hipMemcpy(R->obs_outlier, B.out_outlier + d.obs0, (size_t)d.n_obs, hipMemcpyDeviceToHost));
+                if (R->obs_chi2) HIPCHK(h, hipMemcpy(R->obs_chi2, B.out_chi2 + d.obs0, 8 * (size_t)d.n_obs, hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vba_create(int device, void** handle) {
+    if (!handle) return -1;
+    *handle = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return -2;  // no CPU fallback
+    Handle* h = new Handle();
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return -3;
+    }
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) { delete h; return -4; }
+    h->stop_host = reinterpret_cast<volatile int*>(hp);
+    *h->stop_host = 0;
+    void* dpw = nullptr;
+    if (hipHostGetDevicePointer(&dpw, hp, 0) != hipSuccess) { delete h; return -5; }
+    h->stop_dev = reinterpret_cast<int*>(dpw);
+    memset(&h->prof, 0, sizeof h->prof);
+    *handle = h;
+    return 0;
+}
+
+int vba_destroy(void* handle) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& b : h->buf) b.release();
+    for (auto e : h->evt_pool) (void)hipEventDestroy(e);
+    if (h->stop_host) (void)hipHostFree((void*)h->stop_host);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+const char* vba_last_error(void* handle) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    return h ? h->err.c_str() : "null handle";
+}
+
+int vba_batch_upload(void* handle, int32_t n, vba_problem* const* problems) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    return do_upload(h, n, problems);
+}
+int vba_batch_run(void* handle, const volatile int* stop_flag) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    return do_run(h, stop_flag);
+}
+int vba_batch_download(void* handle, int32_t n, vba_problem* const* inout, vba_result* const* out) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    return do_download(h, n, inout, out);
+}
+
+int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile int* stop_flag) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h || !inout || !out) return -1;
+    if (stop_flag && *stop_flag) {  // src/Optimizer.cpp:453-455: return before anything is built
+        out->status = VBA_ABORTED_BEFORE;
+        out->its_done[0] = out->its_done[1] = 0;
+        out->n_outliers = 0; out->n_trace = 0;
+        out->chi2_vis = out->chi2_prv = out->chi2_bias = 0;
+        return 0;
+    }
+    vba_problem* ps[1] = {inout};
+    vba_result* rs[1] = {out};
+    if (do_upload(h, 1, ps)) return -1;
+    if (do_run(h, stop_flag)) return -1;
+    return do_download(h, 1, ps, rs);
+}
+
+int vba_set_profile(void* handle, int32_t enable) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    h->profile = enable != 0;
+    return 0;
+}
+int vba_get_profile(void* handle, vba_profile* out) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h || !out) return -1;
+    *out = h->prof;
+    return 0;
+}
+
+}  // extern "C"

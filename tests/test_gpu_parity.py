@@ -1,0 +1,117 @@
+"""GPU parity tests proper: the HIP backend, called through its C-ABI, against the CPU oracle on the same
+seeded windows.  Bars (BASELINE.json north_star): final chi2 <= 1e-4 relative, keyframe translations
+<= 1e-6 m; on top: same iteration counts and the same outlier bitmap."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mc_slam_amd import abi, synth, backend
+
+pytestmark = pytest.mark.gpu
+
+CHI2_RTOL = 1e-4
+TRANS_ATOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ba():
+    b = backend.LocalBA(0)
+    yield b
+    b.close()
+
+
+def _check(p, q, r, qo, ro, tight=True):
+    assert r.status == ro.status
+    assert r.its_done == ro.its_done, (r.its_done, ro.its_done, r.chi2_trace, ro.chi2_trace)
+    assert abs(r.chi2_vis - ro.chi2_vis) <= CHI2_RTOL * max(ro.chi2_vis, 1e-12)
+    assert abs(r.chi2_prv - ro.chi2_prv) <= CHI2_RTOL * max(ro.chi2_prv, 1e-9)
+    assert abs(r.chi2_bias - ro.chi2_bias) <= CHI2_RTOL * max(ro.chi2_bias, 1e-9)
+    assert np.abs(q.kf_pose[:, :3] - qo.kf_pose[:, :3]).max() <= TRANS_ATOL
+    assert np.abs(q.kf_pose[:, 3:] - qo.kf_pose[:, 3:]).max() <= 1e-6
+    assert np.abs(q.kf_vel - qo.kf_vel).max() <= 1e-5
+    assert np.abs(q.pt - qo.pt).max() <= 1e-6 * max(1.0, np.abs(qo.pt).max())
+    assert (r.obs_outlier == ro.obs_outlier).all()
+    np.testing.assert_allclose(r.chi2_trace, ro.chi2_trace, rtol=1e-7)
+    np.testing.assert_allclose(r.obs_chi2, ro.obs_chi2, rtol=1e-5, atol=1e-7)
+    # fixed keyframes never move
+    assert (q.kf_pose[p.n_kf_free:] == p.kf_pose[p.n_kf_free:]).all()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31),
+    dict(n_kf=10, n_fixed=1, n_pt=400, n_obs=2000, seed=7),
+    dict(n_kf=12, n_fixed=3, n_pt=500, n_obs=2500, seed=8),     # co-observer fixed keyframes, fixed reference KFs
+    dict(n_kf=23, n_fixed=1, n_pt=1500, n_obs=9000, seed=9),    # np = 330: pads of the 32-blocked factorisation
+])
+def test_idp_window_matches_oracle(ba, oracle, kw):
+    p = synth.make_window(abi.VARIANT_PRV_IDP, **kw)
+    q, r = ba.solve(p)
+    qo, ro = oracle.solve(p)
+    _check(p, q, r, qo, ro)
+
+
+def test_c3_full_size_matches_oracle(ba, oracle):
+    p = synth.config_c3()
+    q, r = ba.solve(p)
+    qo, ro = oracle.solve(p)
+    _check(p, q, r, qo, ro)
+
+
+def test_noise_free_window_terminates_immediately(ba, oracle):
+    p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=8, n_fixed=1, n_pt=200, n_obs=900, seed=41, noise=False)
+    q, r = ba.solve(p)
+    assert r.its_done == (1, 1) and r.n_outliers == 0 and r.status == 0
+    assert np.abs(q.kf_pose - p.truth["pose"]).max() < 1e-6
+
+
+def test_stop_flag_semantics(ba, oracle):
+    p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=8, n_fixed=1, n_pt=200, n_obs=900, seed=40)
+    q, r = ba.solve(p, stop=C.c_int(1))
+    assert r.status == 2
+    assert (q.kf_pose == p.kf_pose).all() and (q.pt == p.pt).all()
+    # device-resident interface with the flag raised: also untouched
+    ba.upload([p]); ba.run(stop=C.c_int(1)); qs, rs = ba.download()
+    assert rs[0].status == 2 and (qs[0].kf_pose == p.kf_pose).all()
+
+
+def test_batch_of_ragged_windows_equals_single_solves(ba, oracle):
+    ps = [synth.make_window(abi.VARIANT_PRV_IDP, n_kf=8 + 2 * i, n_fixed=1, n_pt=200 + 50 * i, n_obs=900 + 300 * i, seed=50 + i)
+          for i in range(4)]
+    ba.upload(ps); ba.run(); qs, rs = ba.download()
+    for p, q, r in zip(ps, qs, rs):
+        q1, r1 = ba.solve(p)
+        assert r.its_done == r1.its_done and (r.obs_outlier == r1.obs_outlier).all()
+        assert (q.kf_pose == q1.kf_pose).all() and (q.pt == q1.pt).all()   # bit-reproducible
+        qo, ro = oracle.solve(p)
+        _check(p, q, r, qo, ro)
+
+
+def test_rerun_is_bit_reproducible(ba):
+    p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=10, n_fixed=1, n_pt=400, n_obs=2000, seed=7)
+    ba.upload([p]); ba.run(); q1, r1 = ba.download()
+    a = q1[0].kf_pose.copy(), q1[0].pt.copy(), r1[0].chi2_vis
+    ba.run(); q2, r2 = ba.download()
+    assert (a[0] == q2[0].kf_pose).all() and (a[1] == q2[0].pt).all() and a[2] == r2[0].chi2_vis
+
+
+def test_empty_and_degenerate_inputs(ba):
+    # a landmark with no edges, and a window without landmarks at all (IMU chain only)
+    p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31)
+    import copy
+    q = p.copy()
+    q.pt_obs_begin = p.pt_obs_begin.copy()
+    # drop all edges of landmark 0 by making its CSR row empty (shift is not needed: rows may leave gaps? no:
+    # rebuild compactly)
+    keep = np.ones(p.n_obs, dtype=bool); keep[p.pt_obs_begin[0]:p.pt_obs_begin[1]] = False
+    cnt = np.diff(p.pt_obs_begin); cnt[0] = 0
+    q.pt_obs_begin = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    q.obs_kf = p.obs_kf[keep].copy(); q.obs_uv = p.obs_uv[keep].copy(); q.obs_w = p.obs_w[keep].copy()
+    qq, r = ba.solve(q)
+    assert r.status == 0 and qq.pt[0, 0] == p.pt[0, 0]
+    # error path: duplicate observation from one keyframe is rejected with a message, not a crash
+    bad = p.copy(); bad.obs_kf = p.obs_kf.copy()
+    o0 = p.pt_obs_begin[0]
+    bad.obs_kf[o0 + 1] = bad.obs_kf[o0]
+    with pytest.raises(RuntimeError, match="observed twice"):
+        ba.solve(bad)
