@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- LocalBA windows/sec on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (the whole two-stage LocalBAPRVIDP solve, src/Optimizer.cpp:458-517 of
+the reference) over one BATCH of synthetic windows per GPU.  Workload at every N: BASELINE.json configs[2]
+(50 KF = 49 free + fixed predecessor / 5 000 inverse-depth landmarks / 30 000 EdgePRIDP + 49 PRV + 49 bias
+edges, Gauss-Newton 5+10), `--batch` windows per GPU, inputs already resident in HBM when the timed region
+starts (vba_batch_upload before, vba_batch_run timed).  Weak scaling: every rank solves its own batch, no
+data-path collective (windows are independent); torch.distributed (RCCL) only carries the
+barrier and the max-over-ranks time.
+
+One JSON line on rank 0, with `roofline` (dominant kernel class, HIP events on the backend's own stream) and
+`cpu_baseline` (the CPU oracle = restatement of the reference's g2o path, 1 core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="windows per GPU per step")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct seeded windows generated per rank (cycled to fill the batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+
+    from mc_slam_amd import synth, backend
+
+    # synthetic windows of configs[2]; seeds 100.. per BASELINE.md (rank r uses 100 + 1000 r + i)
+    wins = [synth.config_c3(seed=100 + 1000 * rank + i) for i in range(min(args.distinct, args.batch))]
+    batch = [wins[i % len(wins)] for i in range(args.batch)]
+    ba = backend.LocalBA(local_rank)
+    ba.upload(batch)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ba.run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ba.run()          # vba_batch_run returns after the stream has drained
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_windows = args.batch * args.steps * world
+    value = total_windows / dt
+
+    out = None
+    if rank == 0:
+        # roofline of the dominant kernel class: a separate profiled run (HIP events around every launch of the
+        # class, on the backend's stream), never mixed into `value`
+        ba.set_profile(True)
+        ba.run()
+        pf = ba.get_profile()
+        ba.set_profile(False)
+        _, res = ba.download()
+        classes = {k: v for k, v in pf.items() if k != "total_ms"}
+        dom = max(classes, key=lambda k: classes[k]["ms"])
+        its = [sum(r.its_done) for r in res]
+        # algorithmic work of the dominant class
+        n_p = 15 * batch[0].n_kf_free
+        solves = float(sum(its))
+        if dom in ("factor", "trsv", "schur"):
+            # dense FP64 factorisation of the reduced system: n^3/3 flop per solve; its HBM floor is the matrix
+            # read + written once (n_p^2 * 8 B * 2)
+            alg_bytes = solves * 2.0 * n_p * n_p * 8.0
+        else:
+            alg_bytes = classes[dom]["bytes"]
+        dur_s = classes[dom]["ms"] * 1e-3
+        launches = max(1, classes[dom]["launches"])
+        achieved = alg_bytes / dur_s / 1e9 if dur_s > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": None,
+                    "avg_launch_ms": classes[dom]["ms"] / launches, "launches": launches,
+                    "class_ms": {k: round(v["ms"], 4) for k, v in classes.items() if v["launches"]},
+                    "profiled_total_ms": pf["total_ms"]}
+        if dom == "factor":
+            flops = solves * (n_p ** 3) / 3.0
+            roofline["fp64_tflops"] = flops / dur_s / 1e12
+            roofline["fp64_peak_tflops"] = 78.6
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            import oracle_lib
+            oracle_lib.lib()
+            n_done, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_seconds and n_done < 4 * len(wins):
+                t1 = time.perf_counter()
+                oracle_lib.solve(wins[n_done % len(wins)], solver_mode=1)
+                t_cpu += time.perf_counter() - t1
+                n_done += 1
+            cpu = {"value": n_done / t_cpu, "unit": "windows/s", "cores": 1, "kind": "port",
+                   "sample": "%d solves of the same C3 windows, single thread, oracle/libvba_oracle.so (restatement of "
+                             "the reference's g2o path, -O3; the reference itself cannot be built here)" % n_done}
+        out = {
+            "metric": "LocalBA windows/sec (50 KF, 5k pts, 30k obs, IMU edges)", "value": value, "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: LocalBAPRVIDP window, 50 KF (49 free) / 5000 IDP landmarks / "
+                                   "30000 EdgePRIDP + 49 PRV + 49 bias edges, GN 5+10",
+                       "windows_per_gpu_per_step": args.batch, "distinct_windows": len(wins),
+                       "parallelism": "independent windows sharded %d per GPU, no data-path collective" % args.batch,
+                       "mean_outer_iterations": float(np.mean(its))},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
