@@ -36,6 +36,9 @@ struct WinDesc {
     int vec0;       // offset into rhs/x vectors (nS slots per window)
     int part0;      // offset into the chi2 partial array
     int n_part_lin; // point blocks of this window in the linearise launch
+    int tl_step0;   // offset of this window's step_begin / pan_begin rows (nb + 1 entries each)
+    int tl_pair0;   // offset into the tile-pair list
+    int tl_pan0;    // offset into the panel-tile list
     int pad0;
     long long S0;   // offset (doubles) into S
     double K[4];
@@ -211,6 +214,19 @@ DEVI void so3inv(const double* a, double* o) {
     o[0] = -a[0]; o[1] = -a[1]; o[2] = -a[2]; o[3] = a[3];
     qnorm(o);
 }
+// Position of local dof r of free keyframe a inside the reduced system.  VI variants order all V/Bias
+// blocks first (9 per keyframe, chain order) and all PR blocks last: the V/Bias part of the factor then
+// stays block-banded and whole 32x32 tiles of L are structurally zero (skipped by the tile lists).
+DEVI int vpos(const WinDesc& d, int a, int r) {
+    return d.pdim == 15 ? (r < 6 ? 9 * d.n_free + 6 * a + r : 9 * a + (r - 6)) : 6 * a + r;
+}
+DEVI double rl64(double v, int lane) {  // wave-uniform broadcast of one lane's double
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
 // Huber (robust_kernel_impl.cpp:78-91): returns rho(e), sets *w = rho'(e)
 DEVI double huber(double e, double delta, double* w) {
     const double dsqr = delta * delta;

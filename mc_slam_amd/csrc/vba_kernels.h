@@ -31,9 +31,13 @@ struct Batch {
     double *imuH, *imu_chi;  // imu_chi: [4] per edge: robust prv, robust bias, raw prv, raw bias
     // reduced system
     double *S, *vec, *bpose;
+    double *Lf, *yv;  // factor tiles and forward-substituted rhs (written out of place: S tiles are read by
+                      // other workgroups of the same launch)
     int* var_act;
     // structure (g2o buildStructure analogue, built on the host at upload)
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
+    // tile structure of the factor (symbolic factorisation on 32x32 tiles, built at upload)
+    const int *tl_step_begin, *tl_pairs, *tl_pan_begin, *tl_pan;
     double* part;
     const volatile int* stop_word;
     unsigned char* out_outlier;
@@ -123,20 +127,20 @@ __global__ void __launch_bounds__(64) k_stage_mark(Batch B) {
     if (t < d.n_obs && !B.lvl[d.obs0 + t]) {
         const int kf = B.obs_kf[d.obs0 + t];
         if (kf < d.n_free)
-            for (int i = 0; i < 6; i++) va[kf * d.pdim + i] = 1;
+            for (int i = 0; i < 6; i++) va[vpos(d, kf, i)] = 1;
         if (d.variant == 2) {
             const int rf = B.pt_ref[d.pt0 + B.obs_pt[d.obs0 + t]];
             if (rf < d.n_free)
-                for (int i = 0; i < 6; i++) va[rf * d.pdim + i] = 1;
+                for (int i = 0; i < 6; i++) va[vpos(d, rf, i)] = 1;
         }
     }
     if (t < d.n_imu) {
         const int i = B.imu_i[d.imu0 + t], j = B.imu_j[d.imu0 + t];
         if (i < d.n_free || j < d.n_free) {  // allVerticesFixed edges are dropped
             if (i < d.n_free)
-                for (int k = 0; k < 15; k++) va[i * 15 + k] = 1;
+                for (int k = 0; k < 15; k++) va[vpos(d, i, k)] = 1;
             if (j < d.n_free)
-                for (int k = 0; k < 15; k++) va[j * 15 + k] = 1;
+                for (int k = 0; k < 15; k++) va[vpos(d, j, k)] = 1;
         }
     }
 }
@@ -619,7 +623,7 @@ __global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
             const int ro = (role & 1) ? 15 : 0, co = (role & 2) ? 15 : 0;  // bit0: a is j ; bit1: b is j
             s += H[(ro + r) * 30 + co + col];
         }
-        const int gr = a * P + r, gc = b * P + col;
+        const int gr = vpos(d, a, r), gc = vpos(d, b, col);
         if (diag) {
             if (!va[gr] || !va[gc]) s = (r == col) ? 1.0 : 0.0;  // vertex outside the index mapping
             else if (r == col) s += lambda;                       // setLambda, block_solver.hpp:564-589
@@ -637,7 +641,7 @@ __global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
             sb += H[900 + ro + t];
             h += H[(ro + t) * 30 + ro + t];
         }
-        const int gr = a * P + t;
+        const int gr = vpos(d, a, t);
         const bool act = va[gr] != 0;
         vec[gr] = act ? (sb + s) : 0.0;   // reduced rhs = b_p - sum W Dinv b_l
         bpose[gr] = act ? sb : 0.0;       // unreduced b_p (LM computeScale)
@@ -646,154 +650,191 @@ __global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense reduced-system factorisation S = L L^T, right-looking, NB = 32, lock-step launches.
-// Restates LinearSolverEigen::solve (linear_solver_eigen.h:94-124) on the dense reduced system; the
-// right-hand side rides along as an extra row (forward substitution for free).
-// k_chol_panel(k): every workgroup factors the diagonal block redundantly in LDS, workgroup 0 stores it
-//                  and y_k; workgroup j>=0 solves two 32-row panels below it and updates their rhs rows.
-// k_chol_syrk(k) : trailing update A_ij -= L_ik L_jk^T on 32x32 tiles, j <= i.
+// Reduced-system factorisation S = L L^T on 32x32 tiles, right-looking, ONE launch per block column:
+// every workgroup (one wave) of step k owns one tile pair (I,J) of the trailing update and redoes, on its
+// own, the little work it depends on -- POTRF of the diagonal tile (registers + v_readlane broadcasts, no
+// LDS round trips on the critical path) and the triangular solves of the two panel tiles L_Ik, L_Jk -- then
+// applies C_IJ -= L_Ik L_Jk^T with v_mfma_f64_16x16x4_f64.  No inter-workgroup dependency inside a launch.
+// The right-hand side rides along as one more row of the panel solve (forward substitution for free).
+// Tiles that are structurally zero in L (V/Bias-first ordering) are not in the lists and never touched.
+// Restates LinearSolverEigen::solve (linear_solver_eigen.h:94-124) on the dense reduced system.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_chol_panel(Batch B, int k) {
-    __shared__ double Lk[32][33];
-    __shared__ double yk[32];
+__global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
+    __shared__ double Lk[32 * 33];
+    __shared__ double rd[32];
+    __shared__ double XI[32 * 34];
+    __shared__ double XJ[32 * 34];
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
     if (!c.active) return;
     if (k >= d.nb) return;
-    const int n = d.nS, t = threadIdx.x;
+    const int* sb = B.tl_step_begin + d.tl_step0;
+    const int npair = sb[k + 1] - sb[k];
+    const int bx = blockIdx.x;
+    if (bx >= (npair > 0 ? npair : 1)) return;
+    const bool has_pair = bx < npair;
+    int I = 0, J = 0;
+    if (has_pair) {
+        const int v = B.tl_pairs[d.tl_pair0 + sb[k] + bx];
+        I = v >> 16;
+        J = v & 0xffff;
+    }
+    const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
+    const int n = d.nS;
     double* S = B.S + d.S0;
+    double* Lf = B.Lf + d.S0;
     double* vec = B.vec + d.vec0;
-    const int m = d.nb - k - 1;                 // panel block rows below the diagonal
-    const int j = blockIdx.x;
-    if (j > 0 && 2 * j >= m) return;            // block j handles panel rows 2j, 2j+1
+    double* yv = B.yv + d.vec0;
     const size_t dk = (size_t)k * 32;
-    for (int q = t; q < 1024; q += 64) {
-        const int r = q >> 5, col = q & 31;
-        Lk[r][col] = (col <= r) ? S[(dk + r) * n + dk + col] : 0.0;
+    const bool diagp = has_pair && (I == J);
+    const bool rhs_lane = (!has_pair || diagp) && lane == 32;
+    const bool row_act = has_pair && (hi == 0 || !diagp);
+    // panel rows first: their loads are in flight while the diagonal tile is factored
+    double x[32];
+    {
+        const double* src = row_act ? (S + ((size_t)(hi ? J : I) * 32 + r) * n + dk) : (vec + dk);
+        const bool ld = row_act || rhs_lane;
+#pragma unroll
+        for (int q = 0; q < 32; q++) x[q] = ld ? src[q] : 0.0;
     }
-    if (t < 32) yk[t] = vec[dk + t];
-    __syncthreads();
-    // factor the diagonal block (lanes 0..31 own one row each)
+    double a[32];
+    const double* arow = S + (dk + r) * n + dk;
+#pragma unroll
+    for (int q = 0; q < 32; q++) a[q] = (q <= r) ? arow[q] : 0.0;
     bool bad = false;
+#pragma unroll
     for (int cc = 0; cc < 32; cc++) {
-        const double piv = Lk[cc][cc];
-        if (!(piv > 0.0)) bad = true;  // also catches NaN
+        const double piv = rl64(a[cc], cc);
+        bad = bad || !(piv > 0.0);
         const double dg = sqrt(piv);
-        __syncthreads();
-        if (t < 32 && t >= cc) Lk[t][cc] = (t == cc) ? dg : Lk[t][cc] / dg;
-        __syncthreads();
-        if (t < 32 && t > cc) {
-            const double l = Lk[t][cc];
-            for (int c2 = cc + 1; c2 <= t; c2++) Lk[t][c2] -= l * Lk[c2][cc];
+        const double rinv = 1.0 / dg;
+        const double l = (r == cc) ? dg : a[cc] * rinv;
+        a[cc] = l;
+#pragma unroll
+        for (int c2 = cc + 1; c2 < 32; c2++) a[c2] -= l * rl64(l, c2);
+    }
+    if (hi == 0) {
+#pragma unroll
+        for (int q = 0; q < 32; q++) Lk[r * 33 + q] = (q <= r) ? a[q] : 0.0;
+        double dgr = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; q++) dgr = (q == r) ? a[q] : dgr;
+        rd[r] = 1.0 / dgr;
+        if (bx == 0) {
+            double* lrow = Lf + (dk + r) * n + dk;
+#pragma unroll
+            for (int q = 0; q < 32; q++)
+                if (q <= r) lrow[q] = a[q];
         }
-        __syncthreads();
     }
-    // y_k = L_kk^-1 r_k
-    for (int cc = 0; cc < 32; cc++) {
-        if (t == cc) yk[cc] = yk[cc] / Lk[cc][cc];
-        __syncthreads();
-        if (t < 32 && t > cc) yk[t] -= Lk[t][cc] * yk[cc];
-        __syncthreads();
+    if (bx == 0 && lane == 0 && bad) c.chol_fail = 1;
+    __syncthreads();
+    // X L_kk^T = A  (row per lane, column-oriented so the 31-q updates of a step are independent)
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const double xq = x[q] * rd[q];
+        x[q] = xq;
+#pragma unroll
+        for (int c2 = q + 1; c2 < 32; c2++) x[c2] -= xq * Lk[c2 * 33 + q];
     }
-    if (j == 0) {
-        for (int q = t; q < 1024; q += 64) {
-            const int r = q >> 5, col = q & 31;
-            if (col <= r) S[(dk + r) * n + dk + col] = Lk[r][col];
+    if (bx == 0 && lane == 32) {
+#pragma unroll
+        for (int q = 0; q < 32; q++) yv[dk + q] = x[q];  // y_k
+    }
+    if (!has_pair) return;
+    double sy = 0.0;  // x_row . y_k ; y_k sits in lane 32 of a diagonal pair (wave-uniform control flow here)
+#pragma unroll
+    for (int q = 0; q < 32; q++) sy += x[q] * rl64(x[q], 32);
+    if (diagp && hi == 0) {
+        double* dst = Lf + ((size_t)I * 32 + r) * n + dk;
+#pragma unroll
+        for (int q = 0; q < 32; q++) dst[q] = x[q];  // L_Ik
+        vec[(size_t)I * 32 + r] -= sy;
+    }
+    {
+        double* X = hi ? XJ : XI;
+        if (hi == 0 || !diagp) {
+#pragma unroll
+            for (int q = 0; q < 32; q++) X[r * 34 + q] = x[q];
         }
-        if (t < 32) vec[dk + t] = yk[t];
-        if (t == 0 && bad) c.chol_fail = 1;
-    }
-    // panel rows: lanes 0..31 -> block row k+1+2j, lanes 32..63 -> k+2+2j
-    const int pi = 2 * j + (t >> 5);
-    if (pi < m) {
-        const int r = t & 31;
-        const size_t row = ((size_t)(k + 1 + pi)) * 32 + r;
-        double* A = S + row * n + dk;
-        double x[32];
-#pragma unroll
-        for (int cc = 0; cc < 32; cc++) x[cc] = A[cc];
-        double ry = vec[row];
-#pragma unroll
-        for (int cc = 0; cc < 32; cc++) {
-            double s = x[cc];
-#pragma unroll
-            for (int q = 0; q < cc; q++) s -= x[q] * Lk[cc][q];
-            s /= Lk[cc][cc];
-            x[cc] = s;
-            ry -= s * yk[cc];
-        }
-#pragma unroll
-        for (int cc = 0; cc < 32; cc++) A[cc] = x[cc];
-        vec[row] = ry;
-    }
-}
-
-__global__ void __launch_bounds__(64) k_chol_syrk(Batch B, int k) {
-    __shared__ double Li[32][33];
-    __shared__ double Lj[32][33];
-    const int w = blockIdx.z;
-    const WinDesc& d = B.desc[w];
-    if (!B.ctrl[w].active) return;
-    const int m = d.nb - k - 1;
-    const int bi = blockIdx.x, bj = blockIdx.y;
-    if (bi >= m || bj > bi) return;
-    const int n = d.nS, t = threadIdx.x;
-    double* S = B.S + d.S0;
-    const size_t ri = ((size_t)(k + 1 + bi)) * 32, rj = ((size_t)(k + 1 + bj)) * 32, ck = (size_t)k * 32;
-    for (int q = t; q < 1024; q += 64) {
-        const int r = q >> 5, col = q & 31;
-        Li[r][col] = S[(ri + r) * n + ck + col];
-        Lj[r][col] = S[(rj + r) * n + ck + col];
     }
     __syncthreads();
-    const int r = t & 31, h = t >> 5;
-    double acc[16];
+    const double* XJp = diagp ? XI : XJ;
+    const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
-    for (int q = 0; q < 16; q++) acc[q] = 0.0;
-    for (int kk = 0; kk < 32; kk++) {
-        const double av = Li[r][kk];
+    for (int ti = 0; ti < 2; ti++)
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc[q] += av * Lj[h * 16 + q][kk];
-    }
-    double* A = S + (ri + r) * n + rj + h * 16;
+        for (int tj = 0; tj < 2; tj++) {
+            if (diagp && tj > ti) continue;
+            double* C = S + ((size_t)I * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
+            d4_t acc;
 #pragma unroll
-    for (int q = 0; q < 16; q++) A[q] -= acc[q];
+            for (int i = 0; i < 4; i++) acc[i] = C[(size_t)(l4 + 4 * i) * n + l15];
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                const double av = -XI[(16 * ti + l15) * 34 + 4 * ks + l4];
+                const double bv = XJp[(16 * tj + l15) * 34 + 4 * ks + l4];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = acc[i];
+        }
 }
 
-// K_trsv: L^T x = y, one 256-thread workgroup per window, block column by block column from the bottom.
+// K_trsv: L^T x = y.  One 256-thread workgroup per window walks the block columns from the bottom: the
+// column's nonzero tiles are gathered by all four waves, the 32x32 triangular solve runs in wave 0 on
+// registers (column of L per lane, v_readlane broadcasts).
 __global__ void __launch_bounds__(256) k_trsv(Batch B) {
-    extern __shared__ double xs[];  // nS doubles + 8*32 partials + 32*33 diag block
+    extern __shared__ double xs[];  // nS doubles + 8*32 partials + 32*33 diagonal tile
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
     if (!B.ctrl[w].active) return;
     const int n = d.nS, t = threadIdx.x;
     double* part = xs + n;
-    double* Lk = part + 256;
-    const double* S = B.S + d.S0;
+    double* Lt = part + 256;
+    const double* S = B.Lf + d.S0;
     double* vec = B.vec + d.vec0;
-    for (int q = t; q < n; q += 256) xs[q] = vec[q];
+    const double* yv = B.yv + d.vec0;
+    const int* pb = B.tl_pan_begin + d.tl_step0;
+    const int* pan = B.tl_pan + d.tl_pan0;
+    for (int q = t; q < n; q += 256) xs[q] = yv[q];
     __syncthreads();
     const int cc = t & 31, rl = t >> 5;
     for (int k = d.nb - 1; k >= 0; k--) {
         const size_t dk = (size_t)k * 32;
         double s = 0.0;
-        for (int r = (k + 1) * 32 + rl; r < n; r += 8) s += S[(size_t)r * n + dk + cc] * xs[r];
+        for (int idx = pb[k]; idx < pb[k + 1]; idx++) {
+            const int I = pan[idx];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int row = I * 32 + rl + 8 * rr;
+                s += S[(size_t)row * n + dk + cc] * xs[row];
+            }
+        }
         part[rl * 32 + cc] = s;
-        for (int q = t; q < 1024; q += 256) Lk[(q >> 5) * 33 + (q & 31)] = S[(dk + (q >> 5)) * n + dk + (q & 31)];
+        for (int q = t; q < 1024; q += 256) Lt[(q >> 5) * 33 + (q & 31)] = S[(dk + (q >> 5)) * n + dk + (q & 31)];
         __syncthreads();
-        if (t < 32) {
-            double v = xs[dk + t];
-            for (int q = 0; q < 8; q++) v -= part[q * 32 + t];
-            xs[dk + t] = v;
+        if (t < 64) {
+            const int c = t & 31;
+            double v = xs[dk + c];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v -= part[q * 32 + c];
+            double col[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) col[j] = Lt[j * 33 + c];  // column c of L_kk (rows j >= c are the factor)
+            double dgc = 1.0;
+#pragma unroll
+            for (int j = 0; j < 32; j++) dgc = (j == c) ? col[j] : dgc;
+            const double rdc = 1.0 / dgc;
+#pragma unroll
+            for (int j = 31; j >= 0; j--) {
+                const double xj = rl64(v * rdc, j);
+                v = (c == j) ? xj : ((c < j) ? v - col[j] * xj : v);
+            }
+            if (t < 32) xs[dk + c] = v;
         }
         __syncthreads();
-        for (int c2 = 31; c2 >= 0; c2--) {  // L_kk^T x_k = v
-            if (t == c2) xs[dk + c2] = xs[dk + c2] / Lk[c2 * 33 + c2];
-            __syncthreads();
-            if (t < c2) xs[dk + t] -= Lk[c2 * 33 + t] * xs[dk + c2];
-            __syncthreads();
-        }
     }
     for (int q = t; q < n; q += 256) vec[q] = xs[q];
 }
@@ -820,7 +861,7 @@ __global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
         const int rf = B.pt_ref[gp];
         if (rf < d.n_free)
 #pragma unroll
-            for (int i = 0; i < 6; i++) cl -= pr[2 + i] * x[rf * P + i];
+            for (int i = 0; i < 6; i++) cl -= pr[2 + i] * x[vpos(d, rf, i)];
         const int* ob = B.pt_obs_begin + d.pt0 + w;
         for (int o = ob[p]; o < ob[p + 1]; o++) {
             const size_t go = d.obs0 + o;
@@ -828,7 +869,7 @@ __global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
             if (kf >= d.n_free) continue;
             const double* rec = B.erec + VBA_EREC * go;
 #pragma unroll
-            for (int i = 0; i < 6; i++) cl -= rec[24 + i] * x[kf * P + i];
+            for (int i = 0; i < 6; i++) cl -= rec[24 + i] * x[vpos(d, kf, i)];
         }
         const double lam = (d.algo == 1) ? c.lambda : 0.0;
         double rho = B.pt[3 * gp] + cl / (D + lam);
@@ -838,9 +879,10 @@ __global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
         const int a = (blockIdx.x - nblk_pt) * 64 + threadIdx.x;
         if (a >= d.n_free) return;
         const int* va = B.var_act + d.vec0;
-        const double* dx = x + a * P;
+        double dx[15];
+        for (int i = 0; i < P; i++) dx[i] = x[vpos(d, a, i)];
         const size_t gk = d.kf0 + a;
-        if (va[a * P]) {  // NavState::IncSmallPR, NavState.cpp:63-70
+        if (va[vpos(d, a, 0)]) {  // NavState::IncSmallPR, NavState.cpp:63-70
             double* T = B.pose + 7 * gk;
             T[0] += dx[0]; T[1] += dx[1]; T[2] += dx[2];
             double dq[4], qn[4];
@@ -850,9 +892,9 @@ __global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
             kf_cache(B, d, a);
         }
         if (P == 15) {
-            if (va[a * P + 6])
+            if (va[vpos(d, a, 6)])
                 for (int i = 0; i < 3; i++) B.vel[3 * gk + i] += dx[6 + i];
-            if (va[a * P + 9])
+            if (va[vpos(d, a, 9)])
                 for (int i = 0; i < 6; i++) B.bias[12 * gk + 6 + i] += dx[9 + i];
         }
     }

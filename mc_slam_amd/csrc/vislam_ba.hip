@@ -43,7 +43,7 @@ enum {
     BUF_DESC, BUF_CTRL, BUF_POSE, BUF_VEL, BUF_BIAS, BUF_KFR, BUF_POSE0, BUF_VEL0, BUF_BIAS0, BUF_POSEBK, BUF_VELBK,
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
     BUF_CHI2E, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
-    BUF_S, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
+    BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_N
 };
 
@@ -64,6 +64,8 @@ struct Handle {
     // launch geometry (maxima over the batch)
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
     int max_nS = 0, max_its[2] = {0, 0};
+    std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
+    double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
     int algo = 0, variant = 2;
     volatile int* stop_host = nullptr;  // pinned, device-visible
     int* stop_dev = nullptr;
@@ -127,7 +129,11 @@ struct ProfScope {
 // ---- structure build (g2o BlockSolver::buildStructure analogue, block_solver.hpp:143-295) -------------
 struct Structure {
     std::vector<int> pair_a, pair_b, item_begin, items, pimu_begin, pimu, obs_pt;
+    std::vector<int> step_begin, tpairs, pan_begin, pan;  // tile lists of the factorisation
+    std::vector<int> step_npairs;
 };
+
+int vpos_host(int pdim, int nf, int a, int r) { return pdim == 15 ? (r < 6 ? 9 * nf + 6 * a + r : 9 * a + (r - 6)) : 6 * a + r; }
 
 int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2;
@@ -199,6 +205,43 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         st.pimu_begin[i + 1] = st.pimu_begin[i] + (int)pl[i].size();
         for (auto& e : pl[i]) { st.pimu.push_back(e.first); st.pimu.push_back(e.second); }
     }
+    // symbolic factorisation on 32x32 tiles (the tile-level analogue of SimplicialLDLT::analyzePattern,
+    // linear_solver_eigen.h:147-152): which tiles of L can be nonzero under the V/Bias-first ordering
+    const int pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
+    const int np = pdim * nf, nS = ((np + VBA_NB - 1) / VBA_NB) * VBA_NB, nb = nS / VBA_NB;
+    std::vector<unsigned char> T((size_t)nb * nb, 0);
+    for (int i = 0; i < nb; i++) T[(size_t)i * nb + i] = 1;
+    for (int pi = 0; pi < npairs; pi++) {
+        const int a = st.pair_a[pi], b = st.pair_b[pi];
+        const bool vis = st.item_begin[pi + 1] > st.item_begin[pi];
+        const bool imu = st.pimu_begin[pi + 1] > st.pimu_begin[pi];
+        if (!vis && !imu && a != b) continue;
+        const int dim = (imu || a == b) ? pdim : 6;
+        for (int r = 0; r < dim; r++)
+            for (int cc = 0; cc < dim; cc++) {
+                const int ti = vpos_host(pdim, nf, a, r) / VBA_NB, tj = vpos_host(pdim, nf, b, cc) / VBA_NB;
+                T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)] = 1;
+            }
+    }
+    st.step_begin.assign(nb + 1, 0);
+    st.pan_begin.assign(nb + 1, 0);
+    st.step_npairs.assign(nb, 0);
+    std::vector<int> pk;
+    for (int k = 0; k < nb; k++) {
+        pk.clear();
+        for (int I = k + 1; I < nb; I++)
+            if (T[(size_t)I * nb + k]) pk.push_back(I);
+        for (int I : pk) st.tpairs.push_back((I << 16) | I);  // diagonal pairs first: pair 0 owns y_k
+        for (size_t i = 0; i < pk.size(); i++)
+            for (size_t j = 0; j < i; j++) {
+                st.tpairs.push_back((pk[i] << 16) | pk[j]);
+                T[(size_t)pk[i] * nb + pk[j]] = 1;  // fill
+            }
+        for (int I : pk) st.pan.push_back(I);
+        st.step_begin[k + 1] = (int)st.tpairs.size();
+        st.pan_begin[k + 1] = (int)st.pan.size();
+        st.step_npairs[k] = st.step_begin[k + 1] - st.step_begin[k];
+    }
     return 0;
 }
 
@@ -230,6 +273,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->desc.assign(n, WinDesc());
     std::vector<double> pose, vel, bias, pt, uv, ow, meas, info;
     std::vector<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
+    std::vector<int> tlstep, tlpair, tlpanb, tlpan;
+    h->step_grid.clear();
+    h->tile_updates = 0;
     size_t S_tot = 0;
     int kf0 = 0, pt0 = 0, obs0 = 0, imu0 = 0, pair0 = 0, item0 = 0, pimu0 = 0, vec0 = 0, part0 = 0;
     h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
@@ -264,6 +310,14 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         d.chi2_th = P->chi2_th; d.depth_min = P->depth_min; d.rho_min = P->rho_min;
         Structure st;
         if (build_structure(h, P, st)) return -1;
+        d.tl_step0 = (int)tlstep.size(); d.tl_pair0 = (int)tlpair.size(); d.tl_pan0 = (int)tlpan.size();
+        tlstep.insert(tlstep.end(), st.step_begin.begin(), st.step_begin.end());
+        tlpanb.insert(tlpanb.end(), st.pan_begin.begin(), st.pan_begin.end());
+        tlpair.insert(tlpair.end(), st.tpairs.begin(), st.tpairs.end());
+        tlpan.insert(tlpan.end(), st.pan.begin(), st.pan.end());
+        if ((int)h->step_grid.size() < d.nb) h->step_grid.resize(d.nb, 1);
+        for (int k = 0; k < d.nb; k++) h->step_grid[k] = std::max(h->step_grid[k], std::max(1, st.step_npairs[k]));
+        h->tile_updates += (double)st.tpairs.size();
         pose.insert(pose.end(), P->kf_pose, P->kf_pose + 7 * (size_t)d.n_kf);
         if (P->kf_vel) vel.insert(vel.end(), P->kf_vel, P->kf_vel + 3 * (size_t)d.n_kf);
         else vel.insert(vel.end(), 3 * (size_t)d.n_kf, 0.0);
@@ -322,6 +376,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (h2d(h, BUF_IMUI, imui) || h2d(h, BUF_IMUJ, imuj) || h2d(h, BUF_IMUMEAS, meas) || h2d(h, BUF_IMUINFO, info)) return -1;
     if (dalloc(h, BUF_IMUH, (size_t)imu0 * VBA_IMUH * 8) || dalloc(h, BUF_IMUCHI, (size_t)imu0 * 4 * 8)) return -1;
     if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
+    if (dalloc(h, BUF_LF, S_tot * 8) || dalloc(h, BUF_YV, (size_t)vec0 * 8)) return -1;
+    if (h2d(h, BUF_TLSTEP, tlstep) || h2d(h, BUF_TLPAIR, tlpair) || h2d(h, BUF_TLPANB, tlpanb) || h2d(h, BUF_TLPAN, tlpan)) return -1;
     if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
     if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b) || h2d(h, BUF_ITEMBEG, item_begin) || h2d(h, BUF_ITEMS, items)) return -1;
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu)) return -1;
@@ -329,6 +385,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     // S: zero everything once, identity on the pads
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_VEC].p, 0, (size_t)vec0 * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf[BUF_LF].p, 0, S_tot * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf[BUF_YV].p, 0, (size_t)vec0 * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_BPOSE].p, 0, (size_t)vec0 * 16, h->stream));
     {
         std::vector<double> one(1, 1.0);
@@ -353,6 +411,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.imu_meas = dp<double>(h, BUF_IMUMEAS); B.imu_info = dp<double>(h, BUF_IMUINFO);
     B.imuH = dp<double>(h, BUF_IMUH); B.imu_chi = dp<double>(h, BUF_IMUCHI);
     B.S = dp<double>(h, BUF_S); B.vec = dp<double>(h, BUF_VEC); B.bpose = dp<double>(h, BUF_BPOSE);
+    B.Lf = dp<double>(h, BUF_LF); B.yv = dp<double>(h, BUF_YV);
+    B.tl_step_begin = dp<int>(h, BUF_TLSTEP); B.tl_pairs = dp<int>(h, BUF_TLPAIR);
+    B.tl_pan_begin = dp<int>(h, BUF_TLPANB); B.tl_pan = dp<int>(h, BUF_TLPAN);
     B.var_act = dp<int>(h, BUF_VARACT);
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS);
@@ -376,11 +437,8 @@ void enqueue_solve_iteration(Handle* h) {
     }
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
-        for (int k = 0; k < h->max_nb; k++) {
-            const int m = h->max_nb - k - 1;
-            hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (m + 1) / 2), n), dim3(64), 0, h->stream, B, k);
-            if (m > 0) hipLaunchKernelGGL(k_chol_syrk, dim3(m, m, n), dim3(64), 0, h->stream, B, k);
-        }
+        for (int k = 0; k < h->max_nb; k++)
+            hipLaunchKernelGGL(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
     }
     {
         ProfScope ps(h, VBA_PROF_TRSV);
