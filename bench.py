@@ -51,33 +51,23 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU path")
     torch.cuda.set_device(local_rank)
 
-    from mc_slam_amd import synth, backend
+    from mc_slam_amd import synth, backend, shard
 
-    # synthetic windows of configs[2]; seeds 100.. per BASELINE.md (rank r uses 100 + 1000 r + i)
-    wins = [synth.config_c3(seed=100 + 1000 * rank + i) for i in range(min(args.distinct, args.batch))]
+    # synthetic windows of configs[2]; window w of the job belongs to rank w % world, seed 100 + w
+    n_distinct = min(args.distinct, args.batch)
+    gids = shard.window_ids(n_distinct * world, rank, world)
+    wins = [synth.config_c3(seed=shard.window_seed(g)) for g in gids]
     batch = [wins[i % len(wins)] for i in range(args.batch)]
     ba = backend.LocalBA(local_rank)
     ba.upload(batch)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    meter = shard.ThroughputMeter(dist, torch.cuda.synchronize)
     for _ in range(args.warmup):
         ba.run()
-    barrier()
-    t0 = time.perf_counter()
+    meter.start()
     for _ in range(args.steps):
         ba.run()          # vba_batch_run returns after the stream has drained
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    total_windows = args.batch * args.steps * world
+    total_windows, dt = meter.stop(args.batch * args.steps, device="cuda")
     value = total_windows / dt
 
     out = None
