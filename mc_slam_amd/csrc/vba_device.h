@@ -7,23 +7,20 @@
 #include <stdint.h>
 
 #define VBA_NB 32          // block size of the dense reduced-system factorisation
-#define VBA_EREC 40        // doubles per edge record   (320 B)
-#define VBA_PREC 40        // doubles per point record  (320 B)
+#define VBA_EREC 32        // doubles per edge record   (256 B)
+#define VBA_PREC 32        // doubles per point record  (256 B)
+#define VBA_SLOT 8         // doubles per slot record   (64 B = one line)
 #define VBA_IMUH 960       // doubles per IMU edge pair: 30x30 local Hessian + 30 rhs (+ pad)
 #define VBA_TRACE 64
 
-// edge record (variant 2, EdgePRIDP; all Jacobians pre-scaled by sqrt(rho' * invSigma2)):
-//   [0..11]  Bi  : 2x6 Jacobian w.r.t. the observing keyframe's PR   (g2otypes.cpp:139-145)
-//   [12..23] Br  : 2x6 Jacobian w.r.t. the reference keyframe's PR   (g2otypes.cpp:128-134)
-//   [24..29] W   : Bi^T a   (H_pl block of the observing keyframe, a = 2x1 Jacobian w.r.t. rho)
-//   [30..35] g   : -Bi^T r  (b contribution of the observing keyframe)
-// edge record (variants 0,1; XYZ landmarks):
-//   [0..11]  Bi  : 2x6 pose Jacobian
-//   [12..17] A   : 2x3 point Jacobian
-//   [18..19] r   : residual
-// point record (variant 2):  [0] D  [1] bl  [2..7] W0 (ref KF)  [8..13] g0  [14..34] G0 (upper 6x6, row-major packed)  [35] Dinv
-// point record (variants 0,1): [0..5] Hll (sym packed) [6..8] bl [9..14] Dinv (sym packed)
-
+// Linearisation products kept in HBM between k_lin and its consumers (variant 2, EdgePRIDP).  A "slot" is one
+// (landmark, keyframe) incidence = one H_pl block: observation e -> slot e, reference keyframe of landmark p
+// -> slot n_obs + p.  Jacobians are pre-scaled by sqrt(rho' * invSigma2) and never stored unreduced.
+//   slot record  [0..5] U = W * sqrt(Dinv)  (W = H_pl block, 6x1)   [6] beta = sqrt(Dinv) * b_l   [7] sqrt(Dinv) (ref slot)
+//                -> Schur term of a keyframe pair is -U_a U_b^T, reduced rhs term -U_a beta, x_l = sD (beta - sum U.x_p)
+//   edge record  [0..11] Bi (2x6, d/d observing KF PR, g2otypes.cpp:139-145)  [12..23] Br (2x6, d/d reference KF PR,
+//                :128-134)  [24..29] g = -Bi^T r
+//   point record [0..20] G0 = sum Br^T Br (upper 6x6 packed)  [21..26] g0 = -sum Br^T r  [27] D
 struct WinDesc {
     int variant, algo;
     int n_kf, n_free, n_pt, n_obs, n_imu;

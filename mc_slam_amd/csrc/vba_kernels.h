@@ -24,7 +24,7 @@ struct Batch {
     const double *obs_uv, *obs_w;
     unsigned char* lvl;
     double *chi2_e, *depth_e;
-    double *erec, *prec;
+    double *erec, *prec, *slot;
     // IMU factors
     const int *imu_i, *imu_j;
     const double *imu_meas, *imu_info;
@@ -200,7 +200,7 @@ DEVI void lin_point_idp(const Batch& B, const WinDesc& d, const WinCtrl& c, int 
         double* rec = B.erec + VBA_EREC * go;
         if (B.lvl[go]) {
             if (mode == LIN_FULL)
-                for (int i = 0; i < 36; i++) rec[i] = 0.0;
+                for (int i = 0; i < 30; i++) rec[i] = 0.0;
             continue;
         }
         const double iz = 1.0 / Pc[2];
@@ -262,20 +262,35 @@ DEVI void lin_point_idp(const Batch& B, const WinDesc& d, const WinCtrl& c, int 
         }
 #pragma unroll
         for (int i = 0; i < 12; i++) { rec[i] = Bi[i]; rec[12 + i] = Br[i]; }
+        double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + o);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            rec[24 + i] = Bi[i] * a[0] + Bi[6 + i] * a[1];
-            rec[30 + i] = -(Bi[i] * r0 + Bi[6 + i] * r1);
+            sl[i] = Bi[i] * a[0] + Bi[6 + i] * a[1];          // W (scaled to U below, once D is known)
+            rec[24 + i] = -(Bi[i] * r0 + Bi[6 + i] * r1);
         }
     }
     if (mode == LIN_FULL) {
+        const double sD = (D > 0.0) ? sqrt(1.0 / D) : 0.0;
+        const double beta = sD * bl;
+        for (int o = o0; o < o1; o++) {
+            double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + o);
+            const bool on = !B.lvl[d.obs0 + o];
+#pragma unroll
+            for (int i = 0; i < 6; i++) sl[i] = on ? sl[i] * sD : 0.0;
+            sl[6] = beta;
+            sl[7] = sD;
+        }
+        double* sr = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + d.n_obs + p);
+#pragma unroll
+        for (int i = 0; i < 6; i++) sr[i] = W0[i] * sD;
+        sr[6] = beta;
+        sr[7] = sD;
         double* pr = B.prec + VBA_PREC * gp;
-        pr[0] = D; pr[1] = bl;
 #pragma unroll
-        for (int i = 0; i < 6; i++) { pr[2 + i] = W0[i]; pr[8 + i] = g0[i]; }
+        for (int i = 0; i < 21; i++) pr[i] = G0[i];
 #pragma unroll
-        for (int i = 0; i < 21; i++) pr[14 + i] = G0[i];
-        pr[35] = (D > 0.0) ? 1.0 / D : 0.0;
+        for (int i = 0; i < 6; i++) pr[21 + i] = g0[i];
+        pr[27] = D;
     }
 }
 
@@ -513,11 +528,15 @@ DEVI double wave_sum(double v) {
 __global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
     __shared__ double blk[15 * 15 + 16];
     __shared__ double sh_r[6], sh_b[6], sh_h[6];
-    const int w = blockIdx.y;
+    // XCD-aware mapping: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so every
+    // workgroup of one window gets the same (id % 8) and the window's slot records stay in one XCD's L2
+    const int lid = blockIdx.x;
+    const int w = (lid & 7) + 8 * ((lid >> 3) / max_pairs);
+    const int pr = (lid >> 3) % max_pairs;
+    if (w >= B.n_win) return;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
     if (!c.active) return;
-    const int pr = blockIdx.x;
     if (pr >= d.n_pairs) return;
     const int t = threadIdx.x;
     const int a = B.pair_a[d.pair0 + pr], b = B.pair_b[d.pair0 + pr];
@@ -529,64 +548,61 @@ __global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
 #pragma unroll
     for (int i = 0; i < 6; i++) rhs[i] = bp[i] = hd[i] = 0;
     const int ib = B.item_begin[d.pair0 + w + pr], ie = B.item_begin[d.pair0 + w + pr + 1];
+    const double* slots = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0);
     for (int it = ib + t; it < ie; it += 64) {
-        const int* itm = B.items + 3 * (size_t)(d.item0 + it);
-        const int p = itm[0], sa = itm[1], sb = itm[2];
-        const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + p);
-        const double Dl = pr_[0];
-        const double Dinv = (d.algo == 1) ? ((Dl + lambda) != 0.0 ? 1.0 / (Dl + lambda) : 0.0) : pr_[35];
-        double WA[6], WB[6];
-        const double* ra = (sa >= 0) ? B.erec + VBA_EREC * (size_t)(d.obs0 + sa) : nullptr;
-        const double* rb = (sb >= 0) ? B.erec + VBA_EREC * (size_t)(d.obs0 + sb) : nullptr;
+        const int2 itm = *reinterpret_cast<const int2*>(B.items + 2 * (size_t)(d.item0 + it));
+        const int sa = itm.x, sb = itm.y;
+        const double* qa = slots + VBA_SLOT * (size_t)sa;
+        const double* qb = slots + VBA_SLOT * (size_t)sb;
+        double UA[6], UB[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            WA[i] = ra ? ra[24 + i] : pr_[2 + i];
-            WB[i] = rb ? rb[24 + i] : pr_[2 + i];
-        }
+        for (int i = 0; i < 6; i++) { UA[i] = qa[i]; UB[i] = qb[i]; }
         if (diag) {
-            // same slot on both sides: direct term G (H_pp diagonal block) and the rhs pieces
-            if (sa < 0) {
+            // one slot on both sides: H_pp diagonal block of the slot's keyframe and the rhs pieces
+            if (sa >= d.n_obs) {
+                const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + sa - d.n_obs);
                 int gi = 0;
 #pragma unroll
                 for (int i = 0; i < 6; i++)
 #pragma unroll
                     for (int j = i; j < 6; j++) {
-                        const double g = pr_[14 + gi++];
+                        const double g = pr_[gi++];
                         acc[6 * i + j] += g;
                         if (j != i) acc[6 * j + i] += g;
                         if (j == i) hd[i] += g;
                     }
 #pragma unroll
-                for (int i = 0; i < 6; i++) bp[i] += pr_[8 + i];
+                for (int i = 0; i < 6; i++) bp[i] += pr_[21 + i];
             } else {
+                const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
 #pragma unroll
                     for (int j = 0; j < 6; j++) acc[6 * i + j] += ra[i] * ra[j] + ra[6 + i] * ra[6 + j];
                     hd[i] += ra[i] * ra[i] + ra[6 + i] * ra[6 + i];
-                    bp[i] += ra[30 + i];
+                    bp[i] += ra[24 + i];
                 }
             }
-            const double bl = pr_[1];
+            const double beta = qa[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) rhs[i] -= WA[i] * (Dinv * bl);
-        } else if (sa < 0 && sb >= 0) {  // a = reference KF, b = observer: Br^T Bi of edge sb
+            for (int i = 0; i < 6; i++) rhs[i] -= UA[i] * beta;
+        } else if (sa >= d.n_obs) {  // a = reference KF, b = observer: Br^T Bi of edge sb
+            const double* rb = B.erec + VBA_EREC * (size_t)(d.obs0 + sb);
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
                 for (int j = 0; j < 6; j++) acc[6 * i + j] += rb[12 + i] * rb[j] + rb[18 + i] * rb[6 + j];
-        } else if (sa >= 0 && sb < 0) {  // a = observer, b = reference KF: Bi^T Br of edge sa
+        } else if (sb >= d.n_obs) {  // a = observer, b = reference KF: Bi^T Br of edge sa
+            const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
                 for (int j = 0; j < 6; j++) acc[6 * i + j] += ra[i] * ra[12 + j] + ra[6 + i] * ra[18 + j];
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const double wd = WA[i] * Dinv;
+        for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = 0; j < 6; j++) acc[6 * i + j] -= wd * WB[j];
-        }
+            for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA[i] * UB[j];
     }
     // fixed-order wave reduction
 #pragma unroll
@@ -628,8 +644,10 @@ __global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
             if (!va[gr] || !va[gc]) s = (r == col) ? 1.0 : 0.0;  // vertex outside the index mapping
             else if (r == col) s += lambda;                       // setLambda, block_solver.hpp:564-589
         }
-        S[(size_t)gr * n + gc] = s;
-        if (!diag) S[(size_t)gc * n + gr] = s;
+        // the factorisation reads the lower triangle only; a diagonal block's upper half is dropped (its mirror
+        // thread writes the same position), an off-diagonal block lands wherever its entry is below the diagonal
+        if (gr >= gc) S[(size_t)gr * n + gc] = s;
+        else if (!diag) S[(size_t)gc * n + gr] = s;
     }
     if (diag && t < P) {
         double s = 0.0, sb = 0.0, h = 0.0;
@@ -854,25 +872,24 @@ __global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
         const int p = blockIdx.x * 64 + threadIdx.x;
         if (p >= d.n_pt) return;
         const size_t gp = d.pt0 + p;
-        const double* pr = B.prec + VBA_PREC * gp;
-        const double D = pr[0];
-        if (!(D > 0.0)) return;  // landmark outside the active set
-        double cl = pr[1];
+        const double* slots = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0);
+        const double* sr = slots + VBA_SLOT * (size_t)(d.n_obs + p);
+        const double sD = sr[7];
+        if (!(sD > 0.0)) return;  // landmark outside the active set
+        double cl = sr[6];        // beta - sum U . x_p
         const int rf = B.pt_ref[gp];
         if (rf < d.n_free)
 #pragma unroll
-            for (int i = 0; i < 6; i++) cl -= pr[2 + i] * x[vpos(d, rf, i)];
+            for (int i = 0; i < 6; i++) cl -= sr[i] * x[vpos(d, rf, i)];
         const int* ob = B.pt_obs_begin + d.pt0 + w;
         for (int o = ob[p]; o < ob[p + 1]; o++) {
-            const size_t go = d.obs0 + o;
-            const int kf = B.obs_kf[go];
+            const int kf = B.obs_kf[d.obs0 + o];
             if (kf >= d.n_free) continue;
-            const double* rec = B.erec + VBA_EREC * go;
+            const double* sl = slots + VBA_SLOT * (size_t)o;
 #pragma unroll
-            for (int i = 0; i < 6; i++) cl -= rec[24 + i] * x[vpos(d, kf, i)];
+            for (int i = 0; i < 6; i++) cl -= sl[i] * x[vpos(d, kf, i)];
         }
-        const double lam = (d.algo == 1) ? c.lambda : 0.0;
-        double rho = B.pt[3 * gp] + cl / (D + lam);
+        double rho = B.pt[3 * gp] + sD * cl;
         if (rho < 1e-6) rho = 1e-6;  // VertexIDP::oplusImpl, g2otypes.h:50-55
         B.pt[3 * gp] = rho;
     } else {

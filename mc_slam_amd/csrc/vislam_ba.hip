@@ -42,7 +42,7 @@ struct DevBuf {
 enum {
     BUF_DESC, BUF_CTRL, BUF_POSE, BUF_VEL, BUF_BIAS, BUF_KFR, BUF_POSE0, BUF_VEL0, BUF_BIAS0, BUF_POSEBK, BUF_VELBK,
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
-    BUF_CHI2E, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
+    BUF_CHI2E, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_N
 };
@@ -154,7 +154,7 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         if (pass == 1) {
             st.item_begin.assign(npairs + 1, 0);
             for (int i = 0; i < npairs; i++) st.item_begin[i + 1] = st.item_begin[i] + cnt[i];
-            st.items.resize(3 * (size_t)st.item_begin[npairs]);
+            st.items.resize(2 * (size_t)st.item_begin[npairs]);
             fill.assign(st.item_begin.begin(), st.item_begin.end() - 1);
         }
         for (int p = 0; p < P->n_pt; p++) {
@@ -181,8 +181,10 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
                     const int pi = pidx(sl[i1].first, sl[i2].first);
                     if (pass == 0) cnt[pi]++;
                     else {
-                        int* it = &st.items[3 * (size_t)fill[pi]++];
-                        it[0] = p; it[1] = sl[i1].second; it[2] = sl[i2].second;
+                        int* it = &st.items[2 * (size_t)fill[pi]++];
+                        // slot ids: observation o -> o ; reference keyframe of landmark p -> n_obs + p
+                        it[0] = sl[i1].second >= 0 ? sl[i1].second : P->n_obs + p;
+                        it[1] = sl[i2].second >= 0 ? sl[i2].second : P->n_obs + p;
                     }
                 }
         }
@@ -344,7 +346,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         pimu_begin.insert(pimu_begin.end(), st.pimu_begin.begin(), st.pimu_begin.end());
         pimu.insert(pimu.end(), st.pimu.begin(), st.pimu.end());
         kf0 += d.n_kf; pt0 += d.n_pt; obs0 += d.n_obs; imu0 += d.n_imu;
-        pair0 += d.n_pairs; item0 += (int)(st.items.size() / 3); pimu0 += (int)(st.pimu.size() / 2);
+        pair0 += d.n_pairs; item0 += (int)(st.items.size() / 2); pimu0 += (int)(st.pimu.size() / 2);
         vec0 += d.nS;
         const int obs_blk = (d.n_obs + 63) / 64;
         part0 += std::max(d.n_part_lin, 2 * obs_blk) + 2;
@@ -373,6 +375,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow)) return -1;
     if (dalloc(h, BUF_LVL, (size_t)obs0) || dalloc(h, BUF_CHI2E, (size_t)obs0 * 8) || dalloc(h, BUF_DEPTH, (size_t)obs0 * 8)) return -1;
     if (dalloc(h, BUF_EREC, (size_t)obs0 * VBA_EREC * 8) || dalloc(h, BUF_PREC, (size_t)pt0 * VBA_PREC * 8)) return -1;
+    if (dalloc(h, BUF_SLOT, ((size_t)obs0 + pt0) * VBA_SLOT * 8)) return -1;
     if (h2d(h, BUF_IMUI, imui) || h2d(h, BUF_IMUJ, imuj) || h2d(h, BUF_IMUMEAS, meas) || h2d(h, BUF_IMUINFO, info)) return -1;
     if (dalloc(h, BUF_IMUH, (size_t)imu0 * VBA_IMUH * 8) || dalloc(h, BUF_IMUCHI, (size_t)imu0 * 4 * 8)) return -1;
     if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
@@ -383,9 +386,12 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu)) return -1;
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
     // S: zero everything once, identity on the pads
-    HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->stream));
+    for (int w = 0; w < n; w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
+        const WinDesc& d = h->desc[w];
+        if (d.nS > d.np)
+            HIPCHK(h, hipMemsetAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)d.np * d.nS, 0, (size_t)(d.nS - d.np) * d.nS * 8, h->stream));
+    }
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_VEC].p, 0, (size_t)vec0 * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf[BUF_LF].p, 0, S_tot * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_YV].p, 0, (size_t)vec0 * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_BPOSE].p, 0, (size_t)vec0 * 16, h->stream));
     {
@@ -406,7 +412,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.obs_kf = dp<int>(h, BUF_OBSKF); B.obs_pt = dp<int>(h, BUF_OBSPT);
     B.obs_uv = dp<double>(h, BUF_OBSUV); B.obs_w = dp<double>(h, BUF_OBSW);
     B.lvl = dp<unsigned char>(h, BUF_LVL); B.chi2_e = dp<double>(h, BUF_CHI2E); B.depth_e = dp<double>(h, BUF_DEPTH);
-    B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC);
+    B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC); B.slot = dp<double>(h, BUF_SLOT);
     B.imu_i = dp<int>(h, BUF_IMUI); B.imu_j = dp<int>(h, BUF_IMUJ);
     B.imu_meas = dp<double>(h, BUF_IMUMEAS); B.imu_info = dp<double>(h, BUF_IMUINFO);
     B.imuH = dp<double>(h, BUF_IMUH); B.imu_chi = dp<double>(h, BUF_IMUCHI);
@@ -433,7 +439,7 @@ void enqueue_solve_iteration(Handle* h) {
     const int n = h->n_win;
     {
         ProfScope ps(h, VBA_PROF_SCHUR);
-        hipLaunchKernelGGL(k_schur, dim3(h->max_pairs, n), dim3(64), 0, h->stream, B, h->max_pairs);
+        hipLaunchKernelGGL(k_schur, dim3(h->max_pairs * 8 * ((n + 7) / 8)), dim3(64), 0, h->stream, B, h->max_pairs);
     }
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
