@@ -525,111 +525,31 @@ DEVI double wave_sum(double v) {
     return v;
 }
 
-__global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
-    __shared__ double blk[15 * 15 + 16];
-    __shared__ double sh_r[6], sh_b[6], sh_h[6];
-    // XCD-aware mapping: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so every
-    // workgroup of one window gets the same (id % 8) and the window's slot records stay in one XCD's L2
+// window / pair of a workgroup.  With >= 8 windows the mapping is XCD-aware: the dispatcher deals consecutive
+// workgroups round-robin over the 8 XCDs, so all workgroups of one window share (id % 8) and the window's slot
+// records stay in one XCD's L2.  (Speed only; results do not depend on placement.)
+DEVI bool schur_map(const Batch& B, int per_win, int& w, int& idx) {
     const int lid = blockIdx.x;
-    const int w = (lid & 7) + 8 * ((lid >> 3) / max_pairs);
-    const int pr = (lid >> 3) % max_pairs;
-    if (w >= B.n_win) return;
-    const WinDesc& d = B.desc[w];
-    const WinCtrl& c = B.ctrl[w];
-    if (!c.active) return;
-    if (pr >= d.n_pairs) return;
-    const int t = threadIdx.x;
-    const int a = B.pair_a[d.pair0 + pr], b = B.pair_b[d.pair0 + pr];
+    if (B.n_win >= 8) {
+        w = (lid & 7) + 8 * ((lid >> 3) / per_win);
+        idx = (lid >> 3) % per_win;
+    } else {
+        w = lid / per_win;
+        idx = lid % per_win;
+    }
+    return w < B.n_win;
+}
+
+// adds the IMU blocks, applies the active-set / damping rules and writes one pdim x pdim block of S (lower
+// triangle only: the factorisation never reads above the diagonal)
+DEVI void schur_write_block(const Batch& B, const WinDesc& d, const WinCtrl& c, int w, int pr, int a, int b,
+                            const double* blk) {
+    const int t = threadIdx.x, P = d.pdim, n = d.nS;
     const bool diag = (a == b);
     const double lambda = (d.algo == 1) ? c.lambda : 0.0;
-    double acc[36], rhs[6], bp[6], hd[6];
-#pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) rhs[i] = bp[i] = hd[i] = 0;
-    const int ib = B.item_begin[d.pair0 + w + pr], ie = B.item_begin[d.pair0 + w + pr + 1];
-    const double* slots = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0);
-    for (int it = ib + t; it < ie; it += 64) {
-        const int2 itm = *reinterpret_cast<const int2*>(B.items + 2 * (size_t)(d.item0 + it));
-        const int sa = itm.x, sb = itm.y;
-        const double* qa = slots + VBA_SLOT * (size_t)sa;
-        const double* qb = slots + VBA_SLOT * (size_t)sb;
-        double UA[6], UB[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) { UA[i] = qa[i]; UB[i] = qb[i]; }
-        if (diag) {
-            // one slot on both sides: H_pp diagonal block of the slot's keyframe and the rhs pieces
-            if (sa >= d.n_obs) {
-                const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + sa - d.n_obs);
-                int gi = 0;
-#pragma unroll
-                for (int i = 0; i < 6; i++)
-#pragma unroll
-                    for (int j = i; j < 6; j++) {
-                        const double g = pr_[gi++];
-                        acc[6 * i + j] += g;
-                        if (j != i) acc[6 * j + i] += g;
-                        if (j == i) hd[i] += g;
-                    }
-#pragma unroll
-                for (int i = 0; i < 6; i++) bp[i] += pr_[21 + i];
-            } else {
-                const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-#pragma unroll
-                    for (int j = 0; j < 6; j++) acc[6 * i + j] += ra[i] * ra[j] + ra[6 + i] * ra[6 + j];
-                    hd[i] += ra[i] * ra[i] + ra[6 + i] * ra[6 + i];
-                    bp[i] += ra[24 + i];
-                }
-            }
-            const double beta = qa[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) rhs[i] -= UA[i] * beta;
-        } else if (sa >= d.n_obs) {  // a = reference KF, b = observer: Br^T Bi of edge sb
-            const double* rb = B.erec + VBA_EREC * (size_t)(d.obs0 + sb);
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j < 6; j++) acc[6 * i + j] += rb[12 + i] * rb[j] + rb[18 + i] * rb[6 + j];
-        } else if (sb >= d.n_obs) {  // a = observer, b = reference KF: Bi^T Br of edge sa
-            const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j < 6; j++) acc[6 * i + j] += ra[i] * ra[12 + j] + ra[6 + i] * ra[18 + j];
-        }
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA[i] * UB[j];
-    }
-    // fixed-order wave reduction
-#pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] = wave_sum(acc[i]);
-    if (diag) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) { rhs[i] = wave_sum(rhs[i]); bp[i] = wave_sum(bp[i]); hd[i] = wave_sum(hd[i]); }
-    }
-    const int P = d.pdim;
-    for (int q = t; q < P * P; q += 64) blk[q] = 0.0;
-    __syncthreads();
-    if (t == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-#pragma unroll
-            for (int j = 0; j < 6; j++) blk[i * P + j] = acc[6 * i + j];
-            sh_r[i] = rhs[i]; sh_b[i] = bp[i]; sh_h[i] = hd[i];
-        }
-    }
-    __syncthreads();
-    // IMU blocks + rhs
     const int qb = B.pimu_begin[d.pair0 + w + pr], qe = B.pimu_begin[d.pair0 + w + pr + 1];
-    double* vec = B.vec + d.vec0;
-    double* bpose = B.bpose + d.vec0;
     const int* va = B.var_act + d.vec0;
     double* S = B.S + d.S0;
-    const int n = d.nS;
     for (int q = t; q < P * P; q += 64) {
         const int r = q / P, col = q % P;
         double s = blk[q];
@@ -644,14 +564,166 @@ __global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
             if (!va[gr] || !va[gc]) s = (r == col) ? 1.0 : 0.0;  // vertex outside the index mapping
             else if (r == col) s += lambda;                       // setLambda, block_solver.hpp:564-589
         }
-        // the factorisation reads the lower triangle only; a diagonal block's upper half is dropped (its mirror
-        // thread writes the same position), an off-diagonal block lands wherever its entry is below the diagonal
         if (gr >= gc) S[(size_t)gr * n + gc] = s;
         else if (!diag) S[(size_t)gc * n + gr] = s;
     }
-    if (diag && t < P) {
+}
+
+// off-diagonal keyframe pairs (a < b): 36 accumulators per lane, lanes stride over the pair's items
+__global__ void __launch_bounds__(64, 3) k_schur_off(Batch B, int max_pairs) {
+    __shared__ double blk[15 * 15 + 16];
+    int w, pr;
+    if (!schur_map(B, max_pairs, w, pr)) return;
+    const WinDesc& d = B.desc[w];
+    const WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;
+    if (pr >= d.n_pairs) return;
+    const int t = threadIdx.x;
+    const int a = B.pair_a[d.pair0 + pr], b = B.pair_b[d.pair0 + pr];
+    if (a == b) return;  // k_schur_diag
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+    const int ib = B.item_begin[d.pair0 + w + pr], ie = B.item_begin[d.pair0 + w + pr + 1];
+    const double* slots = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0);
+    const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
+    for (int it = ib + t; it < ie; it += 64) {
+        const int2 itm = items[it];
+        const int sa = itm.x, sb = itm.y;
+        const double* qa = slots + VBA_SLOT * (size_t)sa;
+        const double* qb = slots + VBA_SLOT * (size_t)sb;
+        double UA[6], UB[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { UA[i] = qa[i]; UB[i] = qb[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA[i] * UB[j];
+        if (sa >= d.n_obs) {         // a = reference KF, b = observer: Br^T Bi of edge sb
+            const double* rb = B.erec + VBA_EREC * (size_t)(d.obs0 + sb);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                double bi[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) bi[j] = rb[6 * h + j];
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double br = rb[12 + 6 * h + i];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) acc[6 * i + j] += br * bi[j];
+                }
+            }
+        } else if (sb >= d.n_obs) {  // a = observer, b = reference KF: Bi^T Br of edge sa
+            const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                double br[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) br[j] = ra[12 + 6 * h + j];
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double bi = ra[6 * h + i];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) acc[6 * i + j] += bi * br[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = wave_sum(acc[i]);  // fixed-order butterfly
+    const int P = d.pdim;
+    for (int q = t; q < P * P; q += 64) blk[q] = 0.0;
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) blk[i * P + j] = acc[6 * i + j];
+    }
+    __syncthreads();
+    schur_write_block(B, d, c, w, pr, a, b, blk);
+}
+
+// diagonal pairs (a,a): every slot of keyframe a; also the reduced rhs (block_solver.hpp:436-439), the
+// unreduced b_p and the H_pp diagonal (LM's lambda init)
+__global__ void __launch_bounds__(64) k_schur_diag(Batch B, int max_free) {
+    __shared__ double blk[15 * 15 + 16];
+    __shared__ double sh_r[6], sh_b[6], sh_h[6];
+    int w, a;
+    if (!schur_map(B, max_free, w, a)) return;
+    const WinDesc& d = B.desc[w];
+    const WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;
+    if (a >= d.n_free) return;
+    const int t = threadIdx.x;
+    const int pr = a * d.n_free - a * (a - 1) / 2;  // index of pair (a,a)
+    double acc[36], rhs[6], bp[6], hd[6];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) rhs[i] = bp[i] = hd[i] = 0;
+    const int ib = B.item_begin[d.pair0 + w + pr], ie = B.item_begin[d.pair0 + w + pr + 1];
+    const double* slots = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0);
+    const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
+    for (int it = ib + t; it < ie; it += 64) {
+        const int sa = items[it].x;
+        const double* qa = slots + VBA_SLOT * (size_t)sa;
+        double UA[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) UA[i] = qa[i];
+        const double beta = qa[6];
+        if (sa >= d.n_obs) {
+            const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + sa - d.n_obs);
+            int gi = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = i; j < 6; j++) {
+                    const double g = pr_[gi++];
+                    acc[6 * i + j] += g;
+                    if (j != i) acc[6 * j + i] += g;
+                    if (j == i) hd[i] += g;
+                }
+#pragma unroll
+            for (int i = 0; i < 6; i++) bp[i] += pr_[21 + i];
+        } else {
+            const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) acc[6 * i + j] += ra[i] * ra[j] + ra[6 + i] * ra[6 + j];
+                hd[i] += ra[i] * ra[i] + ra[6 + i] * ra[6 + i];
+                bp[i] += ra[24 + i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            rhs[i] -= UA[i] * beta;
+#pragma unroll
+            for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA[i] * UA[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = wave_sum(acc[i]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { rhs[i] = wave_sum(rhs[i]); bp[i] = wave_sum(bp[i]); hd[i] = wave_sum(hd[i]); }
+    const int P = d.pdim;
+    for (int q = t; q < P * P; q += 64) blk[q] = 0.0;
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) blk[i * P + j] = acc[6 * i + j];
+            sh_r[i] = rhs[i]; sh_b[i] = bp[i]; sh_h[i] = hd[i];
+        }
+    }
+    __syncthreads();
+    schur_write_block(B, d, c, w, pr, a, a, blk);
+    if (t < P) {
         double s = 0.0, sb = 0.0, h = 0.0;
         if (t < 6) { s = sh_r[t]; sb = sh_b[t]; h = sh_h[t]; }
+        const int qb = B.pimu_begin[d.pair0 + w + pr], qe = B.pimu_begin[d.pair0 + w + pr + 1];
         for (int m = qb; m < qe; m++) {
             const int k = B.pimu[2 * (size_t)(d.pimu0 + m)], role = B.pimu[2 * (size_t)(d.pimu0 + m) + 1];
             const double* H = B.imuH + VBA_IMUH * (size_t)(d.imu0 + k);
@@ -660,10 +732,10 @@ __global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
             h += H[(ro + t) * 30 + ro + t];
         }
         const int gr = vpos(d, a, t);
-        const bool act = va[gr] != 0;
-        vec[gr] = act ? (sb + s) : 0.0;   // reduced rhs = b_p - sum W Dinv b_l
-        bpose[gr] = act ? sb : 0.0;       // unreduced b_p (LM computeScale)
-        bpose[n + gr] = act ? h : 0.0;    // H_pp diagonal (LM computeLambdaInit)
+        const bool act = B.var_act[d.vec0 + gr] != 0;
+        (B.vec + d.vec0)[gr] = act ? (sb + s) : 0.0;            // reduced rhs = b_p - sum W Dinv b_l
+        (B.bpose + d.vec0)[gr] = act ? sb : 0.0;                // unreduced b_p (LM computeScale)
+        (B.bpose + d.vec0)[d.nS + gr] = act ? h : 0.0;          // H_pp diagonal (LM computeLambdaInit)
     }
 }
 
@@ -678,10 +750,10 @@ __global__ void __launch_bounds__(64) k_schur(Batch B, int max_pairs) {
 // Restates LinearSolverEigen::solve (linear_solver_eigen.h:94-124) on the dense reduced system.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
-    __shared__ double Lk[32 * 33];
-    __shared__ double rd[32];
-    __shared__ double XI[32 * 34];
+    __shared__ double XI[32 * 34];   // first holds L_kk (stride 33) for the panel solves, then X_I (stride 34)
     __shared__ double XJ[32 * 34];
+    __shared__ double rd[32];
+    double* Lk = XI;
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
@@ -721,13 +793,20 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
 #pragma unroll
     for (int q = 0; q < 32; q++) a[q] = (q <= r) ? arow[q] : 0.0;
     bool bad = false;
+    double rdiag = 1.0;  // 1 / L_rr of this lane's row
 #pragma unroll
     for (int cc = 0; cc < 32; cc++) {
         const double piv = rl64(a[cc], cc);
         bad = bad || !(piv > 0.0);
-        const double dg = sqrt(piv);
-        const double rinv = 1.0 / dg;
+        // 1/sqrt(piv) by v_rsq_f64 + two Newton steps (full double accuracy) instead of a sqrt and a divide on the
+        // critical path of the 32-step chain
+        double y = __builtin_amdgcn_rsq(piv);
+        y = y * (1.5 - 0.5 * piv * y * y);
+        y = y * (1.5 - 0.5 * piv * y * y);
+        const double rinv = y;
+        const double dg = piv * rinv;
         const double l = (r == cc) ? dg : a[cc] * rinv;
+        rdiag = (r == cc) ? rinv : rdiag;
         a[cc] = l;
 #pragma unroll
         for (int c2 = cc + 1; c2 < 32; c2++) a[c2] -= l * rl64(l, c2);
@@ -735,10 +814,7 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
     if (hi == 0) {
 #pragma unroll
         for (int q = 0; q < 32; q++) Lk[r * 33 + q] = (q <= r) ? a[q] : 0.0;
-        double dgr = 0.0;
-#pragma unroll
-        for (int q = 0; q < 32; q++) dgr = (q == r) ? a[q] : dgr;
-        rd[r] = 1.0 / dgr;
+        rd[r] = rdiag;
         if (bx == 0) {
             double* lrow = Lf + (dk + r) * n + dk;
 #pragma unroll
@@ -770,6 +846,7 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
         for (int q = 0; q < 32; q++) dst[q] = x[q];  // L_Ik
         vec[(size_t)I * 32 + r] -= sy;
     }
+    __syncthreads();  // every lane is done reading L_kk before X_I overwrites it
     {
         double* X = hi ? XJ : XI;
         if (hi == 0 || !diagp) {

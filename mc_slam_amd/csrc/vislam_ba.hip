@@ -63,7 +63,7 @@ struct Handle {
     int n_win = 0;
     // launch geometry (maxima over the batch)
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
-    int max_nS = 0, max_its[2] = {0, 0};
+    int max_nS = 0, max_its[2] = {0, 0}, max_free = 0;
     std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
     int algo = 0, variant = 2;
@@ -280,6 +280,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->tile_updates = 0;
     size_t S_tot = 0;
     int kf0 = 0, pt0 = 0, obs0 = 0, imu0 = 0, pair0 = 0, item0 = 0, pimu0 = 0, vec0 = 0, part0 = 0;
+    h->max_free = 0;
     h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
     h->max_its[0] = h->max_its[1] = 0;
     for (int w = 0; w < n; w++) {
@@ -354,6 +355,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         h->max_pt_blk = std::max(h->max_pt_blk, d.n_part_lin);
         h->max_imu = std::max(h->max_imu, d.n_imu);
         h->max_pairs = std::max(h->max_pairs, d.n_pairs);
+        h->max_free = std::max(h->max_free, d.n_free);
         h->max_nb = std::max(h->max_nb, d.nb);
         h->max_obs_blk = std::max(h->max_obs_blk, obs_blk);
         h->max_kf_blk = std::max(h->max_kf_blk, (d.n_kf + 63) / 64);
@@ -439,7 +441,9 @@ void enqueue_solve_iteration(Handle* h) {
     const int n = h->n_win;
     {
         ProfScope ps(h, VBA_PROF_SCHUR);
-        hipLaunchKernelGGL(k_schur, dim3(h->max_pairs * 8 * ((n + 7) / 8)), dim3(64), 0, h->stream, B, h->max_pairs);
+        const int ngrp = (n >= 8) ? 8 * ((n + 7) / 8) : n;
+        hipLaunchKernelGGL(k_schur_diag, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free);
+        hipLaunchKernelGGL(k_schur_off, dim3(h->max_pairs * ngrp), dim3(64), 0, h->stream, B, h->max_pairs);
     }
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
