@@ -9,7 +9,8 @@
 #define VBA_NB 32          // block size of the dense reduced-system factorisation
 #define VBA_EREC 32        // doubles per edge record   (256 B)
 #define VBA_PREC 32        // doubles per point record  (256 B)
-#define VBA_SLOT 8         // doubles per slot record   (64 B = one line)
+#define VBA_SLOT 8         // doubles per slot record   (64 B = one line), inverse-depth landmarks
+#define VBA_SLOT3 24       // doubles per slot record, XYZ landmarks: U (6x3), beta (3), pad
 #define VBA_IMUH 960       // doubles per IMU edge pair: 30x30 local Hessian + 30 rhs (+ pad)
 #define VBA_TRACE 64
 
@@ -60,8 +61,8 @@ struct WinCtrl {
     // LM state (levenberg.cpp)
     int lm_trial;     // trials done in the current outer iteration (qmax)
     int lm_need_trial;// 1: another trial must run in this outer iteration
+    int lm_restore;   // 1: the last trial was rejected, k_restore must pop the state
     int nbad;
-    int pad;
     double lambda, ni;
     double chi_prev;  // GN: preChi2 of the last started iteration.  LM: currentChi
     double chi_ini;   // LM: iniChi

@@ -23,7 +23,7 @@ struct Batch {
     const int *obs_kf, *obs_pt;
     const double *obs_uv, *obs_w;
     unsigned char* lvl;
-    double *chi2_e, *depth_e;
+    double *chi2_e, *depth_e, *chi2_f;  // chi2_f: chi2 recomputed at the final estimates (LM: chi2_e may be stale)
     double *erec, *prec, *slot;
     // IMU factors
     const int *imu_i, *imu_j;
@@ -46,6 +46,9 @@ struct Batch {
 
 #define LIN_FULL 0
 #define LIN_ERR 1
+
+// window takes part in the current solve: GN -> while its optimize() loop runs; LM -> only while a trial is due
+DEVI bool win_on(const WinDesc& d, const WinCtrl& c) { return c.active && (d.algo == 0 || c.lm_need_trial); }
 
 // ------------------------------------------------------------------------------------------------
 // K_reset: working state <- uploaded state, R|t cache, control block
@@ -114,6 +117,7 @@ __global__ void __launch_bounds__(64) k_stage_clear(Batch B, int stage) {
                 c.active = 1;
             c.robust_vis = 0;  // e->setRobustKernel(0) on every vision edge, :489
         }
+        if (d.its[stage] <= 0) c.active = 0;  // optimize(0) runs nothing
         c.stage = stage; c.it = 0; c.chol_fail = 0; c.step_ok = 0;
         c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0; c.ni = 2;
     }
@@ -569,14 +573,16 @@ DEVI void schur_write_block(const Batch& B, const WinDesc& d, const WinCtrl& c, 
     }
 }
 
-// off-diagonal keyframe pairs (a < b): 36 accumulators per lane, lanes stride over the pair's items
-__global__ void __launch_bounds__(64, 3) k_schur_off(Batch B, int max_pairs) {
-    __shared__ double blk[15 * 15 + 16];
+// off-diagonal keyframe pairs (a < b): 36 accumulators per lane, lanes stride over the pair's items.
+// LD = landmark dimension (1: inverse depth, slot record 8 doubles; 3: XYZ, slot record 24 doubles)
+template <int LD>
+DEVI void schur_off_body(const Batch& B, int max_pairs, double* blk) {
+    constexpr int SS = (LD == 1) ? VBA_SLOT : VBA_SLOT3;
     int w, pr;
     if (!schur_map(B, max_pairs, w, pr)) return;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
-    if (!c.active) return;
+    if (!win_on(d, c)) return;
     if (pr >= d.n_pairs) return;
     const int t = threadIdx.x;
     const int a = B.pair_a[d.pair0 + pr], b = B.pair_b[d.pair0 + pr];
@@ -585,46 +591,50 @@ __global__ void __launch_bounds__(64, 3) k_schur_off(Batch B, int max_pairs) {
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
     const int ib = B.item_begin[d.pair0 + w + pr], ie = B.item_begin[d.pair0 + w + pr + 1];
-    const double* slots = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0);
+    const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
     for (int it = ib + t; it < ie; it += 64) {
         const int2 itm = items[it];
         const int sa = itm.x, sb = itm.y;
-        const double* qa = slots + VBA_SLOT * (size_t)sa;
-        const double* qb = slots + VBA_SLOT * (size_t)sb;
-        double UA[6], UB[6];
+        const double* qa = slots + SS * (size_t)sa;
+        const double* qb = slots + SS * (size_t)sb;
+        double UA[6 * LD], UB[6 * LD];
 #pragma unroll
-        for (int i = 0; i < 6; i++) { UA[i] = qa[i]; UB[i] = qb[i]; }
+        for (int i = 0; i < 6 * LD; i++) { UA[i] = qa[i]; UB[i] = qb[i]; }
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA[i] * UB[j];
-        if (sa >= d.n_obs) {         // a = reference KF, b = observer: Br^T Bi of edge sb
-            const double* rb = B.erec + VBA_EREC * (size_t)(d.obs0 + sb);
+            for (int j = 0; j < 6; j++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                double bi[6];
+                for (int l = 0; l < LD; l++) acc[6 * i + j] -= UA[LD * i + l] * UB[LD * j + l];
+        if (LD == 1) {
+            if (sa >= d.n_obs) {         // a = reference KF, b = observer: Br^T Bi of edge sb
+                const double* rb = B.erec + VBA_EREC * (size_t)(d.obs0 + sb);
 #pragma unroll
-                for (int j = 0; j < 6; j++) bi[j] = rb[6 * h + j];
+                for (int h = 0; h < 2; h++) {
+                    double bi[6];
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const double br = rb[12 + 6 * h + i];
+                    for (int j = 0; j < 6; j++) bi[j] = rb[6 * h + j];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) acc[6 * i + j] += br * bi[j];
+                    for (int i = 0; i < 6; i++) {
+                        const double br = rb[12 + 6 * h + i];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) acc[6 * i + j] += br * bi[j];
+                    }
                 }
-            }
-        } else if (sb >= d.n_obs) {  // a = observer, b = reference KF: Bi^T Br of edge sa
-            const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
+            } else if (sb >= d.n_obs) {  // a = observer, b = reference KF: Bi^T Br of edge sa
+                const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                double br[6];
+                for (int h = 0; h < 2; h++) {
+                    double br[6];
 #pragma unroll
-                for (int j = 0; j < 6; j++) br[j] = ra[12 + 6 * h + j];
+                    for (int j = 0; j < 6; j++) br[j] = ra[12 + 6 * h + j];
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const double bi = ra[6 * h + i];
+                    for (int i = 0; i < 6; i++) {
+                        const double bi = ra[6 * h + i];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) acc[6 * i + j] += bi * br[j];
+                        for (int j = 0; j < 6; j++) acc[6 * i + j] += bi * br[j];
+                    }
                 }
             }
         }
@@ -643,17 +653,25 @@ __global__ void __launch_bounds__(64, 3) k_schur_off(Batch B, int max_pairs) {
     __syncthreads();
     schur_write_block(B, d, c, w, pr, a, b, blk);
 }
+__global__ void __launch_bounds__(64, 3) k_schur_off(Batch B, int max_pairs) {
+    __shared__ double blk[15 * 15 + 16];
+    schur_off_body<1>(B, max_pairs, blk);
+}
+__global__ void __launch_bounds__(64) k_schur_off3(Batch B, int max_pairs) {
+    __shared__ double blk[15 * 15 + 16];
+    schur_off_body<3>(B, max_pairs, blk);
+}
 
 // diagonal pairs (a,a): every slot of keyframe a; also the reduced rhs (block_solver.hpp:436-439), the
 // unreduced b_p and the H_pp diagonal (LM's lambda init)
-__global__ void __launch_bounds__(64) k_schur_diag(Batch B, int max_free) {
-    __shared__ double blk[15 * 15 + 16];
-    __shared__ double sh_r[6], sh_b[6], sh_h[6];
+template <int LD>
+DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk, double* sh_r, double* sh_b, double* sh_h) {
+    constexpr int SS = (LD == 1) ? VBA_SLOT : VBA_SLOT3;
     int w, a;
     if (!schur_map(B, max_free, w, a)) return;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
-    if (!c.active) return;
+    if (hd_pass ? !c.active : !win_on(d, c)) return;  // hd_pass: LM's pre-trial pass for computeLambdaInit
     if (a >= d.n_free) return;
     const int t = threadIdx.x;
     const int pr = a * d.n_free - a * (a - 1) / 2;  // index of pair (a,a)
@@ -663,16 +681,17 @@ __global__ void __launch_bounds__(64) k_schur_diag(Batch B, int max_free) {
 #pragma unroll
     for (int i = 0; i < 6; i++) rhs[i] = bp[i] = hd[i] = 0;
     const int ib = B.item_begin[d.pair0 + w + pr], ie = B.item_begin[d.pair0 + w + pr + 1];
-    const double* slots = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0);
+    const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
     for (int it = ib + t; it < ie; it += 64) {
         const int sa = items[it].x;
-        const double* qa = slots + VBA_SLOT * (size_t)sa;
-        double UA[6];
+        const double* qa = slots + SS * (size_t)sa;
+        double UA[6 * LD], beta[LD];
 #pragma unroll
-        for (int i = 0; i < 6; i++) UA[i] = qa[i];
-        const double beta = qa[6];
-        if (sa >= d.n_obs) {
+        for (int i = 0; i < 6 * LD; i++) UA[i] = qa[i];
+#pragma unroll
+        for (int l = 0; l < LD; l++) beta[l] = qa[6 * LD + l];
+        if (LD == 1 && sa >= d.n_obs) {
             const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + sa - d.n_obs);
             int gi = 0;
 #pragma unroll
@@ -697,11 +716,13 @@ __global__ void __launch_bounds__(64) k_schur_diag(Batch B, int max_free) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            rhs[i] -= UA[i] * beta;
+        for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA[i] * UA[j];
-        }
+            for (int l = 0; l < LD; l++) {
+                rhs[i] -= UA[LD * i + l] * beta[l];
+#pragma unroll
+                for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA[LD * i + l] * UA[LD * j + l];
+            }
     }
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = wave_sum(acc[i]);
@@ -734,9 +755,19 @@ __global__ void __launch_bounds__(64) k_schur_diag(Batch B, int max_free) {
         const int gr = vpos(d, a, t);
         const bool act = B.var_act[d.vec0 + gr] != 0;
         (B.vec + d.vec0)[gr] = act ? (sb + s) : 0.0;            // reduced rhs = b_p - sum W Dinv b_l
-        (B.bpose + d.vec0)[gr] = act ? sb : 0.0;                // unreduced b_p (LM computeScale)
-        (B.bpose + d.vec0)[d.nS + gr] = act ? h : 0.0;          // H_pp diagonal (LM computeLambdaInit)
+        (B.bpose + 2 * (size_t)d.vec0)[gr] = act ? sb : 0.0;        // unreduced b_p (LM computeScale)
+        (B.bpose + 2 * (size_t)d.vec0)[d.nS + gr] = act ? h : 0.0;  // H_pp diagonal (LM computeLambdaInit)
     }
+}
+__global__ void __launch_bounds__(64) k_schur_diag(Batch B, int max_free) {
+    __shared__ double blk[15 * 15 + 16];
+    __shared__ double sh_r[6], sh_b[6], sh_h[6];
+    schur_diag_body<1>(B, max_free, 0, blk, sh_r, sh_b, sh_h);
+}
+__global__ void __launch_bounds__(64) k_schur_diag3(Batch B, int max_free, int hd_pass) {
+    __shared__ double blk[15 * 15 + 16];
+    __shared__ double sh_r[6], sh_b[6], sh_h[6];
+    schur_diag_body<3>(B, max_free, hd_pass, blk, sh_r, sh_b, sh_h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -757,7 +788,7 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
-    if (!c.active) return;
+    if (!win_on(d, c)) return;
     if (k >= d.nb) return;
     const int* sb = B.tl_step_begin + d.tl_step0;
     const int npair = sb[k + 1] - sb[k];
@@ -792,24 +823,23 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
     const double* arow = S + (dk + r) * n + dk;
 #pragma unroll
     for (int q = 0; q < 32; q++) a[q] = (q <= r) ? arow[q] : 0.0;
+    // L D L^T of the diagonal tile (unit lower L, D on the diagonal), as Eigen's SimplicialLDLT does: negative
+    // pivots are fine, only an exactly zero / non-finite pivot fails (linear_solver_eigen.h:105-111)
     bool bad = false;
-    double rdiag = 1.0;  // 1 / L_rr of this lane's row
+    double rdiag = 1.0;  // 1 / d_r of this lane's row
 #pragma unroll
     for (int cc = 0; cc < 32; cc++) {
         const double piv = rl64(a[cc], cc);
-        bad = bad || !(piv > 0.0);
-        // 1/sqrt(piv) by v_rsq_f64 + two Newton steps (full double accuracy) instead of a sqrt and a divide on the
-        // critical path of the 32-step chain
-        double y = __builtin_amdgcn_rsq(piv);
-        y = y * (1.5 - 0.5 * piv * y * y);
-        y = y * (1.5 - 0.5 * piv * y * y);
-        const double rinv = y;
-        const double dg = piv * rinv;
-        const double l = (r == cc) ? dg : a[cc] * rinv;
-        rdiag = (r == cc) ? rinv : rdiag;
-        a[cc] = l;
+        bad = bad || (piv == 0.0) || !isfinite(piv);
+        double y = __builtin_amdgcn_rcp(piv);  // v_rcp_f64 + two Newton steps: full double accuracy
+        y = y * (2.0 - piv * y);
+        y = y * (2.0 - piv * y);
+        const double u = a[cc];                 // a_{r,cc} before the division = l_{r,cc} d_cc
+        const double l = u * y;
+        rdiag = (r == cc) ? y : rdiag;
+        a[cc] = (r == cc) ? piv : l;
 #pragma unroll
-        for (int c2 = cc + 1; c2 < 32; c2++) a[c2] -= l * rl64(l, c2);
+        for (int c2 = cc + 1; c2 < 32; c2++) a[c2] -= l * rl64(u, c2);
     }
     if (hi == 0) {
 #pragma unroll
@@ -824,38 +854,46 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
     }
     if (bx == 0 && lane == 0 && bad) c.chol_fail = 1;
     __syncthreads();
-    // X L_kk^T = A  (row per lane, column-oriented so the 31-q updates of a step are independent)
+    // X' L_kk^T = A with unit-diagonal L (row per lane, column-oriented so the 31-q updates of a step are
+    // independent); the panel factor is L_Ik = X' D^-1, the forward-substituted rhs z_k = L_kk^-1 r_k
 #pragma unroll
     for (int q = 0; q < 32; q++) {
-        const double xq = x[q] * rd[q];
-        x[q] = xq;
+        const double xq = x[q];
 #pragma unroll
         for (int c2 = q + 1; c2 < 32; c2++) x[c2] -= xq * Lk[c2 * 33 + q];
     }
     if (bx == 0 && lane == 32) {
 #pragma unroll
-        for (int q = 0; q < 32; q++) yv[dk + q] = x[q];  // y_k
+        for (int q = 0; q < 32; q++) yv[dk + q] = x[q];  // z_k
     }
     if (!has_pair) return;
-    double sy = 0.0;  // x_row . y_k ; y_k sits in lane 32 of a diagonal pair (wave-uniform control flow here)
+    double xs[32];   // row of L_Ik = X' D^-1
 #pragma unroll
-    for (int q = 0; q < 32; q++) sy += x[q] * rl64(x[q], 32);
+    for (int q = 0; q < 32; q++) xs[q] = x[q] * rd[q];
+    double sy = 0.0;  // L_Ik row . z_k ; z_k sits in lane 32 of a diagonal pair (wave-uniform control flow here)
+#pragma unroll
+    for (int q = 0; q < 32; q++) sy += xs[q] * rl64(x[q], 32);
     if (diagp && hi == 0) {
         double* dst = Lf + ((size_t)I * 32 + r) * n + dk;
 #pragma unroll
-        for (int q = 0; q < 32; q++) dst[q] = x[q];  // L_Ik
+        for (int q = 0; q < 32; q++) dst[q] = xs[q];  // L_Ik
         vec[(size_t)I * 32 + r] -= sy;
     }
     __syncthreads();  // every lane is done reading L_kk before X_I overwrites it
-    {
-        double* X = hi ? XJ : XI;
-        if (hi == 0 || !diagp) {
+    // C_IJ -= L_Ik D L_Jk^T = (X'_I D^-1) X'_J^T : XI holds the scaled rows of tile I, XJ the unscaled rows of tile J
+    if (hi == 0) {
 #pragma unroll
-            for (int q = 0; q < 32; q++) X[r * 34 + q] = x[q];
+        for (int q = 0; q < 32; q++) XI[r * 34 + q] = xs[q];
+        if (diagp) {
+#pragma unroll
+            for (int q = 0; q < 32; q++) XJ[r * 34 + q] = x[q];
         }
+    } else if (!diagp) {
+#pragma unroll
+        for (int q = 0; q < 32; q++) XJ[r * 34 + q] = x[q];
     }
     __syncthreads();
-    const double* XJp = diagp ? XI : XJ;
+    const double* XJp = XJ;
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int ti = 0; ti < 2; ti++)
@@ -884,7 +922,7 @@ __global__ void __launch_bounds__(256) k_trsv(Batch B) {
     extern __shared__ double xs[];  // nS doubles + 8*32 partials + 32*33 diagonal tile
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
-    if (!B.ctrl[w].active) return;
+    if (!win_on(d, B.ctrl[w])) return;
     const int n = d.nS, t = threadIdx.x;
     double* part = xs + n;
     double* Lt = part + 256;
@@ -912,20 +950,20 @@ __global__ void __launch_bounds__(256) k_trsv(Batch B) {
         __syncthreads();
         if (t < 64) {
             const int c = t & 31;
-            double v = xs[dk + c];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v -= part[q * 32 + c];
+            double v;
             double col[32];
 #pragma unroll
             for (int j = 0; j < 32; j++) col[j] = Lt[j * 33 + c];  // column c of L_kk (rows j >= c are the factor)
             double dgc = 1.0;
 #pragma unroll
-            for (int j = 0; j < 32; j++) dgc = (j == c) ? col[j] : dgc;
-            const double rdc = 1.0 / dgc;
+            for (int j = 0; j < 32; j++) dgc = (j == c) ? col[j] : dgc;  // d_c sits on the diagonal of the tile
+            v = xs[dk + c] / dgc;                                         // D^-1 z
 #pragma unroll
-            for (int j = 31; j >= 0; j--) {
-                const double xj = rl64(v * rdc, j);
-                v = (c == j) ? xj : ((c < j) ? v - col[j] * xj : v);
+            for (int q = 0; q < 8; q++) v -= part[q * 32 + c];
+#pragma unroll
+            for (int j = 31; j >= 0; j--) {                               // unit-diagonal L_kk^T x_k = v
+                const double xj = rl64(v, j);
+                v = (c < j) ? v - col[j] * xj : v;
             }
             if (t < 32) xs[dk + c] = v;
         }
@@ -1026,7 +1064,7 @@ __global__ void __launch_bounds__(64) k_final_edges(Batch B) {
         if (d.variant == 2 && (B.pt[3 * (size_t)(d.pt0 + B.obs_pt[go])] < d.rho_min || B.lvl[go])) bad = true;
         B.out_outlier[go] = bad ? 1 : 0;
         B.out_chi2[go] = s;
-        if (!B.lvl[go]) chi = s;
+        if (!B.lvl[go]) chi = B.chi2_f ? B.chi2_f[go] : s;
         cnt = bad ? 1.0 : 0.0;
     }
     const double tc = block_sum<64>(chi, sm);

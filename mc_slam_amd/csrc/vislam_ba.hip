@@ -6,7 +6,7 @@
 // on the device (k_ctrl_*), the host only enqueues.  No CPU fallback exists: without a HIP device every entry
 // point fails with an error.
 #include "../../include/vislam_ba.h"
-#include "vba_kernels.h"
+#include "vba_kernels_lm.h"
 
 #include <algorithm>
 #include <chrono>
@@ -42,7 +42,7 @@ struct DevBuf {
 enum {
     BUF_DESC, BUF_CTRL, BUF_POSE, BUF_VEL, BUF_BIAS, BUF_KFR, BUF_POSE0, BUF_VEL0, BUF_BIAS0, BUF_POSEBK, BUF_VELBK,
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
-    BUF_CHI2E, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
+    BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_N
 };
@@ -286,8 +286,11 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     for (int w = 0; w < n; w++) {
         const vba_problem* P = probs[w];
         if (!P) return fail(h, "null problem");
-        if (P->variant != VBA_VARIANT_PRV_IDP || P->algo != VBA_ALGO_GN)
-            return fail(h, "this build of the HIP backend implements variant 2 (PR/V/Bias + IDP) with Gauss-Newton");
+        if (P->variant < 0 || P->variant > 2 || (P->algo != VBA_ALGO_GN && P->algo != VBA_ALGO_LM)) return fail(h, "bad variant / algo");
+        if (P->variant == VBA_VARIANT_PRV_IDP && P->algo != VBA_ALGO_GN)
+            return fail(h, "inverse-depth landmarks are solved with Gauss-Newton only (as the reference does, src/Optimizer.cpp:136)");
+        if (P->variant != VBA_VARIANT_PRV_IDP && P->algo != VBA_ALGO_LM)
+            return fail(h, "XYZ landmarks are solved with Levenberg-Marquardt only (as the reference does, src/Optimizer.cpp:1028,3928)");
         if (P->n_kf_free <= 0 || P->n_kf_free > P->n_kf || P->n_pt < 0 || P->n_obs < 0) return fail(h, "bad sizes");
         if (w > 0 && (P->variant != probs[0]->variant || P->algo != probs[0]->algo)) return fail(h, "mixed batch");
         if (P->its_stage1 > 30 || P->its_stage2 > 30 || P->its_stage1 < 0 || P->its_stage2 < 0) return fail(h, "its out of range");
@@ -350,7 +353,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         pair0 += d.n_pairs; item0 += (int)(st.items.size() / 2); pimu0 += (int)(st.pimu.size() / 2);
         vec0 += d.nS;
         const int obs_blk = (d.n_obs + 63) / 64;
-        part0 += std::max(d.n_part_lin, 2 * obs_blk) + 2;
+        part0 += std::max(3 * d.n_part_lin, 2 * obs_blk) + 2;
         S_tot += (size_t)d.nS * d.nS;
         h->max_pt_blk = std::max(h->max_pt_blk, d.n_part_lin);
         h->max_imu = std::max(h->max_imu, d.n_imu);
@@ -377,7 +380,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow)) return -1;
     if (dalloc(h, BUF_LVL, (size_t)obs0) || dalloc(h, BUF_CHI2E, (size_t)obs0 * 8) || dalloc(h, BUF_DEPTH, (size_t)obs0 * 8)) return -1;
     if (dalloc(h, BUF_EREC, (size_t)obs0 * VBA_EREC * 8) || dalloc(h, BUF_PREC, (size_t)pt0 * VBA_PREC * 8)) return -1;
-    if (dalloc(h, BUF_SLOT, ((size_t)obs0 + pt0) * VBA_SLOT * 8)) return -1;
+    if (dalloc(h, BUF_SLOT, ((size_t)obs0 + pt0) * (probs[0]->variant == VBA_VARIANT_PRV_IDP ? VBA_SLOT : VBA_SLOT3) * 8)) return -1;
+    if (dalloc(h, BUF_CHI2F, (size_t)obs0 * 8)) return -1;
     if (h2d(h, BUF_IMUI, imui) || h2d(h, BUF_IMUJ, imuj) || h2d(h, BUF_IMUMEAS, meas) || h2d(h, BUF_IMUINFO, info)) return -1;
     if (dalloc(h, BUF_IMUH, (size_t)imu0 * VBA_IMUH * 8) || dalloc(h, BUF_IMUCHI, (size_t)imu0 * 4 * 8)) return -1;
     if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
@@ -414,6 +418,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.obs_kf = dp<int>(h, BUF_OBSKF); B.obs_pt = dp<int>(h, BUF_OBSPT);
     B.obs_uv = dp<double>(h, BUF_OBSUV); B.obs_w = dp<double>(h, BUF_OBSW);
     B.lvl = dp<unsigned char>(h, BUF_LVL); B.chi2_e = dp<double>(h, BUF_CHI2E); B.depth_e = dp<double>(h, BUF_DEPTH);
+    B.chi2_f = (probs[0]->variant == VBA_VARIANT_PRV_IDP) ? nullptr : dp<double>(h, BUF_CHI2F);
     B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC); B.slot = dp<double>(h, BUF_SLOT);
     B.imu_i = dp<int>(h, BUF_IMUI); B.imu_j = dp<int>(h, BUF_IMUJ);
     B.imu_meas = dp<double>(h, BUF_IMUMEAS); B.imu_info = dp<double>(h, BUF_IMUINFO);
@@ -439,11 +444,18 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
 void enqueue_solve_iteration(Handle* h) {
     const Batch& B = h->B;
     const int n = h->n_win;
+    const bool idp = h->variant == VBA_VARIANT_PRV_IDP;
     {
         ProfScope ps(h, VBA_PROF_SCHUR);
         const int ngrp = (n >= 8) ? 8 * ((n + 7) / 8) : n;
-        hipLaunchKernelGGL(k_schur_diag, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free);
-        hipLaunchKernelGGL(k_schur_off, dim3(h->max_pairs * ngrp), dim3(64), 0, h->stream, B, h->max_pairs);
+        if (idp) {
+            hipLaunchKernelGGL(k_schur_diag, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free);
+            hipLaunchKernelGGL(k_schur_off, dim3(h->max_pairs * ngrp), dim3(64), 0, h->stream, B, h->max_pairs);
+        } else {
+            hipLaunchKernelGGL(k_dinv, dim3(h->max_pt_blk, n), dim3(64), 0, h->stream, B);
+            hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 0);
+            hipLaunchKernelGGL(k_schur_off3, dim3(h->max_pairs * ngrp), dim3(64), 0, h->stream, B, h->max_pairs);
+        }
     }
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
@@ -457,13 +469,60 @@ void enqueue_solve_iteration(Handle* h) {
     }
     {
         ProfScope ps(h, VBA_PROF_UPDATE);
-        hipLaunchKernelGGL(k_update, dim3(h->max_pt_blk + h->max_kf_blk, n), dim3(64), 0, h->stream, B, h->max_pt_blk);
+        if (idp) hipLaunchKernelGGL(k_update, dim3(h->max_pt_blk + h->max_kf_blk, n), dim3(64), 0, h->stream, B, h->max_pt_blk);
+        else hipLaunchKernelGGL(k_update_xyz, dim3(h->max_pt_blk + h->max_kf_blk, n), dim3(64), 0, h->stream, B, h->max_pt_blk);
     }
 }
 
 void enqueue_lin(Handle* h, int mode) {
     ProfScope ps(h, VBA_PROF_LINEARIZE);
-    hipLaunchKernelGGL(k_lin, dim3(h->max_pt_blk + h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
+    if (h->variant == VBA_VARIANT_PRV_IDP)
+        hipLaunchKernelGGL(k_lin, dim3(h->max_pt_blk + h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
+    else
+        hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk + h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
+}
+
+// Levenberg-Marquardt stage (levenberg.cpp:61-164).  One trial = damp, Schur, factor, solve, update,
+// re-evaluate; the device decides accept / reject.  The host learns through one pinned word per trial whether
+// any window needs another trial (rho < 0) or another outer iteration, and enqueues only those.
+int enqueue_lm_stage(Handle* h, int stage, const volatile int* stop_flag) {
+    const Batch& B = h->B;
+    const int n = h->n_win;
+    const int big_blk = std::max(h->max_kf_blk, h->max_pt_blk);
+    const int ngrp = (n >= 8) ? 8 * ((n + 7) / 8) : n;
+    volatile int* flags = h->stop_host + 4;  // [0] another trial, [1] another outer iteration
+    for (int it = 0; it < h->max_its[stage]; it++) {
+        enqueue_lin(h, LIN_FULL);
+        {
+            ProfScope ps(h, VBA_PROF_CONTROL);
+            // H_pp diagonal for computeLambdaInit (the block it writes into S is rewritten by the first trial)
+            hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 1);
+            hipLaunchKernelGGL(k_ctrl_lm_outer, dim3(n), dim3(64), 0, h->stream, B);
+        }
+        bool more_outer = false;
+        for (int trial = 0; trial < 10; trial++) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            flags[0] = 0;
+            flags[1] = 0;
+            {
+                ProfScope ps(h, VBA_PROF_MISC);
+                hipLaunchKernelGGL(k_backup, dim3(big_blk, n), dim3(64), 0, h->stream, B);
+            }
+            enqueue_solve_iteration(h);
+            enqueue_lin(h, LIN_ERR_TRIAL);
+            {
+                ProfScope ps(h, VBA_PROF_CONTROL);
+                hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(n), dim3(64), 0, h->stream, B, h->stop_dev + 4);
+                hipLaunchKernelGGL(k_restore, dim3(big_blk, n), dim3(64), 0, h->stream, B);
+            }
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (stop_flag && *stop_flag) *h->stop_host = 1;
+            more_outer = flags[1] != 0;
+            if (!flags[0]) break;
+        }
+        if (!more_outer) break;
+    }
+    return 0;
 }
 
 int do_run(Handle* h, const volatile int* stop_flag) {
@@ -492,19 +551,31 @@ int do_run(Handle* h, const volatile int* stop_flag) {
             if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, n), dim3(64), 0, h->stream, B);
             hipLaunchKernelGGL(k_stage_mark, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
         }
-        for (int it = 0; it < h->max_its[stage]; it++) {
-            enqueue_lin(h, LIN_FULL);
+        if (h->algo == VBA_ALGO_LM) {
+            if (enqueue_lm_stage(h, stage, stop_flag)) return -1;
+        } else {
+            for (int it = 0; it < h->max_its[stage]; it++) {
+                enqueue_lin(h, LIN_FULL);
+                {
+                    ProfScope ps(h, VBA_PROF_CONTROL);
+                    hipLaunchKernelGGL(k_ctrl_gn, dim3(n), dim3(64), 0, h->stream, B, 0);
+                }
+                enqueue_solve_iteration(h);
+            }
+            enqueue_lin(h, LIN_ERR);
             {
                 ProfScope ps(h, VBA_PROF_CONTROL);
-                hipLaunchKernelGGL(k_ctrl_gn, dim3(n), dim3(64), 0, h->stream, B, 0);
+                hipLaunchKernelGGL(k_ctrl_gn, dim3(n), dim3(64), 0, h->stream, B, 1);
             }
-            enqueue_solve_iteration(h);
         }
-        enqueue_lin(h, LIN_ERR);
-        {
-            ProfScope ps(h, VBA_PROF_CONTROL);
-            hipLaunchKernelGGL(k_ctrl_gn, dim3(n), dim3(64), 0, h->stream, B, 1);
+        if (h->variant != VBA_VARIANT_PRV_IDP) {
+            ProfScope ps(h, VBA_PROF_MISC);
+            hipLaunchKernelGGL(k_depth_xyz, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
         }
+    }
+    if (h->variant != VBA_VARIANT_PRV_IDP) {
+        ProfScope ps(h, VBA_PROF_MISC);
+        hipLaunchKernelGGL(k_chi2_fresh_xyz, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
     }
     {
         ProfScope ps(h, VBA_PROF_MISC);
@@ -664,6 +735,24 @@ int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile 
     if (do_upload(h, 1, ps)) return -1;
     if (do_run(h, stop_flag)) return -1;
     return do_download(h, 1, ps, rs);
+}
+
+// test/debug hook (not part of include/vislam_ba.h): raw copy out of one device buffer of the last batch
+int vba_debug_copy(void* handle, int32_t buf_id, uint64_t offset_bytes, void* dst, uint64_t nbytes) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h || buf_id < 0 || buf_id >= BUF_N || offset_bytes + nbytes > h->buf[buf_id].cap) return -1;
+    (void)hipSetDevice(h->device);
+    return hipMemcpy(dst, reinterpret_cast<char*>(h->buf[buf_id].p) + offset_bytes, nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+int vba_debug_buf_id(const char* name) {
+    static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
+        "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
+        "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
+        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI"};
+    static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
+    for (int i = 0; i < BUF_N; i++)
+        if (!strcmp(names[i], name)) return i;
+    return -1;
 }
 
 int vba_set_profile(void* handle, int32_t enable) {

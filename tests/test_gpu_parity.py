@@ -51,6 +51,42 @@ def test_idp_window_matches_oracle(ba, oracle, kw):
     _check(p, q, r, qo, ro)
 
 
+@pytest.mark.parametrize("variant,algo,kw", [
+    (abi.VARIANT_SE3_XYZ, abi.ALGO_LM, dict(n_kf=6, n_fixed=2, n_pt=60, n_obs=300, seed=33)),
+    (abi.VARIANT_SE3_XYZ, abi.ALGO_LM, dict(n_kf=12, n_fixed=2, n_pt=500, n_obs=3000, seed=34)),
+    (abi.VARIANT_PRV_XYZ, abi.ALGO_LM, dict(n_kf=6, n_fixed=1, n_pt=60, n_obs=300, seed=32)),
+    (abi.VARIANT_PRV_XYZ, abi.ALGO_LM, dict(n_kf=12, n_fixed=1, n_pt=500, n_obs=3000, seed=35)),
+    (abi.VARIANT_SE3_XYZ, abi.ALGO_LM, dict(n_kf=10, n_fixed=2, n_pt=300, n_obs=1800, seed=36)),
+    (abi.VARIANT_PRV_XYZ, abi.ALGO_LM, dict(n_kf=10, n_fixed=1, n_pt=300, n_obs=1800, seed=37)),
+])
+def test_xyz_variants_match_oracle(ba, oracle, variant, algo, kw):
+    """EdgeSE3ProjectXYZ (vision-only LocalBundleAdjustment, LM) and EdgeNavStatePRPointXYZ (+ IMU chain)."""
+    p = synth.make_window(variant, algo=algo, **kw)
+    q, r = ba.solve(p)
+    qo, ro = oracle.solve(p)
+    _check(p, q, r, qo, ro)
+    if algo == abi.ALGO_LM:
+        assert abs(r.lambda_final - ro.lambda_final) <= 1e-6 * ro.lambda_final
+
+
+def test_unsupported_combinations_fail_loudly(ba):
+    # the reference never runs GN on XYZ landmarks nor LM on inverse-depth ones; the backend says so instead of guessing
+    p = synth.make_window(abi.VARIANT_SE3_XYZ, algo=abi.ALGO_GN, n_kf=6, n_fixed=2, n_pt=60, n_obs=300, seed=33)
+    with pytest.raises(RuntimeError, match="Levenberg-Marquardt only"):
+        ba.solve(p)
+    p = synth.make_window(abi.VARIANT_PRV_IDP, algo=abi.ALGO_LM, n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31)
+    with pytest.raises(RuntimeError, match="Gauss-Newton only"):
+        ba.solve(p)
+
+
+def test_c2_full_size_matches_oracle(ba, oracle):
+    """BASELINE configs[1]: vision-only LocalBundleAdjustment, 20 KF / 2k MapPoints / 12k EdgeSE3ProjectXYZ, LM."""
+    p = synth.config_c2()
+    q, r = ba.solve(p)
+    qo, ro = oracle.solve(p)
+    _check(p, q, r, qo, ro)
+
+
 def test_c3_full_size_matches_oracle(ba, oracle):
     p = synth.config_c3()
     q, r = ba.solve(p)
