@@ -1368,6 +1368,47 @@ int vba_oracle_linearize(vba_problem *P, double lambda, double *Hfull, double *b
     return ok ? n : -1;
 }
 
+/* Residual-only evaluation at the problem's CURRENT state (no system is built: cheap at any size).
+ * out[0] = robust chi2 of all edges (Huber on vision iff robust_vis), out[1..3] = plain chi2 of vision / PRV / bias
+ * edges; per-edge vision chi2 and depth in obs_chi2 / obs_depth (may be NULL). */
+int vba_oracle_eval(vba_problem *P, int robust_vis, double *out, double *obs_chi2, double *obs_depth) {
+    ctx C, *c = &C;
+    memset(c, 0, sizeof C);
+    c->P = P; c->variant = P->variant;
+    c->nkf = P->n_kf; c->nfree = P->n_kf_free; c->npt = P->n_pt; c->nobs = P->n_obs;
+    c->nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
+    c->pose = P->kf_pose; c->vel = P->kf_vel; c->bias = P->kf_bias; c->pt = P->pt;
+    double rho[3];
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int k = 0; k < c->nimu; k++) {
+        if (!imu_edge_active(c, k)) continue;
+        const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
+        const double *meas = P->imu_meas + VBA_IMU_MEAS_STRIDE * k;
+        double e9[9], e6[6];
+        vbo_edge_prv_error(c->pose + 7 * i, c->pose + 7 * j, c->vel + 3 * i, c->vel + 3 * j, c->bias + 12 * i, meas, P->g_w, e9);
+        const double s = quadform(e9, P->imu_info_prv + 81 * k, 9);
+        vbo_huber(s, P->huber_prv, rho);
+        out[0] += rho[0]; out[2] += s;
+        vbo_edge_bias_error(c->bias + 12 * i, c->bias + 12 * j, e6);
+        const double wg = P->inv_bg_rw2 / meas[0], wa = P->inv_ba_rw2 / meas[0];
+        const double sb = wg * (e6[0] * e6[0] + e6[1] * e6[1] + e6[2] * e6[2]) + wa * (e6[3] * e6[3] + e6[4] * e6[4] + e6[5] * e6[5]);
+        vbo_huber(sb, P->huber_bias, rho);
+        out[0] += rho[0]; out[3] += sb;
+    }
+    for (int p = 0; p < c->npt; p++)
+        for (int o = P->pt_obs_begin[p]; o < P->pt_obs_begin[p + 1]; o++) {
+            double e[2];
+            const double z = vis_eval(c, p, o, e, NULL, NULL, NULL);
+            const double s = chi2_2(e, P->obs_w[o]);
+            if (robust_vis) { vbo_huber(s, P->huber_vis, rho); out[0] += rho[0]; }
+            else out[0] += s;
+            out[1] += s;
+            if (obs_chi2) obs_chi2[o] = s;
+            if (obs_depth) obs_depth[o] = z;
+        }
+    return 0;
+}
+
 /* retraction hooks for the finite-difference Jacobian tests (same oplus the optimiser uses) */
 void vbo_oplus_pr(double *pose7, const double *d6) { /* NavState::IncSmallPR */
     pose7[0] += d6[0]; pose7[1] += d6[1]; pose7[2] += d6[2];

@@ -49,6 +49,17 @@ def solve(prob: abi.Problem, solver_mode=0, stop=None):
     return q, rb.get()
 
 
+def evaluate(prob: abi.Problem, robust_vis=True):
+    """residual-only evaluation at prob's current state: (robust chi2, chi2_vis, chi2_prv, chi2_bias, per-edge chi2, depth)"""
+    out = np.zeros(4)
+    ch = np.zeros(max(prob.n_obs, 1)); dp = np.zeros(max(prob.n_obs, 1))
+    s = prob.as_struct()
+    f = lib().vba_oracle_eval
+    f.restype = C.c_int
+    f(C.byref(s), C.c_int(1 if robust_vis else 0), P(out), P(ch), P(dp))
+    return out[0], out[1], out[2], out[3], ch[:prob.n_obs], dp[:prob.n_obs]
+
+
 def linearize(prob: abi.Problem, lam=0.0, want_H=True):
     """Dense H, b and the Schur solution at prob's current state (all edges active, Huber on)."""
     pdim = 6 if prob.variant == abi.VARIANT_SE3_XYZ else 15

@@ -151,3 +151,41 @@ def test_empty_and_degenerate_inputs(ba):
     bad.obs_kf[o0 + 1] = bad.obs_kf[o0]
     with pytest.raises(RuntimeError, match="observed twice"):
         ba.solve(bad)
+
+
+def test_c4_full_size_properties(ba, oracle):
+    """BASELINE configs[3]: 200 KF / 50k landmarks / 500k EdgePRIDP + IMU chain.  The oracle's dense solve would take
+    minutes at this size, so the full-size check uses size-independent properties, each against the oracle's
+    residual functions (cheap at any size):
+      * the first traced value is the robust chi2 of the uploaded state;
+      * every edge the backend keeps as an inlier carries the chi2 the oracle computes at the returned state;
+      * the IMU chi2 sums match the oracle's at the returned state;
+      * Gauss-Newton made progress: robust chi2 decreases over stage 1, relative keyframe geometry improves."""
+    p = synth.config_c4()
+    q, r = ba.solve(p)
+    assert r.status == 0 and r.its_done[0] >= 1
+    rob0 = oracle.evaluate(p, robust_vis=True)[0]
+    assert abs(r.chi2_trace[0] - rob0) <= 1e-9 * rob0
+    _, _, prv, bias, ch, dep = oracle.evaluate(q, robust_vis=False)
+    assert abs(r.chi2_prv - prv) <= 1e-6 * prv and abs(r.chi2_bias - bias) <= 1e-6 * max(bias, 1e-9)
+    inl = r.obs_outlier == 0
+    np.testing.assert_allclose(r.obs_chi2[inl], ch[inl], rtol=1e-6, atol=1e-9)
+    assert (ch[inl] <= p.chi2_th).all() and (dep[inl] > p.depth_min).all()
+    tr = r.chi2_trace[: r.its_done[0] + 1]
+    assert (np.diff(tr) < 1e-6 * tr[0]).all()
+    # one fixed keyframe anchors a 50 s chain, so absolute error at the far end is drift; the local geometry
+    # (relative translation of consecutive keyframes) is what local BA improves
+    gt = p.truth["pose"][: p.n_kf_free, :3]
+    rel = lambda a: np.diff(a, axis=0)
+    e0 = np.abs(rel(p.kf_pose[: p.n_kf_free, :3]) - rel(gt)).mean()
+    e1 = np.abs(rel(q.kf_pose[: p.n_kf_free, :3]) - rel(gt)).mean()
+    assert e1 < 0.5 * e0, (e0, e1)
+    planted = p.truth["is_outlier"]
+    assert (r.obs_outlier.astype(bool) & planted).sum() >= 0.9 * planted.sum()
+
+
+def test_c4_noise_free_terminates_at_truth(ba):
+    p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=200, n_fixed=1, n_pt=20000, n_obs=200000, seed=4, noise=False)
+    q, r = ba.solve(p)
+    assert r.its_done == (1, 1) and r.n_outliers == 0 and r.status == 0
+    assert np.abs(q.kf_pose - p.truth["pose"]).max() < 1e-6
