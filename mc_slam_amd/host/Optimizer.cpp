@@ -1,0 +1,400 @@
+// Optimizer.cpp -- see Optimizer.h.  Line references: src/Optimizer.cpp of mc275/MC_SLAM.
+#include "Optimizer.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <thread>
+
+namespace ORB_SLAM2 {
+
+long unsigned int KeyFrame::nNextId = 0;
+long unsigned int MapPoint::nNextId = 0;
+int Optimizer::Device = 0;
+
+namespace {
+
+thread_local void* t_handle = nullptr;
+thread_local PackedWindow t_last;
+
+void* handle() {
+    if (!t_handle && vba_create(Optimizer::Device, &t_handle) != 0) t_handle = nullptr;
+    return t_handle;
+}
+
+Quaterniond MatrixToQuat(const double* m) {  // Eigen::Quaterniond(Matrix3d), then normalised
+    Quaterniond q;
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (auto& v : q) v /= n;
+    return q;
+}
+
+// information of EdgeNavStatePRV: swap V/phi rows+cols of the P,V,phi covariance, invert (:273-280)
+bool PRVInformation(const std::array<double, 81>& cov, double* info) {
+    static const int perm[9] = {0, 1, 2, 6, 7, 8, 3, 4, 5};
+    double M[9][18];
+    for (int i = 0; i < 9; i++)
+        for (int j = 0; j < 9; j++) { M[i][j] = cov[9 * perm[i] + perm[j]]; M[i][9 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 9; c++) {
+        int p = c;
+        for (int r = c + 1; r < 9; r++)
+            if (std::fabs(M[r][c]) > std::fabs(M[p][c])) p = r;
+        if (M[p][c] == 0.0) return false;
+        if (p != c)
+            for (int j = 0; j < 18; j++) std::swap(M[c][j], M[p][j]);
+        const double inv = 1.0 / M[c][c];
+        for (int j = 0; j < 18; j++) M[c][j] *= inv;
+        for (int r = 0; r < 9; r++) {
+            if (r == c || M[r][c] == 0.0) continue;
+            const double f = M[r][c];
+            for (int j = 0; j < 18; j++) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 0; i < 9; i++)
+        for (int j = 0; j < 9; j++) info[9 * i + j] = M[i][9 + j];
+    return true;
+}
+
+void FinishProblem(PackedWindow& W) {
+    vba_problem& P = W.P;
+    P.n_kf = (int32_t)W.vKF.size();
+    P.n_pt = (int32_t)W.vMP.size();
+    P.n_obs = (int32_t)W.obsKF.size();
+    P.n_imu = (int32_t)W.imuI.size();
+    P.kf_pose = W.pose.data(); P.kf_vel = W.vel.data(); P.kf_bias = W.bias.data(); P.pt = W.pt.data();
+    P.pt_ref_kf = W.ref.data(); P.pt_obs_begin = W.begin.data(); P.obs_kf = W.obsKF.data();
+    P.obs_uv = W.uv.data(); P.obs_w = W.w.data();
+    P.imu_kf_i = W.imuI.data(); P.imu_kf_j = W.imuJ.data(); P.imu_meas = W.meas.data(); P.imu_info_prv = W.info.data();
+    P.inv_bg_rw2 = 1.0 / IMUData::getGyrBiasRW2();   // :246
+    P.inv_ba_rw2 = 1.0 / IMUData::getAccBiasRW2();   // :249
+    P.huber_vis = (double)(float)std::sqrt(5.991);             // const float thHuberMono, :327
+    P.huber_prv = (double)(float)std::sqrt(100 * 21.666);      // :241
+    P.huber_bias = (double)(float)std::sqrt(100 * 16.812);     // :242
+    P.its_stage1 = 5; P.its_stage2 = 10;                       // :459, :493
+    P.chi2_th = 5.991;
+    W.outlier.assign(P.n_obs ? P.n_obs : 1, 0);
+    W.chi2.assign(P.n_obs ? P.n_obs : 1, 0.0);
+    std::memset(&W.R, 0, sizeof W.R);
+    W.R.obs_outlier = W.outlier.data();
+    W.R.obs_chi2 = W.chi2.data();
+}
+
+// g2o's forceStopFlag is a bool* written by the Tracking thread (LocalMapping::mbAbortBA); the C-ABI polls an int
+struct StopMirror {
+    std::atomic<int> flag{0};
+    std::atomic<bool> done{false};
+    std::thread th;
+    explicit StopMirror(bool* src) {
+        if (!src) return;
+        flag = *src ? 1 : 0;
+        th = std::thread([this, src] {
+            while (!done.load()) {
+                if (*reinterpret_cast<volatile bool*>(src)) flag = 1;
+                std::this_thread::yield();
+            }
+        });
+    }
+    ~StopMirror() {
+        done = true;
+        if (th.joinable()) th.join();
+    }
+    const volatile int* ptr() { return reinterpret_cast<const volatile int*>(&flag); }
+};
+
+}  // namespace
+
+const PackedWindow& Optimizer::LastWindow() { return t_last; }
+PackedWindow& Optimizer::LastWindowMutable() { return t_last; }
+
+// ------------------------------------------------------------------------------------------------
+bool Optimizer::PackLocalBAPRVIDP(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw,
+                                  PackedWindow& W) {
+    W = PackedWindow();
+    std::memset(&W.P, 0, sizeof W.P);
+    if (pCurKF != lLocalKeyFrames.back()) std::cerr << "pCurKF != lLocalKeyFrames.back. check" << std::endl;  // :37-38
+    for (KeyFrame* pKFi : lLocalKeyFrames) pKFi->mnBALocalForKF = pCurKF->mnId;                                 // :49-56
+    std::list<MapPoint*> lLocalMapPoints;                                                                          // :59-79
+    for (KeyFrame* pKFi : lLocalKeyFrames)
+        for (MapPoint* pMP : pKFi->GetMapPointMatches())
+            if (pMP && !pMP->isBad() && pMP->mnBALocalForKF != pCurKF->mnId) {
+                lLocalMapPoints.push_back(pMP);
+                pMP->mnBALocalForKF = pCurKF->mnId;
+            }
+    std::list<KeyFrame*> lFixedCameras;                                                                           // :82-127
+    KeyFrame* pKFPrevLocal = lLocalKeyFrames.front()->GetPrevKeyFrame();
+    if (pKFPrevLocal) {
+        pKFPrevLocal->mnBAFixedForKF = pCurKF->mnId;
+        if (!pKFPrevLocal->isBad()) lFixedCameras.push_back(pKFPrevLocal);
+    } else
+        std::cerr << "pKFPrevLocal is NULL?" << std::endl;
+    for (MapPoint* pMP : lLocalMapPoints)
+        for (auto& mit : pMP->GetObservations()) {
+            KeyFrame* pKFi = mit.first;
+            if (pKFi->mnBALocalForKF != pCurKF->mnId && pKFi->mnBAFixedForKF != pCurKF->mnId) {
+                pKFi->mnBAFixedForKF = pCurKF->mnId;
+                if (!pKFi->isBad()) lFixedCameras.push_back(pKFi);
+            }
+        }
+    // vertices -> rows: free keyframes (window order = ascending mnId) first, fixed after            (:159-232)
+    std::map<KeyFrame*, int> kfIdx;
+    for (KeyFrame* k : lLocalKeyFrames) { kfIdx[k] = (int)W.vKF.size(); W.vKF.push_back(k); }
+    W.P.n_kf_free = (int32_t)W.vKF.size();
+    for (KeyFrame* k : lFixedCameras) { kfIdx[k] = (int)W.vKF.size(); W.vKF.push_back(k); }
+    for (KeyFrame* k : W.vKF) {
+        const NavState& ns = k->GetNavState();
+        const Vector3d P = ns.Get_P(), V = ns.Get_V(), bg = ns.Get_BiasGyr(), ba = ns.Get_BiasAcc(), dbg = ns.Get_dBias_Gyr(), dba = ns.Get_dBias_Acc();
+        const Quaterniond q = ns.Get_R();
+        W.pose.insert(W.pose.end(), {P[0], P[1], P[2], q[0], q[1], q[2], q[3]});
+        W.vel.insert(W.vel.end(), {V[0], V[1], V[2]});
+        W.bias.insert(W.bias.end(), {bg[0], bg[1], bg[2], ba[0], ba[1], ba[2], dbg[0], dbg[1], dbg[2], dba[0], dba[1], dba[2]});
+    }
+    // IMU factors: one EdgeNavStatePRV + one EdgeNavStateBias per local keyframe                     (:251-312)
+    for (KeyFrame* pKF1 : lLocalKeyFrames) {
+        KeyFrame* pKF0 = pKF1->GetPrevKeyFrame();
+        if (!pKF0 || !kfIdx.count(pKF0)) { std::cerr << "pKF0 missing" << std::endl; continue; }
+        const IMUPreintegrator& M = pKF1->GetIMUPreInt();
+        W.imuI.push_back(kfIdx[pKF0]);
+        W.imuJ.push_back(kfIdx[pKF1]);
+        W.meas.push_back(M.getDeltaTime());
+        for (double v : M.getDeltaP()) W.meas.push_back(v);
+        for (double v : M.getDeltaV()) W.meas.push_back(v);
+        for (const Matrix3d* A : {&M.getDeltaR(), &M.getJPBiasg(), &M.getJPBiasa(), &M.getJVBiasg(), &M.getJVBiasa(), &M.getJRBiasg()})
+            for (double v : *A) W.meas.push_back(v);
+        double info[81];
+        if (!PRVInformation(M.getCovPVPhi(), info)) { std::cerr << "singular preintegration covariance" << std::endl; return false; }
+        W.info.insert(W.info.end(), info, info + 81);
+    }
+    // landmarks and EdgePRIDP edges                                                                   (:337-451)
+    W.begin.push_back(0);
+    for (MapPoint* pMP : lLocalMapPoints) {
+        double Pw[3];
+        pMP->GetWorldPos(Pw);
+        KeyFrame* pRefKF = pMP->GetReferenceKeyFrame();
+        if (!pRefKF || pRefKF->isBad()) continue;                                                                // :349-353
+        double Rcw[9], tcw[3];
+        pRefKF->GetRotation(Rcw);
+        pRefKF->GetTranslation(tcw);
+        const double dc = Rcw[6] * Pw[0] + Rcw[7] * Pw[1] + Rcw[8] * Pw[2] + tcw[2];                             // :355-358
+        if (dc < 0.01) continue;                                                                                 // :360-365
+        mapMapPointObs observations = pMP->GetObservations();
+        if (!observations.count(pRefKF)) { std::cerr << "!observations.count(pRefKF)" << std::endl; continue; }
+        const KeyPoint& kpRefUn = pRefKF->mvKeysUn[observations[pRefKF]];
+        const double normx = (kpRefUn.pt.x - pRefKF->cx) / pRefKF->fx, normy = (kpRefUn.pt.y - pRefKF->cy) / pRefKF->fy;  // :382-385
+        const size_t nBefore = W.obsKF.size();
+        for (auto& mit : observations) {
+            KeyFrame* pKFi = mit.first;
+            if (pKFi == pRefKF || pKFi->isBad()) continue;                                                       // :395-400
+            if (pKFi->mvuRight[mit.second] >= 0) { std::cerr << "Stereo not supported yet" << std::endl; continue; }
+            const KeyPoint& kpUn = pKFi->mvKeysUn[mit.second];
+            W.obsKF.push_back(kfIdx[pKFi]);
+            W.uv.push_back(kpUn.pt.x); W.uv.push_back(kpUn.pt.y);
+            W.w.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);                                                  // float -> double, :428-429
+            W.vEdgeKF.push_back(pKFi);
+            W.vEdgeMP.push_back(pMP);
+        }
+        if (W.obsKF.size() == nBefore) continue;  // no edge -> the vertex is never added (:407-412, 588-589)
+        W.pt.insert(W.pt.end(), {1.0 / dc, normx, normy});
+        W.ref.push_back(kfIdx[pRefKF]);
+        W.refXY.push_back(normx); W.refXY.push_back(normy);
+        W.vMP.push_back(pMP);
+        W.begin.push_back((int32_t)W.obsKF.size());
+        W.P.K[0] = pRefKF->fx; W.P.K[1] = pRefKF->fy; W.P.K[2] = pRefKF->cx; W.P.K[3] = pRefKF->cy;              // :422
+    }
+    W.P.variant = VBA_VARIANT_PRV_IDP;
+    W.P.algo = VBA_ALGO_GN;                                                                                       // :136
+    Matrix3d Rcb; Vector3d tcb;
+    ConfigParam::GetEigT_cb(Rcb, tcb);                                                                            // :41-43
+    const Quaterniond qcb = MatrixToQuat(Rcb.data());
+    for (int i = 0; i < 3; i++) { W.P.T_cb[i] = tcb[i]; W.P.g_w[i] = gw[i]; }
+    for (int i = 0; i < 4; i++) W.P.T_cb[3 + i] = qcb[i];
+    W.P.depth_min = 0.01; W.P.rho_min = 2e-6;                                                                     // g2otypes.h:122-127, :484
+    FinishProblem(W);
+    return true;
+}
+
+void Optimizer::LocalBAPRVIDP(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocalKeyFrames, bool* pbStopFlag, Map* pMap,
+                              const Vector3d& gw, LocalMapping* pLM) {
+    PackedWindow& W = t_last;
+    if (!PackLocalBAPRVIDP(pCurKF, lLocalKeyFrames, gw, W)) return;
+    if (pbStopFlag && *pbStopFlag) return;                                                                        // :453-455
+    void* h = handle();
+    if (!h) { std::cerr << "LocalBAPRVIDP: no HIP device, local BA skipped (the backend has no CPU path)" << std::endl; return; }
+    {
+        StopMirror stop(pbStopFlag);
+        if (vba_solve(h, &W.P, &W.R, pbStopFlag ? stop.ptr() : nullptr) != 0) {
+            std::cerr << "LocalBAPRVIDP: " << vba_last_error(h) << std::endl;
+            return;
+        }
+    }
+    if (W.R.status == VBA_ABORTED_BEFORE) return;
+    if (W.R.status == VBA_ABORTED_AFTER_STAGE1)
+        std::cerr << "Hint: local mapping optimize only 5 iter. Need more computation resource." << std::endl;  // :469-470
+    std::vector<std::pair<KeyFrame*, MapPoint*>> vToErase;                                                        // :496-517
+    for (size_t i = 0; i < W.vEdgeKF.size(); i++) {
+        if (W.vEdgeMP[i]->isBad()) continue;
+        if (W.outlier[i]) vToErase.push_back(std::make_pair(W.vEdgeKF[i], W.vEdgeMP[i]));
+    }
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                                                     // :520
+    for (auto& e : vToErase) { e.first->EraseMapPointMatch(e.second); e.second->EraseObservation(e.first); }      // :523-532
+    for (int i = 0; i < W.P.n_kf_free; i++) {                                                                     // :536-570
+        KeyFrame* pKFi = W.vKF[i];
+        pKFi->SetNavStatePos({{W.pose[7 * i], W.pose[7 * i + 1], W.pose[7 * i + 2]}});
+        pKFi->SetNavStateRot({{W.pose[7 * i + 3], W.pose[7 * i + 4], W.pose[7 * i + 5], W.pose[7 * i + 6]}});
+        pKFi->SetNavStateVel({{W.vel[3 * i], W.vel[3 * i + 1], W.vel[3 * i + 2]}});
+        pKFi->SetNavStateDeltaBg({{W.bias[12 * i + 6], W.bias[12 * i + 7], W.bias[12 * i + 8]}});
+        pKFi->SetNavStateDeltaBa({{W.bias[12 * i + 9], W.bias[12 * i + 10], W.bias[12 * i + 11]}});
+        pKFi->UpdatePoseFromNS();
+    }
+    for (size_t p = 0; p < W.vMP.size(); p++) {                                                                   // :573-606
+        MapPoint* pMP = W.vMP[p];
+        KeyFrame* pRefKF = pMP->GetReferenceKeyFrame();
+        if (pRefKF->isBad()) continue;
+        const double rho = W.pt[3 * p];
+        const float Pref[3] = {(float)(W.refXY[2 * p] / rho), (float)(W.refXY[2 * p + 1] / rho), (float)(1.0 / rho)};
+        double Rcw[9], twr[3];
+        pRefKF->GetRotation(Rcw);       // float32 values of the (updated) reference pose
+        pRefKF->GetCameraCenter(twr);
+        float Pw[3];
+        for (int i = 0; i < 3; i++)     // Rwr * Pref + twr in float32 like cv::Mat
+            Pw[i] = (float)Rcw[i] * Pref[0] + (float)Rcw[3 + i] * Pref[1] + (float)Rcw[6 + i] * Pref[2] + (float)twr[i];
+        pMP->SetWorldPos(Pw);
+        pMP->UpdateNormalAndDepth();
+    }
+    if (pLM) pLM->SetMapUpdateFlagInTracking(true);                                                               // :620-623
+}
+
+// ------------------------------------------------------------------------------------------------
+bool Optimizer::PackLocalBundleAdjustment(KeyFrame* pKF, PackedWindow& W) {
+    W = PackedWindow();
+    std::memset(&W.P, 0, sizeof W.P);
+    std::list<KeyFrame*> lLocalKeyFrames;                                                                         // :3861-3875
+    lLocalKeyFrames.push_back(pKF);
+    pKF->mnBALocalForKF = pKF->mnId;
+    for (KeyFrame* pKFi : pKF->GetVectorCovisibleKeyFrames()) {
+        pKFi->mnBALocalForKF = pKF->mnId;
+        if (!pKFi->isBad()) lLocalKeyFrames.push_back(pKFi);
+    }
+    std::list<MapPoint*> lLocalMapPoints;                                                                         // :3878-3895
+    for (KeyFrame* pKFi : lLocalKeyFrames)
+        for (MapPoint* pMP : pKFi->GetMapPointMatches())
+            if (pMP && !pMP->isBad() && pMP->mnBALocalForKF != pKF->mnId) {
+                lLocalMapPoints.push_back(pMP);
+                pMP->mnBALocalForKF = pKF->mnId;
+            }
+    std::list<KeyFrame*> lFixedCameras;                                                                           // :3898-3915
+    for (MapPoint* pMP : lLocalMapPoints)
+        for (auto& mit : pMP->GetObservations()) {
+            KeyFrame* pKFi = mit.first;
+            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+                pKFi->mnBAFixedForKF = pKF->mnId;
+                if (!pKFi->isBad()) lFixedCameras.push_back(pKFi);
+            }
+        }
+    std::map<KeyFrame*, int> kfIdx;
+    std::vector<KeyFrame*> fixedLocal;
+    for (KeyFrame* k : lLocalKeyFrames) {
+        if (k->mnId == 0) { fixedLocal.push_back(k); continue; }   // vSE3->setFixed(pKFi->mnId == 0), :3944
+        kfIdx[k] = (int)W.vKF.size();
+        W.vKF.push_back(k);
+    }
+    W.P.n_kf_free = (int32_t)W.vKF.size();
+    for (KeyFrame* k : fixedLocal) { kfIdx[k] = (int)W.vKF.size(); W.vKF.push_back(k); }
+    for (KeyFrame* k : lFixedCameras) { kfIdx[k] = (int)W.vKF.size(); W.vKF.push_back(k); }
+    if (W.P.n_kf_free == 0) return false;
+    for (KeyFrame* k : W.vKF) {  // Converter::toSE3Quat(pKFi->GetPose()): float32 -> double, Quaterniond(R), normalizeRotation
+        double R[9], t[3];
+        k->GetRotation(R);
+        k->GetTranslation(t);
+        Quaterniond q = MatrixToQuat(R);
+        if (q[3] < 0) for (auto& v : q) v = -v;
+        W.pose.insert(W.pose.end(), {t[0], t[1], t[2], q[0], q[1], q[2], q[3]});
+        W.vel.insert(W.vel.end(), {0, 0, 0});
+        W.bias.insert(W.bias.end(), 12, 0.0);
+    }
+    W.begin.push_back(0);
+    for (MapPoint* pMP : lLocalMapPoints) {                                                                       // :3992-4085
+        double Pw[3];
+        pMP->GetWorldPos(Pw);
+        for (auto& mit : pMP->GetObservations()) {
+            KeyFrame* pKFi = mit.first;
+            if (pKFi->isBad() || pKFi->mvuRight[mit.second] >= 0) continue;  // stereo branch never taken for mono
+            const KeyPoint& kpUn = pKFi->mvKeysUn[mit.second];
+            W.obsKF.push_back(kfIdx[pKFi]);
+            W.uv.push_back(kpUn.pt.x); W.uv.push_back(kpUn.pt.y);
+            W.w.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);
+            W.vEdgeKF.push_back(pKFi);
+            W.vEdgeMP.push_back(pMP);
+            W.P.K[0] = pKFi->fx; W.P.K[1] = pKFi->fy; W.P.K[2] = pKFi->cx; W.P.K[3] = pKFi->cy;
+        }
+        W.pt.insert(W.pt.end(), {Pw[0], Pw[1], Pw[2]});
+        W.ref.push_back(0);
+        W.vMP.push_back(pMP);
+        W.begin.push_back((int32_t)W.obsKF.size());
+    }
+    W.P.variant = VBA_VARIANT_SE3_XYZ;
+    W.P.algo = VBA_ALGO_LM;                                                                                       // :3928
+    W.P.T_cb[6] = 1.0;
+    W.P.depth_min = 0.0;
+    FinishProblem(W);
+    return true;
+}
+
+void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, LocalMapping* pLM) {
+    PackedWindow& W = t_last;
+    if (!PackLocalBundleAdjustment(pKF, W)) return;
+    if (pbStopFlag && *pbStopFlag) return;                                                                        // :4088-4090
+    void* h = handle();
+    if (!h) { std::cerr << "LocalBundleAdjustment: no HIP device, local BA skipped (the backend has no CPU path)" << std::endl; return; }
+    {
+        StopMirror stop(pbStopFlag);
+        if (vba_solve(h, &W.P, &W.R, pbStopFlag ? stop.ptr() : nullptr) != 0) {
+            std::cerr << "LocalBundleAdjustment: " << vba_last_error(h) << std::endl;
+            return;
+        }
+    }
+    if (W.R.status == VBA_ABORTED_BEFORE) return;
+    std::vector<std::pair<KeyFrame*, MapPoint*>> vToErase;                                                        // :4146-4163
+    for (size_t i = 0; i < W.vEdgeKF.size(); i++) {
+        if (W.vEdgeMP[i]->isBad()) continue;
+        if (W.outlier[i]) vToErase.push_back(std::make_pair(W.vEdgeKF[i], W.vEdgeMP[i]));
+    }
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                                                     // :4181
+    for (auto& e : vToErase) { e.first->EraseMapPointMatch(e.second); e.second->EraseObservation(e.first); }
+    for (int i = 0; i < W.P.n_kf_free; i++) {                                                                     // :4198-4204, Converter::toCvMat(SE3Quat)
+        const Matrix3d R = QuatToMatrix({{W.pose[7 * i + 3], W.pose[7 * i + 4], W.pose[7 * i + 5], W.pose[7 * i + 6]}});
+        Mat4f T{};
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) T[4 * r + c] = (float)R[3 * r + c];
+            T[4 * r + 3] = (float)W.pose[7 * i + r];
+        }
+        T[15] = 1.0f;
+        W.vKF[i]->SetPose(T);
+    }
+    for (size_t p = 0; p < W.vMP.size(); p++) {                                                                   // :4207-4214
+        const float Pw[3] = {(float)W.pt[3 * p], (float)W.pt[3 * p + 1], (float)W.pt[3 * p + 2]};
+        W.vMP[p]->SetWorldPos(Pw);
+        W.vMP[p]->UpdateNormalAndDepth();
+    }
+    if (pLM) pLM->SetMapUpdateFlagInTracking(true);
+}
+
+}  // namespace ORB_SLAM2

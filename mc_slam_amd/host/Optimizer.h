@@ -1,0 +1,47 @@
+// Optimizer.h -- host facade with the reference's static Optimizer API (include/Optimizer.h:17-98 of
+// mc275/MC_SLAM) whose hot path runs on the MI355X backend through the C-ABI (include/vislam_ba.h).
+//
+// Kept from the reference: graph extraction (src/Optimizer.cpp:49-451) and erase + write-back (:496-623), same
+// conventions (void return, results written in place into KeyFrame / MapPoint, early return when *pbStopFlag is
+// set, Map::mMutexMapUpdate held during write-back only).  Replaced: everything g2o did in between.
+#pragma once
+#include <list>
+#include <vector>
+
+#include "../../include/vislam_ba.h"
+#include "orbslam_min.h"
+
+namespace ORB_SLAM2 {
+
+// flat arrays of one window in the layout of vba_problem, plus the bookkeeping the write-back needs
+struct PackedWindow {
+    vba_problem P;
+    std::vector<double> pose, vel, bias, pt, uv, w, meas, info;
+    std::vector<int32_t> ref, begin, obsKF, imuI, imuJ;
+    std::vector<KeyFrame*> vKF;          // free keyframes first
+    std::vector<MapPoint*> vMP;          // one per landmark row
+    std::vector<KeyFrame*> vEdgeKF;      // per observation edge
+    std::vector<MapPoint*> vEdgeMP;
+    std::vector<double> refXY;           // variant 2: normalised reference pixel per landmark
+    std::vector<uint8_t> outlier;
+    std::vector<double> chi2;
+    vba_result R;
+};
+
+class Optimizer {
+public:
+    // include/Optimizer.h:22-24 (gw is a cv::Mat 3x1 there)
+    static void LocalBAPRVIDP(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, bool* pbStopFlag, Map* pMap,
+                              const Vector3d& gw, LocalMapping* pLM = NULL);
+    // include/Optimizer.h:74
+    static void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, LocalMapping* pLM = NULL);
+
+    // graph extraction only (what the two entry points hand to vba_solve); exposed for tests
+    static bool PackLocalBAPRVIDP(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw, PackedWindow& W);
+    static bool PackLocalBundleAdjustment(KeyFrame* pKF, PackedWindow& W);
+    static const PackedWindow& LastWindow();
+    static PackedWindow& LastWindowMutable();   // test harness: extraction-only calls pack into it
+    static int Device;  // HIP device of the backend handle (one handle per calling thread)
+};
+
+}  // namespace ORB_SLAM2

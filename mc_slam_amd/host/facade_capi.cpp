@@ -1,0 +1,155 @@
+// facade_capi.cpp -- C entry points that let the test-suite build a KeyFrame / MapPoint map from flat arrays,
+// call the C++ facade (Optimizer.h) and read the map back.  Test harness of the facade, not part of the
+// product ABI (that is include/vislam_ba.h).
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "Optimizer.h"
+
+using namespace ORB_SLAM2;
+
+struct FcMap {
+    Map map;
+    LocalMapping lm;
+    std::map<long, std::unique_ptr<KeyFrame>> kfs;
+    std::map<long, std::unique_ptr<MapPoint>> mps;
+};
+
+extern "C" {
+
+void* fc_create() { return new FcMap(); }
+void fc_destroy(void* m) { delete reinterpret_cast<FcMap*>(m); }
+void fc_set_device(int dev) { Optimizer::Device = dev; }
+void fc_set_tbc(const double* R9, const double* p3) {
+    Matrix3d R; Vector3d p;
+    std::memcpy(R.data(), R9, 72); std::memcpy(p.data(), p3, 24);
+    ConfigParam::SetTbc(R, p);
+}
+// nav: P(3) q(4) V(3) bg(3) ba(3) dbg(3) dba(3)
+int fc_add_keyframe(void* m, long id, const double* nav, const double* K, long prev_id, int bad) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    std::unique_ptr<KeyFrame> k(new KeyFrame());
+    k->mnId = id;
+    if ((long unsigned)id + 1 > KeyFrame::nNextId) KeyFrame::nNextId = id + 1;
+    k->fx = (float)K[0]; k->fy = (float)K[1]; k->cx = (float)K[2]; k->cy = (float)K[3];
+    k->mNavState.Set_Pos({{nav[0], nav[1], nav[2]}});
+    k->mNavState.Set_Rot({{nav[3], nav[4], nav[5], nav[6]}});
+    k->mNavState.Set_Vel({{nav[7], nav[8], nav[9]}});
+    k->mNavState.Set_BiasGyr({{nav[10], nav[11], nav[12]}});
+    k->mNavState.Set_BiasAcc({{nav[13], nav[14], nav[15]}});
+    k->mNavState.Set_DeltaBiasGyr({{nav[16], nav[17], nav[18]}});
+    k->mNavState.Set_DeltaBiasAcc({{nav[19], nav[20], nav[21]}});
+    k->mvInvLevelSigma2.resize(8);
+    for (int l = 0; l < 8; l++) k->mvInvLevelSigma2[l] = 1.0f / (float)std::pow(1.2, 2 * l);  // ORBextractor.cpp:427-441
+    k->mbBad = bad != 0;
+    if (prev_id >= 0 && M->kfs.count(prev_id)) k->mpPrevKeyFrame = M->kfs[prev_id].get();
+    k->UpdatePoseFromNS();
+    M->kfs[id] = std::move(k);
+    return 0;
+}
+int fc_set_pose_tcw(void* m, long id, const float* T16) {  // vision-only path: float32 T_cw given directly
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    Mat4f T; std::memcpy(T.data(), T16, 64);
+    M->kfs.at(id)->SetPose(T);
+    return 0;
+}
+int fc_set_covisible(void* m, long id, const long* ids, int n) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    for (int i = 0; i < n; i++) M->kfs.at(id)->mvpOrderedConnectedKeyFrames.push_back(M->kfs.at(ids[i]).get());
+    return 0;
+}
+int fc_set_preint(void* m, long id, const double* meas61, const double* cov81) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    IMUPreintegrator& P = M->kfs.at(id)->mIMUPreInt;
+    P._delta_time = meas61[0];
+    std::memcpy(P._delta_P.data(), meas61 + 1, 24); std::memcpy(P._delta_V.data(), meas61 + 4, 24);
+    std::memcpy(P._delta_R.data(), meas61 + 7, 72);
+    std::memcpy(P._J_P_Biasg.data(), meas61 + 16, 72); std::memcpy(P._J_P_Biasa.data(), meas61 + 25, 72);
+    std::memcpy(P._J_V_Biasg.data(), meas61 + 34, 72); std::memcpy(P._J_V_Biasa.data(), meas61 + 43, 72);
+    std::memcpy(P._J_R_Biasg.data(), meas61 + 52, 72);
+    std::memcpy(P._cov_P_V_Phi.data(), cov81, 648);
+    return 0;
+}
+int fc_add_mappoint(void* m, long id, const float* Pw, long ref_kf) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    std::unique_ptr<MapPoint> p(new MapPoint());
+    p->mnId = id;
+    if ((long unsigned)id + 1 > MapPoint::nNextId) MapPoint::nNextId = id + 1;
+    p->SetWorldPos(Pw);
+    p->mpRefKF = M->kfs.at(ref_kf).get();
+    M->mps[id] = std::move(p);
+    return 0;
+}
+int fc_add_observation(void* m, long mp, long kf, float u, float v, int octave) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    KeyFrame* k = M->kfs.at(kf).get();
+    MapPoint* p = M->mps.at(mp).get();
+    KeyPoint kp; kp.pt.x = u; kp.pt.y = v; kp.octave = octave;
+    k->mvKeysUn.push_back(kp);
+    k->mvuRight.push_back(-1.0f);
+    k->mvpMapPoints.push_back(p);
+    p->mObservations[k] = k->mvKeysUn.size() - 1;
+    return 0;
+}
+static std::list<KeyFrame*> window(FcMap* M, const long* ids, int n) {
+    std::list<KeyFrame*> l;
+    for (int i = 0; i < n; i++) l.push_back(M->kfs.at(ids[i]).get());
+    return l;
+}
+// mode 0: full LocalBAPRVIDP; 1: extraction only (no GPU needed)
+int fc_local_ba_prvidp(void* m, const long* ids, int n, const double* gw, int stop, int mode) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    std::list<KeyFrame*> l = window(M, ids, n);
+    bool bstop = stop != 0;
+    const Vector3d g{{gw[0], gw[1], gw[2]}};
+    if (mode == 1) {
+        return Optimizer::PackLocalBAPRVIDP(l.back(), l, g, Optimizer::LastWindowMutable()) ? 0 : -1;
+    }
+    Optimizer::LocalBAPRVIDP(l.back(), l, &bstop, &M->map, g, &M->lm);
+    return 0;
+}
+int fc_local_ba_vision(void* m, long cur, int stop) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    bool bstop = stop != 0;
+    Optimizer::LocalBundleAdjustment(M->kfs.at(cur).get(), &bstop, &M->map, &M->lm);
+    return 0;
+}
+int fc_get_nav(void* m, long id, double* nav22, float* T16) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    KeyFrame* k = M->kfs.at(id).get();
+    const NavState& ns = k->GetNavState();
+    const Vector3d P = ns.Get_P(), V = ns.Get_V(), bg = ns.Get_BiasGyr(), ba = ns.Get_BiasAcc(), dbg = ns.Get_dBias_Gyr(), dba = ns.Get_dBias_Acc();
+    const Quaterniond q = ns.Get_R();
+    const double v[22] = {P[0], P[1], P[2], q[0], q[1], q[2], q[3], V[0], V[1], V[2], bg[0], bg[1], bg[2], ba[0], ba[1], ba[2],
+                          dbg[0], dbg[1], dbg[2], dba[0], dba[1], dba[2]};
+    std::memcpy(nav22, v, sizeof v);
+    std::memcpy(T16, k->GetPose().data(), 64);
+    return 0;
+}
+int fc_get_mappoint(void* m, long id, float* Pw, int* n_obs, int* n_updates) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    MapPoint* p = M->mps.at(id).get();
+    std::memcpy(Pw, p->mWorldPos, 12);
+    *n_obs = (int)p->mObservations.size();
+    *n_updates = p->nNormalUpdates;
+    return 0;
+}
+int fc_map_updated(void* m) { return reinterpret_cast<FcMap*>(m)->lm.mbMapUpdateFlagForTracking ? 1 : 0; }
+// last packed window (what the facade handed / would hand to vba_solve)
+const vba_problem* fc_last_problem() { return &Optimizer::LastWindow().P; }
+int fc_last_mp_ids(long* out, int cap) {  // mnId of the MapPoint behind every landmark row of the last window
+    const PackedWindow& W = Optimizer::LastWindow();
+    const int n = (int)W.vMP.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = (long)W.vMP[i]->mnId;
+    return n;
+}
+int fc_last_kf_ids(long* out, int cap) {
+    const PackedWindow& W = Optimizer::LastWindow();
+    const int n = (int)W.vKF.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = (long)W.vKF[i]->mnId;
+    return n;
+}
+const vba_result* fc_last_result() { return &Optimizer::LastWindow().R; }
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+"""The C++ host facade (mc_slam_amd/host): same static Optimizer API as the reference, KeyFrame / MapPoint in,
+KeyFrame / MapPoint out.  CPU part: graph extraction reproduces the window the map was built from.
+GPU part: the facade's in-place results equal a direct C-ABI solve of the extracted window."""
+import numpy as np
+import pytest
+
+from mc_slam_amd import abi, synth
+
+facade = pytest.importorskip("facade_lib")
+
+
+def _mini(variant):
+    if variant == abi.VARIANT_PRV_IDP:
+        return synth.make_window(variant, n_kf=9, n_fixed=1, n_pt=250, n_obs=1200, seed=61)
+    return synth.make_window(variant, n_kf=9, n_fixed=2, n_pt=250, n_obs=1400, seed=62)
+
+
+def test_extraction_reproduces_the_window():
+    p = _mini(abi.VARIANT_PRV_IDP)
+    fm = facade.FacadeMap(p)
+    assert fm.local_ba_prvidp(extract_only=True) == 0
+    e = facade.last_problem()
+    fm_tidx = list(fm.tidx)
+    assert (e.variant, e.algo, e.n_kf_free, e.n_kf, e.n_pt, e.n_obs, e.n_imu) == (2, 0, p.n_kf_free, p.n_kf, p.n_pt, p.n_obs, p.n_imu)
+    assert (e.its_stage1, e.its_stage2, e.chi2_th, e.depth_min, e.rho_min) == (5, 10, 5.991, 0.01, 2e-6)
+    assert (e.huber_vis, e.huber_prv, e.huber_bias) == (abi.HUBER_VIS, abi.HUBER_PRV, abi.HUBER_BIAS)
+    mp_ids, kf_ids = facade.last_ids()
+    # free keyframes keep the window order; states are passed through unchanged (double NavState)
+    assert list(kf_ids[:p.n_kf_free]) == sorted(fm_tidx[i] for i in range(p.n_kf_free))
+    row_of = {fm_tidx[i]: i for i in range(p.n_kf)}          # mnId -> row of the generator's problem
+    rows = [row_of[t] for t in kf_ids]
+    np.testing.assert_array_equal(e.kf_pose, p.kf_pose[rows])
+    np.testing.assert_array_equal(e.kf_vel[:p.n_kf_free], p.kf_vel[:p.n_kf_free])
+    np.testing.assert_array_equal(e.kf_bias, p.kf_bias[rows])
+    # landmarks come in the order the window's keyframes list them (lLocalMapPoints, src/Optimizer.cpp:59-79):
+    # a permutation of the generator's rows; per landmark the same edges in ascending keyframe id
+    assert sorted(mp_ids) == list(range(p.n_pt))
+    inv_row = {r: i for i, r in enumerate(rows)}
+    for j, q in enumerate(mp_ids):
+        a, b = e.pt_obs_begin[j], e.pt_obs_begin[j + 1]
+        c, d = p.pt_obs_begin[q], p.pt_obs_begin[q + 1]
+        assert b - a == d - c
+        order = np.argsort([fm_tidx[k] for k in p.obs_kf[c:d]], kind="stable")   # map order = ascending mnId
+        np.testing.assert_array_equal(e.obs_kf[a:b], [inv_row[k] for k in p.obs_kf[c:d][order]])
+        np.testing.assert_array_equal(e.obs_uv[a:b], p.obs_uv[c:d][order])
+        np.testing.assert_allclose(e.obs_w[a:b], p.obs_w[c:d][order], rtol=2e-7)   # float32 pyramid table
+        assert e.pt_ref_kf[j] == inv_row[p.pt_ref_kf[q]]
+        # inverse depth / bearing are recomputed from the float32 map (src/Optimizer.cpp:355-385)
+        np.testing.assert_allclose(e.pt[j], p.pt[q], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(e.T_cb, p.T_cb, atol=1e-12)
+    np.testing.assert_array_equal(e.imu_meas, p.imu_meas)
+    np.testing.assert_allclose(e.imu_info_prv, p.imu_info_prv, rtol=1e-5)
+
+
+def test_stop_flag_returns_before_touching_anything():
+    p = _mini(abi.VARIANT_PRV_IDP)
+    fm = facade.FacadeMap(p)
+    before = [fm.nav(t)[0].copy() for t in fm.window_ids()]
+    fm.local_ba_prvidp(stop=1)     # src/Optimizer.cpp:453-455 -- needs no GPU: returns before vba_solve
+    after = [fm.nav(t)[0] for t in fm.window_ids()]
+    assert all((a == b).all() for a, b in zip(before, after)) and fm.L.fc_map_updated(fm.m) == 0
+    fm.close()
+
+
+@pytest.mark.gpu
+def test_facade_prvidp_equals_direct_solve():
+    from mc_slam_amd import backend
+    p = _mini(abi.VARIANT_PRV_IDP)
+    fm = facade.FacadeMap(p)
+    fm.local_ba_prvidp(extract_only=True)
+    e = facade.last_problem()
+    ba = backend.LocalBA(0)
+    q, r = ba.solve(e)
+    ba.close()
+    fm2 = facade.FacadeMap(p)
+    n_obs_before = [fm2.mappoint(i)[1] for i in range(p.n_pt)]
+    fm2.local_ba_prvidp()
+    assert fm2.L.fc_map_updated(fm2.m) == 1
+    for i, t in enumerate(fm2.window_ids()):
+        nav, T = fm2.nav(int(t))
+        assert (nav[:7] == q.kf_pose[i]).all() and (nav[7:10] == q.kf_vel[i]).all() and (nav[16:22] == q.kf_bias[i, 6:]).all()
+        # float32 Tcw refreshed from the NavState (KeyFrame::UpdatePoseFromNS)
+        Rwb = synth.quat_to_rot(nav[3:7]); R_bc, p_bc = p.truth["R_bc"], p.truth["p_bc"]
+        Rcw = (Rwb @ R_bc).T
+        np.testing.assert_allclose(T[:3, :3], Rcw, atol=2e-6)
+        np.testing.assert_allclose(T[:3, 3], -Rcw @ (Rwb @ p_bc + nav[:3]), atol=2e-5)
+    # erased observations = the erase list; landmarks rewritten from rho through the updated reference pose
+    erased = sum(n_obs_before) - sum(fm2.mappoint(i)[1] for i in range(p.n_pt))
+    assert erased == int(r.obs_outlier.sum()) > 0
+    mp_ids, kf_ids = facade.last_ids()
+    for j in range(0, len(mp_ids), 17):
+        Pw, _n, upd = fm2.mappoint(int(mp_ids[j]))
+        assert upd == 1
+        T = fm2.pose_tcw(int(kf_ids[e.pt_ref_kf[j]])).astype(np.float64)
+        Pc = np.array([e.pt[j, 1], e.pt[j, 2], 1.0]) / q.pt[j, 0]
+        np.testing.assert_allclose(Pw, T[:3, :3].T @ (Pc - T[:3, 3]), rtol=1e-5, atol=1e-5)
+    fm.close(); fm2.close()
+
+
+@pytest.mark.gpu
+def test_facade_vision_equals_direct_solve():
+    from mc_slam_amd import backend
+    p = _mini(abi.VARIANT_SE3_XYZ)
+    fm = facade.FacadeMap(p)
+    fm.local_ba_vision()
+    res = facade.lib().fc_last_result().contents
+    assert res.status == 0 and res.its_done[0] >= 1
+    # expected: the same window packed by hand from the generator's arrays in the facade's row order (cur KF,
+    # covisibles, fixed observers), with the float32 narrowing the map applies, solved directly through the C-ABI
+    ba = backend.LocalBA(0)
+    order = [sorted(fm.tidx[i] for i in range(p.n_kf_free))[-1]] + sorted(fm.tidx[i] for i in range(p.n_kf_free))[:-1]
+    q, r = ba.solve(_reordered(p, fm, order))
+    ba.close()
+    assert tuple(res.its_done) == r.its_done and res.n_outliers == r.n_outliers
+    for row, t in enumerate(order):
+        T = fm.pose_tcw(t)
+        np.testing.assert_allclose(T[:3, 3], q.kf_pose[row, :3].astype(np.float32), atol=1e-6)
+    fm.close()
+
+
+def _reordered(p, fm, order):
+    """the Problem with keyframe rows in the order the facade packs them (cur KF, covisibles, then fixed observers in
+    first-encounter order) and float32-narrowed poses / points, as the map stores them"""
+    t2i = {fm.tidx[i]: i for i in range(p.n_kf)}
+    fixed = []
+    seen = set(order)
+    # fixed cameras: in the order the local map points' observations meet them (src/Optimizer.cpp:3898-3915)
+    # GetMapPointMatches() order = keypoint order = order in which observations were added = landmark index order
+    pts_in_order = []
+    mark = set()
+    for t in order:
+        i = t2i[t]
+        qs = sorted({int(np.searchsorted(p.pt_obs_begin, o, side="right") - 1) for o in np.nonzero(p.obs_kf == i)[0]})
+        for q in qs:
+            if q not in mark:
+                mark.add(q); pts_in_order.append(q)
+    for q in pts_in_order:
+        for o in range(p.pt_obs_begin[q], p.pt_obs_begin[q + 1]):
+            t = fm.tidx[p.obs_kf[o]]
+            if t not in seen:
+                seen.add(t); fixed.append(t)
+    rows = [t2i[t] for t in order + fixed]
+    inv = {old: new for new, old in enumerate(rows)}
+    pose = []
+    for i in rows:
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = synth.quat_to_rot(p.kf_pose[i, 3:]); T[:3, 3] = p.kf_pose[i, :3]
+        Td = T.astype(np.float64)
+        qd = synth.rot_to_quat(Td[:3, :3])
+        pose.append(np.concatenate([Td[:3, 3], qd]))
+    begin = [0]; okf = []; ouv = []; ow = []; pts = []
+    for q in pts_in_order:
+        for o in range(p.pt_obs_begin[q], p.pt_obs_begin[q + 1]):
+            okf.append(inv[p.obs_kf[o]]); ouv.append(p.obs_uv[o]); ow.append(p.obs_w[o])
+        begin.append(len(okf)); pts.append(np.float32(p.pt[q]).astype(np.float64))
+    return abi.Problem(variant=0, n_kf_free=len(order), kf_pose=np.array(pose), pt=np.array(pts), pt_obs_begin=begin, obs_kf=okf,
+                       obs_uv=np.array(ouv), obs_w=ow, K=np.float32(p.K).astype(np.float64), algo=abi.ALGO_LM, depth_min=0.0)
