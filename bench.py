@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="windows per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="windows per GPU per step")
     ap.add_argument("--distinct", type=int, default=16, help="distinct seeded windows generated per rank (cycled to fill the batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
