@@ -37,7 +37,7 @@ struct WinDesc {
     int tl_step0;   // offset of this window's step_begin / pan_begin rows (nb + 1 entries each)
     int tl_pair0;   // offset into the tile-pair list
     int tl_pan0;    // offset into the panel-tile list
-    int pad0;
+    int lb0;        // offset into the k_lin2 landmark-run table
     long long S0;   // offset (doubles) into S
     double K[4];
     double Rcb[9], tcb[3], g[3];

@@ -36,6 +36,7 @@ struct Batch {
     int* var_act;
     // structure (g2o buildStructure analogue, built on the host at upload)
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
+    const int* lin_blk;  // k_lin2: first landmark of every workgroup's run (n_part_lin + 1 entries per window)
     // tile structure of the factor (symbolic factorisation on 32x32 tiles, built at upload)
     const int *tl_step_begin, *tl_pairs, *tl_pan_begin, *tl_pan;
     double* part;
@@ -470,6 +471,222 @@ __global__ void __launch_bounds__(64) k_lin(Batch B, int nblk_pt, int mode) {
         if (k >= d.n_imu) return;
         lin_imu(B, d, k, mode, sm);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K_lin2 (inverse-depth variant): the same products as k_lin, but edge-parallel.  A 256-thread workgroup owns a
+// run of consecutive landmarks with <= 256 edges (ranges built at upload): one lane per EDGE evaluates the
+// residual and Jacobians (coalesced observation loads), the per-landmark sums (D, b_l, W0, g0, G0) are taken by
+// one lane per LANDMARK from LDS, and the 256-B edge records leave through an LDS transpose as contiguous
+// 16-B chunks instead of 64 scattered records per store instruction.
+// ------------------------------------------------------------------------------------------------
+#define LIN2_ES 31   // LDS row stride (doubles) of one edge: [0..11] Bi [12..23] Br [24..25] a [26..27] r -> later [24..29] g
+#define LIN2_PS 19   // LDS row stride of one landmark: dd, y(3), Xw(3), N0(9), ref_free, sD, beta
+
+__global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
+    extern __shared__ double lsm[];
+    double* ER = lsm;                       // 256 x LIN2_ES
+    double* PT = lsm + 256 * LIN2_ES;       // 64 x LIN2_PS
+    double* red = PT + 64 * LIN2_PS;        // 256
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x >= nblk_lin) {
+        const int k = blockIdx.x - nblk_lin;
+        if (k >= d.n_imu) return;
+        if (t >= 64) return;  // one wave per IMU pair; the barriers inside lin_imu then only see this wave
+        lin_imu(B, d, k, mode, lsm);
+        return;
+    }
+    const int lb = blockIdx.x;
+    if (lb >= d.n_part_lin) return;
+    const int* tbl = B.lin_blk + d.lb0;
+    const int p0 = tbl[lb], p1 = tbl[lb + 1];
+    const int* ob = B.pt_obs_begin + d.pt0 + w;
+    const int e0 = ob[p0], e1 = ob[p1];
+    const int ne = e1 - e0, npb = p1 - p0;
+    const double fx = d.K[0], fy = d.K[1], cx = d.K[2], cy = d.K[3];
+    // A. one lane per landmark: quantities shared by all its edges
+    if (t < npb) {
+        const size_t gp = d.pt0 + p0 + t;
+        double rho = B.pt[3 * gp];
+        const double xb = B.pt[3 * gp + 1], yb = B.pt[3 * gp + 2];
+        if (rho < 1e-6) rho = 1e-6;  // g2otypes.cpp:42-47
+        const double dd = 1.0 / rho;
+        const double P0[3] = {xb * dd, yb * dd, dd};
+        const int rf = B.pt_ref[gp];
+        const double* C0 = B.kfR + 12 * (size_t)(d.kf0 + rf);
+        double R0[9], c0[3], b0[3], y[3], Xw[3], tb[3], Hb[9], N0[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) R0[i] = C0[i];
+        mtv3(d.Rcb, P0, c0);
+        mtv3(d.Rcb, d.tcb, tb);
+        b0[0] = c0[0] - tb[0]; b0[1] = c0[1] - tb[1]; b0[2] = c0[2] - tb[2];
+        mv3(R0, b0, Xw);
+        Xw[0] += C0[9]; Xw[1] += C0[10]; Xw[2] += C0[11];
+        mv3(R0, c0, y);
+        hat3(b0, Hb);
+        mm3(R0, Hb, N0);
+        double* q = PT + t * LIN2_PS;
+        q[0] = dd;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { q[1 + i] = y[i]; q[4 + i] = Xw[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; i++) q[7 + i] = N0[i];
+        q[16] = (rf < d.n_free) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // B. one lane per edge
+    double chi = 0.0;
+    double Bi[12], a[2] = {0, 0}, r2[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 12; i++) Bi[i] = 0.0;
+    bool on = false;
+    int pl = 0;
+    if (t < ne) {
+        const size_t go = d.obs0 + e0 + t;
+        pl = B.obs_pt[go] - p0;
+        const double* q = PT + pl * LIN2_PS;
+        const int kf = B.obs_kf[go];
+        const double* Ci = B.kfR + 12 * (size_t)(d.kf0 + kf);
+        double Ri[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Ri[i] = Ci[i];
+        const double v[3] = {q[4] - Ci[9], q[5] - Ci[10], q[6] - Ci[11]};
+        double ta[3], Pc[3];
+        mtv3(Ri, v, ta);
+        mv3(d.Rcb, ta, Pc);
+        Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
+        B.depth_e[go] = Pc[2];
+        double Br[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) Br[i] = 0.0;
+        if (!B.lvl[go]) {
+            const double iz = 1.0 / Pc[2];
+            const double ex = B.obs_uv[2 * go] - (Pc[0] * iz * fx + cx);
+            const double ey = B.obs_uv[2 * go + 1] - (Pc[1] * iz * fy + cy);
+            const double wgt = B.obs_w[go];
+            const double s = ex * (wgt * ex) + ey * (wgt * ey);
+            B.chi2_e[go] = s;
+            double rw = 1.0;
+            if (c.robust_vis) chi = huber(s, d.hub_vis, &rw);
+            else chi = s;
+            if (mode == LIN_FULL) {
+                on = true;
+                const double sc = sqrt(rw * wgt);
+                const double Jp[6] = {fx * iz, 0.0, -Pc[0] * iz * fx * iz, 0.0, fy * iz, -Pc[1] * iz * fy * iz};
+                double Jc[6], JA[6];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        Jc[3 * rr + k] = Jp[3 * rr] * d.Rcb[k] + Jp[3 * rr + 1] * d.Rcb[3 + k] + Jp[3 * rr + 2] * d.Rcb[6 + k];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        JA[3 * rr + k] = Jc[3 * rr] * Ri[3 * k] + Jc[3 * rr + 1] * Ri[3 * k + 1] + Jc[3 * rr + 2] * Ri[3 * k + 2];
+                const bool ref_free = q[16] != 0.0, of = kf < d.n_free;
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    a[rr] = sc * q[0] * (JA[3 * rr] * q[1] + JA[3 * rr + 1] * q[2] + JA[3 * rr + 2] * q[3]);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const double jan = JA[3 * rr] * q[7 + k] + JA[3 * rr + 1] * q[10 + k] + JA[3 * rr + 2] * q[13 + k];
+                        Br[6 * rr + k] = ref_free ? -sc * JA[3 * rr + k] : 0.0;
+                        Br[6 * rr + 3 + k] = ref_free ? sc * jan : 0.0;
+                        Bi[6 * rr + k] = of ? sc * JA[3 * rr + k] : 0.0;
+                    }
+                    const double j0 = Jc[3 * rr], j1 = Jc[3 * rr + 1], j2 = Jc[3 * rr + 2];
+                    Bi[6 * rr + 3] = of ? -sc * (j1 * ta[2] - j2 * ta[1]) : 0.0;
+                    Bi[6 * rr + 4] = of ? -sc * (j2 * ta[0] - j0 * ta[2]) : 0.0;
+                    Bi[6 * rr + 5] = of ? -sc * (j0 * ta[1] - j1 * ta[0]) : 0.0;
+                }
+                r2[0] = sc * ex; r2[1] = sc * ey;
+            }
+        }
+        if (mode == LIN_FULL) {
+            double* er = ER + t * LIN2_ES;
+#pragma unroll
+            for (int i = 0; i < 12; i++) { er[i] = Bi[i]; er[12 + i] = Br[i]; }
+            er[24] = a[0]; er[25] = a[1]; er[26] = r2[0]; er[27] = r2[1];
+        }
+    }
+    if (mode != LIN_FULL) {
+        const double tot = block_sum<256>(chi, red);
+        if (t == 0) B.part[d.part0 + lb] = tot;
+        return;
+    }
+    __syncthreads();
+    // C. one lane per landmark: sums over its edges (fixed order)
+    if (t < npb) {
+        const int p = p0 + t;
+        const size_t gp = d.pt0 + p;
+        double D = 0, bl = 0, W0[6] = {0, 0, 0, 0, 0, 0}, g0[6] = {0, 0, 0, 0, 0, 0}, G0[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) G0[i] = 0;
+        for (int o = ob[p] - e0; o < ob[p + 1] - e0; o++) {
+            const double* er = ER + o * LIN2_ES;
+            const double a0 = er[24], a1 = er[25], q0 = er[26], q1 = er[27];
+            D += a0 * a0 + a1 * a1;
+            bl -= a0 * q0 + a1 * q1;
+            int gi = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double b0 = er[12 + i], b1 = er[18 + i];
+                W0[i] += b0 * a0 + b1 * a1;
+                g0[i] -= b0 * q0 + b1 * q1;
+#pragma unroll
+                for (int j = i; j < 6; j++) G0[gi++] += b0 * er[12 + j] + b1 * er[18 + j];
+            }
+        }
+        const double sD = (D > 0.0) ? sqrt(1.0 / D) : 0.0;
+        const double beta = sD * bl;
+        PT[t * LIN2_PS + 17] = sD;
+        PT[t * LIN2_PS + 18] = beta;
+        double* sr = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + d.n_obs + p);
+#pragma unroll
+        for (int i = 0; i < 6; i++) sr[i] = W0[i] * sD;
+        sr[6] = beta;
+        sr[7] = sD;
+        double* pr = B.prec + VBA_PREC * gp;
+#pragma unroll
+        for (int i = 0; i < 21; i++) pr[i] = G0[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) pr[21 + i] = g0[i];
+        pr[27] = D;
+    }
+    __syncthreads();
+    // D. one lane per edge: slot record, g into the LDS row
+    if (t < ne) {
+        const double sD = PT[pl * LIN2_PS + 17], beta = PT[pl * LIN2_PS + 18];
+        double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + e0 + t);
+        double* er = ER + t * LIN2_ES;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            sl[i] = on ? (Bi[i] * a[0] + Bi[6 + i] * a[1]) * sD : 0.0;
+            er[24 + i] = -(Bi[i] * r2[0] + Bi[6 + i] * r2[1]);
+        }
+        sl[6] = beta;
+        sl[7] = sD;
+    }
+    __syncthreads();
+    // E. edge records out, as contiguous 16-B chunks
+    {
+        double* dst = B.erec + VBA_EREC * (size_t)(d.obs0 + e0);
+        const int nch = ne * (VBA_EREC / 2);
+        for (int ch = t; ch < nch; ch += 256) {
+            const int row = ch / (VBA_EREC / 2), col = (ch % (VBA_EREC / 2)) * 2;
+            double2 v;
+            v.x = (col < 30) ? ER[row * LIN2_ES + col] : 0.0;
+            v.y = (col + 1 < 30) ? ER[row * LIN2_ES + col + 1] : 0.0;
+            *reinterpret_cast<double2*>(dst + (size_t)row * VBA_EREC + col) = v;
+        }
+    }
+    const double tot = block_sum<256>(chi, red);
+    if (t == 0) B.part[d.part0 + lb] = tot;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -44,7 +44,7 @@ enum {
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
-    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_N
+    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_N
 };
 
 struct ProfEvt {
@@ -63,7 +63,7 @@ struct Handle {
     int n_win = 0;
     // launch geometry (maxima over the batch)
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
-    int max_nS = 0, max_its[2] = {0, 0}, max_free = 0;
+    int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0;
     std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
     int algo = 0, variant = 2;
@@ -275,12 +275,13 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->desc.assign(n, WinDesc());
     std::vector<double> pose, vel, bias, pt, uv, ow, meas, info;
     std::vector<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
-    std::vector<int> tlstep, tlpair, tlpanb, tlpan;
+    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk;
     h->step_grid.clear();
     h->tile_updates = 0;
     size_t S_tot = 0;
     int kf0 = 0, pt0 = 0, obs0 = 0, imu0 = 0, pair0 = 0, item0 = 0, pimu0 = 0, vec0 = 0, part0 = 0;
     h->max_free = 0;
+    h->max_lin_blk = 0;
     h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
     h->max_its[0] = h->max_its[1] = 0;
     for (int w = 0; w < n; w++) {
@@ -307,6 +308,24 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         d.pair0 = pair0; d.n_pairs = d.n_free * (d.n_free + 1) / 2;
         d.item0 = item0; d.pimu0 = pimu0; d.vec0 = vec0; d.part0 = part0;
         d.n_part_lin = (d.n_pt + 63) / 64;
+        if (P->variant == VBA_VARIANT_PRV_IDP) {
+            // k_lin2 work split: runs of consecutive landmarks with <= 256 edges and <= 64 landmarks per workgroup
+            d.lb0 = (int)linblk.size();
+            int nb2 = 0, p = 0;
+            while (p < d.n_pt) {
+                linblk.push_back(p);
+                nb2++;
+                int ne = 0, np2 = 0;
+                while (p < d.n_pt && np2 < 64) {
+                    const int k = P->pt_obs_begin[p + 1] - P->pt_obs_begin[p];
+                    if (k > 256) return fail(h, "a landmark with more than 256 observations is not supported");
+                    if (ne + k > 256) break;
+                    ne += k; np2++; p++;
+                }
+            }
+            linblk.push_back(d.n_pt);
+            d.n_part_lin = nb2;
+        }
         d.S0 = (long long)S_tot;
         for (int i = 0; i < 4; i++) d.K[i] = P->K[i];
         quat_to_R_host(P->T_cb + 3, d.Rcb);
@@ -353,9 +372,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         pair0 += d.n_pairs; item0 += (int)(st.items.size() / 2); pimu0 += (int)(st.pimu.size() / 2);
         vec0 += d.nS;
         const int obs_blk = (d.n_obs + 63) / 64;
-        part0 += std::max(3 * d.n_part_lin, 2 * obs_blk) + 2;
+        part0 += std::max(3 * std::max(d.n_part_lin, (d.n_pt + 63) / 64), 2 * obs_blk) + 2;
         S_tot += (size_t)d.nS * d.nS;
-        h->max_pt_blk = std::max(h->max_pt_blk, d.n_part_lin);
+        h->max_pt_blk = std::max(h->max_pt_blk, (d.n_pt + 63) / 64);
+        h->max_lin_blk = std::max(h->max_lin_blk, d.n_part_lin);
         h->max_imu = std::max(h->max_imu, d.n_imu);
         h->max_pairs = std::max(h->max_pairs, d.n_pairs);
         h->max_free = std::max(h->max_free, d.n_free);
@@ -389,7 +409,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (h2d(h, BUF_TLSTEP, tlstep) || h2d(h, BUF_TLPAIR, tlpair) || h2d(h, BUF_TLPANB, tlpanb) || h2d(h, BUF_TLPAN, tlpan)) return -1;
     if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
     if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b) || h2d(h, BUF_ITEMBEG, item_begin) || h2d(h, BUF_ITEMS, items)) return -1;
-    if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu)) return -1;
+    if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d(h, BUF_LINBLK, linblk)) return -1;
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
     // S: zero everything once, identity on the pads
     for (int w = 0; w < n; w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
@@ -431,6 +451,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
+    B.lin_blk = dp<int>(h, BUF_LINBLK);
     B.part = dp<double>(h, BUF_PART);
     B.stop_word = h->stop_dev;
     B.out_outlier = dp<unsigned char>(h, BUF_OUTL); B.out_chi2 = dp<double>(h, BUF_OUTCHI);
@@ -476,8 +497,10 @@ void enqueue_solve_iteration(Handle* h) {
 
 void enqueue_lin(Handle* h, int mode) {
     ProfScope ps(h, VBA_PROF_LINEARIZE);
-    if (h->variant == VBA_VARIANT_PRV_IDP)
-        hipLaunchKernelGGL(k_lin, dim3(h->max_pt_blk + h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
+    if (h->variant == VBA_VARIANT_PRV_IDP) {
+        const size_t shm = (256 * LIN2_ES + 64 * LIN2_PS + 256) * sizeof(double);
+        hipLaunchKernelGGL(k_lin2, dim3(h->max_lin_blk + h->max_imu, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
+    }
     else
         hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk + h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
 }
@@ -681,6 +704,8 @@ int vba_create(int device, void** handle) {
     void* dpw = nullptr;
     if (hipHostGetDevicePointer(&dpw, hp, 0) != hipSuccess) { delete h; return -5; }
     h->stop_dev = reinterpret_cast<int*>(dpw);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lin2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((256 * LIN2_ES + 64 * LIN2_PS + 256) * sizeof(double)));
     memset(&h->prof, 0, sizeof h->prof);
     *handle = h;
     return 0;
@@ -748,7 +773,7 @@ int vba_debug_buf_id(const char* name) {
     static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
-        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI"};
+        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
