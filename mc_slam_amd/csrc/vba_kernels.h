@@ -36,6 +36,7 @@ struct Batch {
     int* var_act;
     // structure (g2o buildStructure analogue, built on the host at upload)
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
+    const int *off_pair, *pair_mask;  // off-diagonal pair indices; per pair: which sub-blocks of S are ever read
     const int* lin_blk;  // k_lin2: first landmark of every workgroup's run (n_part_lin + 1 entries per window)
     // tile structure of the factor (symbolic factorisation on 32x32 tiles, built at upload)
     const int *tl_step_begin, *tl_pairs, *tl_pan_begin, *tl_pan;
@@ -764,16 +765,21 @@ DEVI bool schur_map(const Batch& B, int per_win, int& w, int& idx) {
 // adds the IMU blocks, applies the active-set / damping rules and writes one pdim x pdim block of S (lower
 // triangle only: the factorisation never reads above the diagonal)
 DEVI void schur_write_block(const Batch& B, const WinDesc& d, const WinCtrl& c, int w, int pr, int a, int b,
-                            const double* blk) {
-    const int t = threadIdx.x, P = d.pdim, n = d.nS;
+                            const double* blk, int t = threadIdx.x, int nt = 64, int bstride = -1) {
+    const int P = d.pdim, n = d.nS;
+    if (bstride < 0) bstride = P;
     const bool diag = (a == b);
     const double lambda = (d.algo == 1) ? c.lambda : 0.0;
     const int qb = B.pimu_begin[d.pair0 + w + pr], qe = B.pimu_begin[d.pair0 + w + pr + 1];
     const int* va = B.var_act + d.vec0;
     double* S = B.S + d.S0;
-    for (int q = t; q < P * P; q += 64) {
+    // sub-blocks that no tile of the factor ever reads (structurally zero in L under the V/Bias-first order) are
+    // not written at all: bit0 PRxPR, bit1 PRxVB, bit2 VBxPR, bit3 VBxVB (mask built with the tile lists at upload)
+    const int mask = B.pair_mask[d.pair0 + pr];
+    for (int q = t; q < P * P; q += nt) {
         const int r = q / P, col = q % P;
-        double s = blk[q];
+        if (!((mask >> ((r >= 6 ? 2 : 0) + (col >= 6 ? 1 : 0))) & 1)) continue;
+        double s = (r < 6 && col < 6) ? blk[r * bstride + col] : 0.0;
         for (int m = qb; m < qe; m++) {
             const int k = B.pimu[2 * (size_t)(d.pimu0 + m)], role = B.pimu[2 * (size_t)(d.pimu0 + m) + 1];
             const double* H = B.imuH + VBA_IMUH * (size_t)(d.imu0 + k);
@@ -790,27 +796,39 @@ DEVI void schur_write_block(const Batch& B, const WinDesc& d, const WinCtrl& c, 
     }
 }
 
-// off-diagonal keyframe pairs (a < b): 36 accumulators per lane, lanes stride over the pair's items.
+// off-diagonal keyframe pairs (a < b).  A pair has ~90 items on average, far too few for a whole wave: four
+// pairs share one wave, 16 lanes each (the 36-value reduction then costs 4 butterfly steps per FOUR pairs
+// instead of 6 per pair, and every lane sees ~6 items instead of ~1.4).
 // LD = landmark dimension (1: inverse depth, slot record 8 doubles; 3: XYZ, slot record 24 doubles)
-template <int LD>
-DEVI void schur_off_body(const Batch& B, int max_pairs, double* blk) {
+// LP = lanes per pair: 64 (one pair per wave: small batches, latency) or 16 (four pairs per wave: throughput)
+template <int LD, int LP>
+DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4) {
     constexpr int SS = (LD == 1) ? VBA_SLOT : VBA_SLOT3;
-    int w, pr;
-    if (!schur_map(B, max_pairs, w, pr)) return;
+    int w, quad;
+    if (!schur_map(B, max_quads, w, quad)) return;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
     if (!win_on(d, c)) return;
-    if (pr >= d.n_pairs) return;
-    const int t = threadIdx.x;
-    const int a = B.pair_a[d.pair0 + pr], b = B.pair_b[d.pair0 + pr];
-    if (a == b) return;  // k_schur_diag
+    constexpr int NG = 64 / LP;  // pairs per wave
+    const int t = threadIdx.x, g = t / LP, l16 = t % LP;
+    // off-diagonal pairs only: enumerate them through the host-built list of their pair indices
+    const int n_off = d.n_pairs - d.n_free;
+    const int oi = quad * NG + g;
+    const bool have = oi < n_off;
+    int pr = 0, a = 0, b = 0, ib = 0, ie = 0;
+    if (have) {
+        pr = B.off_pair[d.pair0 + oi];
+        a = B.pair_a[d.pair0 + pr];
+        b = B.pair_b[d.pair0 + pr];
+        ib = B.item_begin[d.pair0 + w + pr];
+        ie = B.item_begin[d.pair0 + w + pr + 1];
+    }
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
-    const int ib = B.item_begin[d.pair0 + w + pr], ie = B.item_begin[d.pair0 + w + pr + 1];
     const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
-    for (int it = ib + t; it < ie; it += 64) {
+    for (int it = ib + l16; it < ie; it += LP) {
         const int2 itm = items[it];
         const int sa = itm.x, sb = itm.y;
         const double* qa = slots + SS * (size_t)sa;
@@ -825,6 +843,8 @@ DEVI void schur_off_body(const Batch& B, int max_pairs, double* blk) {
 #pragma unroll
                 for (int l = 0; l < LD; l++) acc[6 * i + j] -= UA[LD * i + l] * UB[LD * j + l];
         if (LD == 1) {
+            // direct H_pp terms of the pairs that involve the landmark's reference keyframe (sorted to the end
+            // of a pair's list)
             if (sa >= d.n_obs) {         // a = reference KF, b = observer: Br^T Bi of edge sb
                 const double* rb = B.erec + VBA_EREC * (size_t)(d.obs0 + sb);
 #pragma unroll
@@ -856,27 +876,37 @@ DEVI void schur_off_body(const Batch& B, int max_pairs, double* blk) {
             }
         }
     }
+    // fixed-order butterfly inside each LP-lane group
 #pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] = wave_sum(acc[i]);  // fixed-order butterfly
-    const int P = d.pdim;
-    for (int q = t; q < P * P; q += 64) blk[q] = 0.0;
-    __syncthreads();
-    if (t == 0) {
+    for (int i = 0; i < 36; i++) {
+        double v = acc[i];
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+        for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        acc[i] = v;
+    }
+    double* blk = blk4 + g * 36;
+    if (l16 == 0) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) blk[i * P + j] = acc[6 * i + j];
+        for (int i = 0; i < 36; i++) blk[i] = acc[i];
     }
     __syncthreads();
-    schur_write_block(B, d, c, w, pr, a, b, blk);
+    if (have) schur_write_block(B, d, c, w, pr, a, b, blk, l16, LP, 6);
 }
-__global__ void __launch_bounds__(64, 3) k_schur_off(Batch B, int max_pairs) {
-    __shared__ double blk[15 * 15 + 16];
-    schur_off_body<1>(B, max_pairs, blk);
+__global__ void __launch_bounds__(64, 3) k_schur_off(Batch B, int max_quads) {
+    __shared__ double blk4[4 * 36];
+    schur_off_body<1, 16>(B, max_quads, blk4);
 }
-__global__ void __launch_bounds__(64) k_schur_off3(Batch B, int max_pairs) {
-    __shared__ double blk[15 * 15 + 16];
-    schur_off_body<3>(B, max_pairs, blk);
+__global__ void __launch_bounds__(64, 3) k_schur_off_w(Batch B, int max_quads) {  // one pair per wave
+    __shared__ double blk4[4 * 36];
+    schur_off_body<1, 64>(B, max_quads, blk4);
+}
+__global__ void __launch_bounds__(64) k_schur_off3(Batch B, int max_quads) {
+    __shared__ double blk4[4 * 36];
+    schur_off_body<3, 16>(B, max_quads, blk4);
+}
+__global__ void __launch_bounds__(64) k_schur_off3_w(Batch B, int max_quads) {
+    __shared__ double blk4[4 * 36];
+    schur_off_body<3, 64>(B, max_quads, blk4);
 }
 
 // diagonal pairs (a,a): every slot of keyframe a; also the reduced rhs (block_solver.hpp:436-439), the

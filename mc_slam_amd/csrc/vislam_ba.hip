@@ -44,7 +44,7 @@ enum {
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
-    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_N
+    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_N
 };
 
 struct ProfEvt {
@@ -63,7 +63,7 @@ struct Handle {
     int n_win = 0;
     // launch geometry (maxima over the batch)
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
-    int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0;
+    int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0, max_quads = 1, max_offp = 1;
     std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
     int algo = 0, variant = 2;
@@ -131,6 +131,7 @@ struct Structure {
     std::vector<int> pair_a, pair_b, item_begin, items, pimu_begin, pimu, obs_pt;
     std::vector<int> step_begin, tpairs, pan_begin, pan;  // tile lists of the factorisation
     std::vector<int> step_npairs;
+    std::vector<int> off_pair, pair_mask;
 };
 
 int vpos_host(int pdim, int nf, int a, int r) { return pdim == 15 ? (r < 6 ? 9 * nf + 6 * a + r : 9 * a + (r - 6)) : 6 * a + r; }
@@ -149,13 +150,18 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     std::vector<int> cnt(npairs + 1, 0);
     std::vector<std::pair<int, int>> sl;  // (kf, slot) of one landmark, free keyframes only
     const bool idp = P->variant == VBA_VARIANT_PRV_IDP;
+    // per pair the items are ordered: first the pairs of two observation slots, then the pairs that involve the
+    // landmark's reference keyframe (these also carry a direct H_pp term; grouping them keeps waves uniform)
+    std::vector<int> cnt2(npairs + 1, 0);
     for (int pass = 0; pass < 2; pass++) {
-        std::vector<int> fill;
+        std::vector<int> fill, fill2;
         if (pass == 1) {
             st.item_begin.assign(npairs + 1, 0);
-            for (int i = 0; i < npairs; i++) st.item_begin[i + 1] = st.item_begin[i] + cnt[i];
+            for (int i = 0; i < npairs; i++) st.item_begin[i + 1] = st.item_begin[i] + cnt[i] + cnt2[i];
             st.items.resize(2 * (size_t)st.item_begin[npairs]);
             fill.assign(st.item_begin.begin(), st.item_begin.end() - 1);
+            fill2.resize(npairs);
+            for (int i = 0; i < npairs; i++) fill2[i] = st.item_begin[i] + cnt[i];
         }
         for (int p = 0; p < P->n_pt; p++) {
             sl.clear();
@@ -179,9 +185,10 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
             for (size_t i1 = 0; i1 < sl.size(); i1++)
                 for (size_t i2 = i1; i2 < sl.size(); i2++) {
                     const int pi = pidx(sl[i1].first, sl[i2].first);
-                    if (pass == 0) cnt[pi]++;
+                    const bool refpair = (i1 != i2) && (sl[i1].second < 0 || sl[i2].second < 0);
+                    if (pass == 0) { if (refpair) cnt2[pi]++; else cnt[pi]++; }
                     else {
-                        int* it = &st.items[2 * (size_t)fill[pi]++];
+                        int* it = &st.items[2 * (size_t)(refpair ? fill2[pi]++ : fill[pi]++)];
                         // slot ids: observation o -> o ; reference keyframe of landmark p -> n_obs + p
                         it[0] = sl[i1].second >= 0 ? sl[i1].second : P->n_obs + p;
                         it[1] = sl[i2].second >= 0 ? sl[i2].second : P->n_obs + p;
@@ -244,6 +251,21 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         st.pan_begin[k + 1] = (int)st.pan.size();
         st.step_npairs[k] = st.step_begin[k + 1] - st.step_begin[k];
     }
+    // which sub-blocks of a keyframe pair's block can land in a tile the factorisation reads (T now holds L's pattern)
+    st.pair_mask.assign(npairs, 0);
+    st.off_pair.clear();
+    for (int pi = 0; pi < npairs; pi++) {
+        const int a = st.pair_a[pi], b = st.pair_b[pi];
+        if (a != b) st.off_pair.push_back(pi);
+        int mask = 0;
+        for (int r = 0; r < pdim; r++)
+            for (int cc = 0; cc < pdim; cc++) {
+                const int ti = vpos_host(pdim, nf, a, r) / VBA_NB, tj = vpos_host(pdim, nf, b, cc) / VBA_NB;
+                if (T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)]) mask |= 1 << ((r >= 6 ? 2 : 0) + (cc >= 6 ? 1 : 0));
+            }
+        st.pair_mask[pi] = mask;
+    }
+    st.off_pair.resize(npairs, 0);  // padded to the pair stride
     return 0;
 }
 
@@ -275,13 +297,15 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->desc.assign(n, WinDesc());
     std::vector<double> pose, vel, bias, pt, uv, ow, meas, info;
     std::vector<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
-    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk;
+    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, offpair, pairmask;
     h->step_grid.clear();
     h->tile_updates = 0;
     size_t S_tot = 0;
     int kf0 = 0, pt0 = 0, obs0 = 0, imu0 = 0, pair0 = 0, item0 = 0, pimu0 = 0, vec0 = 0, part0 = 0;
     h->max_free = 0;
     h->max_lin_blk = 0;
+    h->max_quads = 1;
+    h->max_offp = 1;
     h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
     h->max_its[0] = h->max_its[1] = 0;
     for (int w = 0; w < n; w++) {
@@ -364,6 +388,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         }
         pair_a.insert(pair_a.end(), st.pair_a.begin(), st.pair_a.end());
         pair_b.insert(pair_b.end(), st.pair_b.begin(), st.pair_b.end());
+        offpair.insert(offpair.end(), st.off_pair.begin(), st.off_pair.end());
+        pairmask.insert(pairmask.end(), st.pair_mask.begin(), st.pair_mask.end());
         item_begin.insert(item_begin.end(), st.item_begin.begin(), st.item_begin.end());
         items.insert(items.end(), st.items.begin(), st.items.end());
         pimu_begin.insert(pimu_begin.end(), st.pimu_begin.begin(), st.pimu_begin.end());
@@ -379,6 +405,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         h->max_imu = std::max(h->max_imu, d.n_imu);
         h->max_pairs = std::max(h->max_pairs, d.n_pairs);
         h->max_free = std::max(h->max_free, d.n_free);
+        h->max_quads = std::max(h->max_quads, (d.n_pairs - d.n_free + 3) / 4);
+        h->max_offp = std::max(h->max_offp, d.n_pairs - d.n_free);
         h->max_nb = std::max(h->max_nb, d.nb);
         h->max_obs_blk = std::max(h->max_obs_blk, obs_blk);
         h->max_kf_blk = std::max(h->max_kf_blk, (d.n_kf + 63) / 64);
@@ -410,6 +438,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
     if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b) || h2d(h, BUF_ITEMBEG, item_begin) || h2d(h, BUF_ITEMS, items)) return -1;
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d(h, BUF_LINBLK, linblk)) return -1;
+    if (h2d(h, BUF_OFFPAIR, offpair) || h2d(h, BUF_PAIRMASK, pairmask)) return -1;
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
     // S: zero everything once, identity on the pads
     for (int w = 0; w < n; w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
@@ -452,6 +481,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
     B.lin_blk = dp<int>(h, BUF_LINBLK);
+    B.off_pair = dp<int>(h, BUF_OFFPAIR); B.pair_mask = dp<int>(h, BUF_PAIRMASK);
     B.part = dp<double>(h, BUF_PART);
     B.stop_word = h->stop_dev;
     B.out_outlier = dp<unsigned char>(h, BUF_OUTL); B.out_chi2 = dp<double>(h, BUF_OUTCHI);
@@ -471,11 +501,13 @@ void enqueue_solve_iteration(Handle* h) {
         const int ngrp = (n >= 8) ? 8 * ((n + 7) / 8) : n;
         if (idp) {
             hipLaunchKernelGGL(k_schur_diag, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free);
-            hipLaunchKernelGGL(k_schur_off, dim3(h->max_pairs * ngrp), dim3(64), 0, h->stream, B, h->max_pairs);
+            if (n >= 8) hipLaunchKernelGGL(k_schur_off, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
+            else hipLaunchKernelGGL(k_schur_off_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
         } else {
             hipLaunchKernelGGL(k_dinv, dim3(h->max_pt_blk, n), dim3(64), 0, h->stream, B);
             hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 0);
-            hipLaunchKernelGGL(k_schur_off3, dim3(h->max_pairs * ngrp), dim3(64), 0, h->stream, B, h->max_pairs);
+            if (n >= 8) hipLaunchKernelGGL(k_schur_off3, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
+            else hipLaunchKernelGGL(k_schur_off3_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
         }
     }
     {
@@ -773,7 +805,7 @@ int vba_debug_buf_id(const char* name) {
     static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
-        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK"};
+        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;

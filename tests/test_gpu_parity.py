@@ -123,6 +123,24 @@ def test_batch_of_ragged_windows_equals_single_solves(ba, oracle):
         _check(p, q, r, qo, ro)
 
 
+def test_lm_batch_of_ragged_windows_equals_single_solves(ba, oracle):
+    ps = [synth.make_window(abi.VARIANT_SE3_XYZ, n_kf=7 + 2 * i, n_fixed=2, n_pt=150 + 60 * i, n_obs=800 + 400 * i, seed=70 + i)
+          for i in range(3)]
+    ba.upload(ps); ba.run(); qs, rs = ba.download()
+    for p, q, r in zip(ps, qs, rs):
+        q1, r1 = ba.solve(p)
+        assert r.its_done == r1.its_done and (r.obs_outlier == r1.obs_outlier).all()
+        assert (q.kf_pose == q1.kf_pose).all() and (q.pt == q1.pt).all()
+        qo, ro = oracle.solve(p)
+        _check(p, q, r, qo, ro)
+    # nine windows: the >= 8 windows code path (XCD-aware mapping, four pairs per wave)
+    ps9 = [ps[i % 3] for i in range(9)]
+    ba.upload(ps9); ba.run(); q9, r9 = ba.download()
+    for i in range(9):
+        assert (q9[i].kf_pose == qs[i % 3].kf_pose).all() or np.abs(q9[i].kf_pose - qs[i % 3].kf_pose).max() < 1e-9
+        assert r9[i].its_done == rs[i % 3].its_done
+
+
 def test_rerun_is_bit_reproducible(ba):
     p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=10, n_fixed=1, n_pt=400, n_obs=2000, seed=7)
     ba.upload([p]); ba.run(); q1, r1 = ba.download()
