@@ -1162,6 +1162,162 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split form of one factorisation step for LARGE batches: the fused k_chol_step redoes the diagonal-tile
+// factorisation and both panel solves in every tile-pair workgroup, which is free when the launch is
+// latency-bound (few windows) but ~2x the arithmetic when the chip is full.  k_chol_panel solves every
+// panel tile once (two tiles per wave), k_chol_update only does the MFMA update.
+// ------------------------------------------------------------------------------------------------
+DEVI void ldl32_regs(double (&a)[32], int r, double& rdiag, bool& bad) {
+    bad = false;
+    rdiag = 1.0;
+#pragma unroll
+    for (int cc = 0; cc < 32; cc++) {
+        const double piv = rl64(a[cc], cc);
+        bad = bad || (piv == 0.0) || !isfinite(piv);
+        double y = __builtin_amdgcn_rcp(piv);
+        y = y * (2.0 - piv * y);
+        y = y * (2.0 - piv * y);
+        const double u = a[cc];
+        const double l = u * y;
+        rdiag = (r == cc) ? y : rdiag;
+        a[cc] = (r == cc) ? piv : l;
+#pragma unroll
+        for (int c2 = cc + 1; c2 < 32; c2++) a[c2] -= l * rl64(u, c2);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_chol_panel(Batch B, int k) {
+    __shared__ double Lk[32 * 33];
+    __shared__ double rd[32];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    WinCtrl& c = B.ctrl[w];
+    if (!win_on(d, c)) return;
+    if (k >= d.nb) return;
+    const int* pb = B.tl_pan_begin + d.tl_step0;
+    const int* pan = B.tl_pan + d.tl_pan0;
+    const int npan = pb[k + 1] - pb[k];
+    const int bx = blockIdx.x;
+    if (bx > 0 && 2 * bx >= npan) return;
+    const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
+    const int n = d.nS;
+    const double* S = B.S + d.S0;
+    double* Lf = B.Lf + d.S0;
+    double* vec = B.vec + d.vec0;
+    double* yv = B.yv + d.vec0;
+    const size_t dk = (size_t)k * 32;
+    const int pi = 2 * bx + hi;
+    const bool row_act = pi < npan;
+    const int I = row_act ? pan[pb[k] + pi] : 0;
+    double x[32];
+    {
+        const double* src = S + ((size_t)I * 32 + r) * n + dk;
+#pragma unroll
+        for (int q = 0; q < 32; q++) x[q] = row_act ? src[q] : 0.0;
+    }
+    double a[32];
+    const double* arow = S + (dk + r) * n + dk;
+#pragma unroll
+    for (int q = 0; q < 32; q++) a[q] = (q <= r) ? arow[q] : 0.0;
+    double rdiag;
+    bool bad;
+    ldl32_regs(a, r, rdiag, bad);
+    double zr = vec[dk + r];  // lane r (both halves) carries r_k[r]
+    if (hi == 0) {
+#pragma unroll
+        for (int q = 0; q < 32; q++) Lk[r * 33 + q] = (q <= r) ? a[q] : 0.0;
+        rd[r] = rdiag;
+        if (bx == 0) {
+            double* lrow = Lf + (dk + r) * n + dk;
+#pragma unroll
+            for (int q = 0; q < 32; q++)
+                if (q <= r) lrow[q] = a[q];
+        }
+    }
+    if (bx == 0 && lane == 0 && bad) c.chol_fail = 1;
+    __syncthreads();
+    // z_k = L_kk^-1 r_k (unit lower), column-oriented over the wave; afterwards lane q holds z_q
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const double zq = rl64(zr, q);
+        zr = (r > q) ? zr - Lk[r * 33 + q] * zq : zr;
+    }
+    if (bx == 0 && hi == 0) yv[dk + r] = zr;
+    // panel rows: X' L_kk^T = A (unit diagonal), L_Ik = X' D^-1
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const double xq = x[q];
+#pragma unroll
+        for (int c2 = q + 1; c2 < 32; c2++) x[c2] -= xq * Lk[c2 * 33 + q];
+    }
+    double sy = 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        x[q] *= rd[q];
+        sy += x[q] * rl64(zr, q);
+    }
+    if (row_act) {
+        double* dst = Lf + ((size_t)I * 32 + r) * n + dk;
+#pragma unroll
+        for (int q = 0; q < 32; q++) dst[q] = x[q];
+        vec[(size_t)I * 32 + r] -= sy;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_chol_update(Batch B, int k) {
+    __shared__ double XI[32 * 34];
+    __shared__ double XJ[32 * 34];
+    __shared__ double dg[32];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    if (!win_on(d, B.ctrl[w])) return;
+    if (k >= d.nb) return;
+    const int* sb = B.tl_step_begin + d.tl_step0;
+    const int npair = sb[k + 1] - sb[k];
+    const int bx = blockIdx.x;
+    if (bx >= npair) return;
+    const int v = B.tl_pairs[d.tl_pair0 + sb[k] + bx];
+    const int I = v >> 16, J = v & 0xffff;
+    const int lane = threadIdx.x, n = d.nS;
+    double* S = B.S + d.S0;
+    const double* Lf = B.Lf + d.S0;
+    const size_t dk = (size_t)k * 32;
+    if (lane < 32) dg[lane] = Lf[(dk + lane) * n + dk + lane];  // d_k
+    __syncthreads();
+    {   // L_Ik as stored; X'_J = L_Jk D.  16 consecutive doubles per lane.
+        const int row = lane >> 1, c0 = (lane & 1) * 16;
+        const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
+        const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            XI[row * 34 + c0 + q] = si[q];
+            XJ[row * 34 + c0 + q] = sj[q] * dg[c0 + q];
+        }
+    }
+    __syncthreads();
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const bool diagp = (I == J);
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            if (diagp && tj > ti) continue;
+            double* C = S + ((size_t)I * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
+            d4_t acc;
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = C[(size_t)(l4 + 4 * i) * n + l15];
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                const double av = -XI[(16 * ti + l15) * 34 + 4 * ks + l4];
+                const double bv = XJ[(16 * tj + l15) * 34 + 4 * ks + l4];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = acc[i];
+        }
+}
+
 // K_trsv: L^T x = y.  One 256-thread workgroup per window walks the block columns from the bottom: the
 // column's nonzero tiles are gathered by all four waves, the 32x32 triangular solve runs in wave 0 on
 // registers (column of L per lane, v_readlane broadcasts).

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -65,6 +66,7 @@ struct Handle {
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
     int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0, max_quads = 1, max_offp = 1;
     std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
+    std::vector<int> pan_grid, step_npair_max;  // panel tiles / tile pairs per step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
     int algo = 0, variant = 2;
     volatile int* stop_host = nullptr;  // pinned, device-visible
@@ -299,6 +301,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     std::vector<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
     std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, offpair, pairmask;
     h->step_grid.clear();
+    h->pan_grid.clear();
+    h->step_npair_max.clear();
     h->tile_updates = 0;
     size_t S_tot = 0;
     int kf0 = 0, pt0 = 0, obs0 = 0, imu0 = 0, pair0 = 0, item0 = 0, pimu0 = 0, vec0 = 0, part0 = 0;
@@ -364,8 +368,12 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         tlpanb.insert(tlpanb.end(), st.pan_begin.begin(), st.pan_begin.end());
         tlpair.insert(tlpair.end(), st.tpairs.begin(), st.tpairs.end());
         tlpan.insert(tlpan.end(), st.pan.begin(), st.pan.end());
-        if ((int)h->step_grid.size() < d.nb) h->step_grid.resize(d.nb, 1);
-        for (int k = 0; k < d.nb; k++) h->step_grid[k] = std::max(h->step_grid[k], std::max(1, st.step_npairs[k]));
+        if ((int)h->step_grid.size() < d.nb) { h->step_grid.resize(d.nb, 1); h->pan_grid.resize(d.nb, 0); h->step_npair_max.resize(d.nb, 0); }
+        for (int k = 0; k < d.nb; k++) {
+            h->step_grid[k] = std::max(h->step_grid[k], std::max(1, st.step_npairs[k]));
+            h->pan_grid[k] = std::max(h->pan_grid[k], st.pan_begin[k + 1] - st.pan_begin[k]);
+            h->step_npair_max[k] = std::max(h->step_npair_max[k], st.step_npairs[k]);
+        }
         h->tile_updates += (double)st.tpairs.size();
         pose.insert(pose.end(), P->kf_pose, P->kf_pose + 7 * (size_t)d.n_kf);
         if (P->kf_vel) vel.insert(vel.end(), P->kf_vel, P->kf_vel + 3 * (size_t)d.n_kf);
@@ -512,8 +520,17 @@ void enqueue_solve_iteration(Handle* h) {
     }
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
-        for (int k = 0; k < h->max_nb; k++)
-            hipLaunchKernelGGL(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
+        static const int split_min = getenv("VBA_SPLIT_MIN") ? atoi(getenv("VBA_SPLIT_MIN")) : 64;
+        if (n >= split_min) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
+            for (int k = 0; k < h->max_nb; k++) {
+                hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (h->pan_grid[k] + 1) / 2), n), dim3(64), 0, h->stream, B, k);
+                if (h->step_npair_max[k] > 0)
+                    hipLaunchKernelGGL(k_chol_update, dim3(h->step_npair_max[k], n), dim3(64), 0, h->stream, B, k);
+            }
+        } else {        // latency-bound: one fused launch per step
+            for (int k = 0; k < h->max_nb; k++)
+                hipLaunchKernelGGL(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
+        }
     }
     {
         ProfScope ps(h, VBA_PROF_TRSV);
