@@ -38,6 +38,9 @@ struct WinDesc {
     int tl_pair0;   // offset into the tile-pair list
     int tl_pan0;    // offset into the panel-tile list
     int lb0;        // offset into the k_lin2 landmark-run table
+    int win;        // index of this window in the uploaded batch: the CSR-style tables (pt_obs_begin, item_begin,
+                    // pimu_begin) carry one extra entry per window, so their rows start at offset + win
+    int pad1;
     long long S0;   // offset (doubles) into S
     double K[4];
     double Rcb[9], tcb[3], g[3];

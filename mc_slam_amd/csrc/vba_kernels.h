@@ -188,7 +188,7 @@ DEVI void lin_point_idp(const Batch& B, const WinDesc& d, const WinCtrl& c, int 
 #pragma unroll
     for (int i = 0; i < 21; i++) G0[i] = 0;
 
-    const int* ob = B.pt_obs_begin + d.pt0 + (&d - B.desc);  // CSR row of this window (n_pt + 1 entries)
+    const int* ob = B.pt_obs_begin + d.pt0 + d.win;  // CSR row of this window (n_pt + 1 entries)
     const int o0 = ob[p], o1 = ob[p + 1];
     for (int o = o0; o < o1; o++) {
         const size_t go = d.obs0 + o;
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
     if (lb >= d.n_part_lin) return;
     const int* tbl = B.lin_blk + d.lb0;
     const int p0 = tbl[lb], p1 = tbl[lb + 1];
-    const int* ob = B.pt_obs_begin + d.pt0 + w;
+    const int* ob = B.pt_obs_begin + d.pt0 + d.win;
     const int e0 = ob[p0], e1 = ob[p1];
     const int ne = e1 - e0, npb = p1 - p0;
     const double fx = d.K[0], fy = d.K[1], cx = d.K[2], cy = d.K[3];
@@ -770,7 +770,7 @@ DEVI void schur_write_block(const Batch& B, const WinDesc& d, const WinCtrl& c, 
     if (bstride < 0) bstride = P;
     const bool diag = (a == b);
     const double lambda = (d.algo == 1) ? c.lambda : 0.0;
-    const int qb = B.pimu_begin[d.pair0 + w + pr], qe = B.pimu_begin[d.pair0 + w + pr + 1];
+    const int qb = B.pimu_begin[d.pair0 + d.win + pr], qe = B.pimu_begin[d.pair0 + d.win + pr + 1];
     const int* va = B.var_act + d.vec0;
     double* S = B.S + d.S0;
     // sub-blocks that no tile of the factor ever reads (structurally zero in L under the V/Bias-first order) are
@@ -820,8 +820,8 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4) {
         pr = B.off_pair[d.pair0 + oi];
         a = B.pair_a[d.pair0 + pr];
         b = B.pair_b[d.pair0 + pr];
-        ib = B.item_begin[d.pair0 + w + pr];
-        ie = B.item_begin[d.pair0 + w + pr + 1];
+        ib = B.item_begin[d.pair0 + d.win + pr];
+        ie = B.item_begin[d.pair0 + d.win + pr + 1];
     }
     double acc[36];
 #pragma unroll
@@ -927,7 +927,7 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
     for (int i = 0; i < 36; i++) acc[i] = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) rhs[i] = bp[i] = hd[i] = 0;
-    const int ib = B.item_begin[d.pair0 + w + pr], ie = B.item_begin[d.pair0 + w + pr + 1];
+    const int ib = B.item_begin[d.pair0 + d.win + pr], ie = B.item_begin[d.pair0 + d.win + pr + 1];
     const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
     for (int it = ib + t; it < ie; it += 64) {
@@ -991,7 +991,7 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
     if (t < P) {
         double s = 0.0, sb = 0.0, h = 0.0;
         if (t < 6) { s = sh_r[t]; sb = sh_b[t]; h = sh_h[t]; }
-        const int qb = B.pimu_begin[d.pair0 + w + pr], qe = B.pimu_begin[d.pair0 + w + pr + 1];
+        const int qb = B.pimu_begin[d.pair0 + d.win + pr], qe = B.pimu_begin[d.pair0 + d.win + pr + 1];
         for (int m = qb; m < qe; m++) {
             const int k = B.pimu[2 * (size_t)(d.pimu0 + m)], role = B.pimu[2 * (size_t)(d.pimu0 + m) + 1];
             const double* H = B.imuH + VBA_IMUH * (size_t)(d.imu0 + k);
@@ -1399,7 +1399,7 @@ __global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
         if (rf < d.n_free)
 #pragma unroll
             for (int i = 0; i < 6; i++) cl -= sr[i] * x[vpos(d, rf, i)];
-        const int* ob = B.pt_obs_begin + d.pt0 + w;
+        const int* ob = B.pt_obs_begin + d.pt0 + d.win;
         for (int o = ob[p]; o < ob[p + 1]; o++) {
             const int kf = B.obs_kf[d.obs0 + o];
             if (kf >= d.n_free) continue;

@@ -21,7 +21,7 @@ DEVI void lin_point_xyz(const Batch& B, const WinDesc& d, const WinCtrl& c, int 
     const double fx = d.K[0], fy = d.K[1], cx = d.K[2], cy = d.K[3];
     double Hll[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
     int nact = 0;
-    const int* ob = B.pt_obs_begin + d.pt0 + w;
+    const int* ob = B.pt_obs_begin + d.pt0 + d.win;
     for (int o = ob[p]; o < ob[p + 1]; o++) {
         const size_t go = d.obs0 + o;
         const int kf = B.obs_kf[go];
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64) k_dinv(Batch B) {
     const double be0 = C00 * b0 + C10 * b1 + C20 * b2, be1 = C11 * b1 + C21 * b2, be2 = C22 * b2;
     pr[10] = C00; pr[11] = C10; pr[12] = C11; pr[13] = C20; pr[14] = C21; pr[15] = C22;
     pr[16] = be0; pr[17] = be1; pr[18] = be2;
-    const int* ob = B.pt_obs_begin + d.pt0 + w;
+    const int* ob = B.pt_obs_begin + d.pt0 + d.win;
     double* slots = B.slot + VBA_SLOT3 * (size_t)(d.obs0 + d.pt0);
     for (int o = ob[p]; o < ob[p + 1]; o++) {
         const double* rec = B.erec + VBA_EREC * (size_t)(d.obs0 + o);
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(64) k_update_xyz(Batch B, int nblk_pt) {
             const double* pr = B.prec + VBA_PREC * gp;
             if (pr[9] > 0.0) {
                 double v0 = pr[16], v1 = pr[17], v2 = pr[18];
-                const int* ob = B.pt_obs_begin + d.pt0 + w;
+                const int* ob = B.pt_obs_begin + d.pt0 + d.win;
                 const double* slots = B.slot + VBA_SLOT3 * (size_t)(d.obs0 + d.pt0);
                 for (int o = ob[p]; o < ob[p + 1]; o++) {
                     const int kf = B.obs_kf[d.obs0 + o];

@@ -56,6 +56,7 @@ struct ProfEvt {
 struct Handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    std::vector<hipStream_t> xstreams;  // extra streams: one per window group of a large batch
     std::string err;
     DevBuf buf[BUF_N];
     Batch B;
@@ -72,6 +73,7 @@ struct Handle {
     volatile int* stop_host = nullptr;  // pinned, device-visible
     int* stop_dev = nullptr;
     bool profile = false;
+    int opt_streams = 0;  // > 0: window groups / streams for GN batches (test hook; default from VBA_STREAMS, 1)
     std::vector<ProfEvt> evts;
     std::vector<hipEvent_t> evt_pool;
     size_t evt_used = 0;
@@ -325,6 +327,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         if (P->its_stage1 > 30 || P->its_stage2 > 30 || P->its_stage1 < 0 || P->its_stage2 < 0) return fail(h, "its out of range");
         WinDesc& d = h->desc[w];
         d.variant = P->variant; d.algo = P->algo;
+        d.win = w;
         d.n_kf = P->n_kf; d.n_free = P->n_kf_free; d.n_pt = P->n_pt; d.n_obs = P->n_obs;
         d.n_imu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
         d.pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
@@ -597,20 +600,10 @@ int enqueue_lm_stage(Handle* h, int stage, const volatile int* stop_flag) {
     return 0;
 }
 
-int do_run(Handle* h, const volatile int* stop_flag) {
-    if (!h->uploaded) return fail(h, "vba_batch_run before vba_batch_upload");
-    HIPCHK(h, hipSetDevice(h->device));
+// the whole two-stage schedule of the windows currently selected in h->B / h->n_win, on h->stream
+int enqueue_schedule(Handle* h, const volatile int* stop_flag) {
     const Batch& B = h->B;
     const int n = h->n_win;
-    *h->stop_host = (stop_flag && *stop_flag) ? 1 : 0;
-    h->evts.clear();
-    h->evt_used = 0;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    if (h->profile) {
-        ev_begin = get_evt(h);
-        ev_end = get_evt(h);
-        (void)hipEventRecord(ev_begin, h->stream);
-    }
     const int big_blk = std::max(std::max(h->max_kf_blk, h->max_pt_blk), h->max_obs_blk);
     {
         ProfScope ps(h, VBA_PROF_MISC);
@@ -654,18 +647,70 @@ int do_run(Handle* h, const volatile int* stop_flag) {
         hipLaunchKernelGGL(k_final_edges, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
         hipLaunchKernelGGL(k_final_sum, dim3(n), dim3(64), 0, h->stream, B);
     }
+    return 0;
+}
+
+int do_run(Handle* h, const volatile int* stop_flag) {
+    if (!h->uploaded) return fail(h, "vba_batch_run before vba_batch_upload");
+    HIPCHK(h, hipSetDevice(h->device));
+    const Batch B = h->B;
+    const int n = h->n_win;
+    *h->stop_host = (stop_flag && *stop_flag) ? 1 : 0;
+    h->evts.clear();
+    h->evt_used = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    if (h->profile) {
+        ev_begin = get_evt(h);
+        ev_end = get_evt(h);
+        (void)hipEventRecord(ev_begin, h->stream);
+    }
+    // Large Gauss-Newton batches are cut into groups of windows, each with its own stream: the groups are
+    // independent, so while one group sits in its latency-bound factorisation steps another streams through
+    // its bandwidth-bound linearise / Schur kernels, and a group's intermediates are still cache-resident when
+    // they are read back.  (Profiling runs and LM, which needs a host decision per trial, use one stream.)
+    // measured on MI355X (C3 windows): concurrent groups are SLOWER than one lock-step stream (256 windows: 55.7 ms
+    // with 8 groups vs 46.6 ms), so the default is one stream; VBA_STREAMS > 1 keeps the path testable
+    static const int env_streams = getenv("VBA_STREAMS") ? atoi(getenv("VBA_STREAMS")) : 1;
+    const int max_streams = h->opt_streams > 0 ? h->opt_streams : env_streams;
+    int ngroups = 1;
+    if (!h->profile && h->algo == VBA_ALGO_GN && max_streams > 1 && n >= 8)
+        ngroups = std::max(1, std::min(max_streams, (int)std::lround(std::sqrt(n / 4.0))));
+    while ((int)h->xstreams.size() < ngroups - 1) {
+        hipStream_t st;
+        HIPCHK(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        h->xstreams.push_back(st);
+    }
+    hipStream_t main_stream = h->stream;
+    std::vector<hipEvent_t> done(ngroups);
+    int rc = 0;
+    for (int g = 0; g < ngroups && rc == 0; g++) {
+        const int w0 = (int)((long long)n * g / ngroups), w1 = (int)((long long)n * (g + 1) / ngroups);
+        h->B = B;
+        h->B.desc = B.desc + w0;
+        h->B.ctrl = B.ctrl + w0;
+        h->B.n_win = w1 - w0;
+        h->n_win = w1 - w0;
+        h->stream = (g == 0) ? main_stream : h->xstreams[g - 1];
+        rc = enqueue_schedule(h, stop_flag);
+        done[g] = get_evt(h);
+        if (rc == 0 && hipEventRecord(done[g], h->stream) != hipSuccess) rc = -1;
+    }
+    h->B = B;
+    h->n_win = n;
+    h->stream = main_stream;
+    if (rc) return fail(h, h->err.empty() ? "enqueue failed" : h->err);
     if (h->profile) (void)hipEventRecord(ev_end, h->stream);
     HIPCHK(h, hipGetLastError());
     // wait, forwarding the caller's stop flag (g2o forceStopFlag) into the device-visible word
-    hipEvent_t done = get_evt(h);
-    HIPCHK(h, hipEventRecord(done, h->stream));
-    if (stop_flag) {
-        while (hipEventQuery(done) == hipErrorNotReady) {
-            if (*stop_flag) *h->stop_host = 1;
-            std::this_thread::yield();
+    for (int g = 0; g < ngroups; g++) {
+        if (stop_flag) {
+            while (hipEventQuery(done[g]) == hipErrorNotReady) {
+                if (*stop_flag) *h->stop_host = 1;
+                std::this_thread::yield();
+            }
         }
+        HIPCHK(h, hipEventSynchronize(done[g]));
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     h->hctrl.resize(n);
     HIPCHK(h, hipMemcpy(h->hctrl.data(), B.ctrl, sizeof(WinCtrl) * n, hipMemcpyDeviceToHost));
     if (h->profile) {
@@ -767,6 +812,7 @@ int vba_destroy(void* handle) {
     (void)hipStreamSynchronize(h->stream);
     for (auto& b : h->buf) b.release();
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
+    for (auto st : h->xstreams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (h->stop_host) (void)hipHostFree((void*)h->stop_host);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -817,6 +863,12 @@ int vba_debug_copy(void* handle, int32_t buf_id, uint64_t offset_bytes, void* ds
     if (!h || buf_id < 0 || buf_id >= BUF_N || offset_bytes + nbytes > h->buf[buf_id].cap) return -1;
     (void)hipSetDevice(h->device);
     return hipMemcpy(dst, reinterpret_cast<char*>(h->buf[buf_id].p) + offset_bytes, nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+int vba_debug_set_streams(void* handle, int32_t n) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    h->opt_streams = n;
+    return 0;
 }
 int vba_debug_buf_id(const char* name) {
     static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
