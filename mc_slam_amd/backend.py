@@ -10,7 +10,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvislam_ba.so")
+LIB_PATH = os.environ.get("VBA_LIB", os.path.join(_HERE, "csrc", "libvislam_ba.so"))   # VBA_LIB: A/B builds in experiments
 _lib = None
 
 EXPORTS = ["vba_create", "vba_destroy", "vba_last_error", "vba_solve", "vba_batch_upload", "vba_batch_run",

@@ -474,82 +474,6 @@ __global__ void __launch_bounds__(64) k_lin(Batch B, int nblk_pt, int mode) {
     }
 }
 
-// Jacobians of ONE EdgePRIDP edge recomputed from the raw observation (24 B) and the cached keyframe poses: what
-// the Schur gather needs for the direct H_pp terms (Bi^T Bi, Br^T Bi, g) without a 256-B per-edge record ever
-// travelling through HBM.  Same arithmetic as k_lin2.  Returns false for a level-1 edge (contributes nothing).
-DEVI bool idp_edge_recompute(const Batch& B, const WinDesc& d, const WinCtrl& c, int e, double* Bi, double* Br, double* g) {
-    const size_t go = d.obs0 + e;
-    if (B.lvl[go]) return false;
-    const size_t gp = d.pt0 + B.obs_pt[go];
-    double rho = B.pt[3 * gp];
-    if (rho < 1e-6) rho = 1e-6;
-    const double dd = 1.0 / rho;
-    const double P0[3] = {B.pt[3 * gp + 1] * dd, B.pt[3 * gp + 2] * dd, dd};
-    const int rf = B.pt_ref[gp], kf = B.obs_kf[go];
-    const double* C0 = B.kfR + 12 * (size_t)(d.kf0 + rf);
-    const double* Ci = B.kfR + 12 * (size_t)(d.kf0 + kf);
-    double c0[3], b0[3], tb[3], Xw[3];
-    mtv3(d.Rcb, P0, c0);
-    mtv3(d.Rcb, d.tcb, tb);
-    b0[0] = c0[0] - tb[0]; b0[1] = c0[1] - tb[1]; b0[2] = c0[2] - tb[2];
-    mv3(C0, b0, Xw);
-    const double v[3] = {Xw[0] + C0[9] - Ci[9], Xw[1] + C0[10] - Ci[10], Xw[2] + C0[11] - Ci[11]};
-    double ta[3], Pc[3];
-    mtv3(Ci, v, ta);
-    mv3(d.Rcb, ta, Pc);
-    Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
-    const double fx = d.K[0], fy = d.K[1];
-    const double iz = 1.0 / Pc[2];
-    const double ex = B.obs_uv[2 * go] - (Pc[0] * iz * fx + d.K[2]);
-    const double ey = B.obs_uv[2 * go + 1] - (Pc[1] * iz * fy + d.K[3]);
-    const double wgt = B.obs_w[go];
-    double rw = 1.0;
-    if (c.robust_vis) (void)huber(ex * (wgt * ex) + ey * (wgt * ey), d.hub_vis, &rw);
-    const double sc = sqrt(rw * wgt);
-    const double Jp[6] = {fx * iz, 0.0, -Pc[0] * iz * fx * iz, 0.0, fy * iz, -Pc[1] * iz * fy * iz};
-    double Jc[6], JA[6];
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            Jc[3 * rr + k] = Jp[3 * rr] * d.Rcb[k] + Jp[3 * rr + 1] * d.Rcb[3 + k] + Jp[3 * rr + 2] * d.Rcb[6 + k];
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            JA[3 * rr + k] = Jc[3 * rr] * Ci[3 * k] + Jc[3 * rr + 1] * Ci[3 * k + 1] + Jc[3 * rr + 2] * Ci[3 * k + 2];
-    const bool of = kf < d.n_free;
-    const double r0 = sc * ex, r1 = sc * ey;
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const double j0 = Jc[3 * rr], j1 = Jc[3 * rr + 1], j2 = Jc[3 * rr + 2];
-#pragma unroll
-        for (int k = 0; k < 3; k++) Bi[6 * rr + k] = of ? sc * JA[3 * rr + k] : 0.0;
-        Bi[6 * rr + 3] = of ? -sc * (j1 * ta[2] - j2 * ta[1]) : 0.0;
-        Bi[6 * rr + 4] = of ? -sc * (j2 * ta[0] - j0 * ta[2]) : 0.0;
-        Bi[6 * rr + 5] = of ? -sc * (j0 * ta[1] - j1 * ta[0]) : 0.0;
-    }
-    if (g) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) g[i] = -(Bi[i] * r0 + Bi[6 + i] * r1);
-    }
-    if (Br) {
-        const bool ref_free = rf < d.n_free;
-        double Hb[9], N0[9];
-        hat3(b0, Hb);
-        mm3(C0, Hb, N0);
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const double jan = JA[3 * rr] * N0[k] + JA[3 * rr + 1] * N0[3 + k] + JA[3 * rr + 2] * N0[6 + k];
-                Br[6 * rr + k] = ref_free ? -sc * JA[3 * rr + k] : 0.0;
-                Br[6 * rr + 3 + k] = ref_free ? sc * jan : 0.0;
-            }
-    }
-    return true;
-}
-
 // ------------------------------------------------------------------------------------------------
 // K_lin2 (inverse-depth variant): the same products as k_lin, but edge-parallel.  A 256-thread workgroup owns a
 // run of consecutive landmarks with <= 256 edges (ranges built at upload): one lane per EDGE evaluates the
@@ -750,8 +674,8 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
         sl[7] = sD;
     }
     __syncthreads();
-    // E. edge records out, as contiguous 16-B chunks (only when the Schur gather reads records instead of recomputing)
-    if (B.erec) {
+    // E. edge records out, as contiguous 16-B chunks
+    {
         double* dst = B.erec + VBA_EREC * (size_t)(d.obs0 + e0);
         const int nch = ne * (VBA_EREC / 2);
         for (int ch = t; ch < nch; ch += 256) {
@@ -921,21 +845,7 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4) {
         if (LD == 1) {
             // direct H_pp terms of the pairs that involve the landmark's reference keyframe (sorted to the end
             // of a pair's list)
-            if (!B.erec) {
-                if (sa >= d.n_obs || sb >= d.n_obs) {
-                    double Bi[12], Br[12];
-                    const bool refa = sa >= d.n_obs;
-                    if (idp_edge_recompute(B, d, c, refa ? sb : sa, Bi, Br, nullptr)) {
-#pragma unroll
-                        for (int h = 0; h < 2; h++)
-#pragma unroll
-                            for (int i = 0; i < 6; i++)
-#pragma unroll
-                                for (int j = 0; j < 6; j++)
-                                    acc[6 * i + j] += refa ? Br[6 * h + i] * Bi[6 * h + j] : Bi[6 * h + i] * Br[6 * h + j];
-                    }
-                }
-            } else if (sa >= d.n_obs) {         // a = reference KF, b = observer: Br^T Bi of edge sb
+            if (sa >= d.n_obs) {         // a = reference KF, b = observer: Br^T Bi of edge sb
                 const double* rb = B.erec + VBA_EREC * (size_t)(d.obs0 + sb);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
@@ -1042,17 +952,6 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
                 }
 #pragma unroll
             for (int i = 0; i < 6; i++) bp[i] += pr_[21 + i];
-        } else if (LD == 1 && !B.erec) {
-            double Bi[12], g[6];
-            if (idp_edge_recompute(B, d, c, sa, Bi, nullptr, g)) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-#pragma unroll
-                    for (int j = 0; j < 6; j++) acc[6 * i + j] += Bi[i] * Bi[j] + Bi[6 + i] * Bi[6 + j];
-                    hd[i] += Bi[i] * Bi[i] + Bi[6 + i] * Bi[6 + i];
-                    bp[i] += g[i];
-                }
-            }
         } else {
             const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
 #pragma unroll

@@ -438,8 +438,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (h2d(h, BUF_PTREF, ptref) || h2d(h, BUF_PTOBS, ptobs) || h2d(h, BUF_OBSKF, obskf) || h2d(h, BUF_OBSPT, obspt)) return -1;
     if (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow)) return -1;
     if (dalloc(h, BUF_LVL, (size_t)obs0) || dalloc(h, BUF_CHI2E, (size_t)obs0 * 8) || dalloc(h, BUF_DEPTH, (size_t)obs0 * 8)) return -1;
-    if (dalloc(h, BUF_EREC, (probs[0]->variant == VBA_VARIANT_PRV_IDP && getenv("VBA_KEEP_EREC") && !atoi(getenv("VBA_KEEP_EREC"))) ? 16 : (size_t)obs0 * VBA_EREC * 8) ||
-        dalloc(h, BUF_PREC, (size_t)pt0 * VBA_PREC * 8)) return -1;
+    if (dalloc(h, BUF_EREC, (size_t)obs0 * VBA_EREC * 8) || dalloc(h, BUF_PREC, (size_t)pt0 * VBA_PREC * 8)) return -1;
     if (dalloc(h, BUF_SLOT, ((size_t)obs0 + pt0) * (probs[0]->variant == VBA_VARIANT_PRV_IDP ? VBA_SLOT : VBA_SLOT3) * 8)) return -1;
     if (dalloc(h, BUF_CHI2F, (size_t)obs0 * 8)) return -1;
     if (h2d(h, BUF_IMUI, imui) || h2d(h, BUF_IMUJ, imuj) || h2d(h, BUF_IMUMEAS, meas) || h2d(h, BUF_IMUINFO, info)) return -1;
@@ -480,12 +479,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.obs_uv = dp<double>(h, BUF_OBSUV); B.obs_w = dp<double>(h, BUF_OBSW);
     B.lvl = dp<unsigned char>(h, BUF_LVL); B.chi2_e = dp<double>(h, BUF_CHI2E); B.depth_e = dp<double>(h, BUF_DEPTH);
     B.chi2_f = (probs[0]->variant == VBA_VARIANT_PRV_IDP) ? nullptr : dp<double>(h, BUF_CHI2F);
-    // VBA_KEEP_EREC=0: inverse-depth windows keep no per-edge record and the Schur gather recomputes the Jacobians it
-    // needs (idp_edge_recompute).  Measured slower on MI355X (512 windows: linearise -6.6 ms, Schur +10.6 ms), so the
-    // records stay by default.
-    static const int keep_erec = getenv("VBA_KEEP_EREC") ? atoi(getenv("VBA_KEEP_EREC")) : 1;
-    B.erec = (probs[0]->variant == VBA_VARIANT_PRV_IDP && !keep_erec) ? nullptr : dp<double>(h, BUF_EREC);
-    B.prec = dp<double>(h, BUF_PREC); B.slot = dp<double>(h, BUF_SLOT);
+    B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC); B.slot = dp<double>(h, BUF_SLOT);
     B.imu_i = dp<int>(h, BUF_IMUI); B.imu_j = dp<int>(h, BUF_IMUJ);
     B.imu_meas = dp<double>(h, BUF_IMUMEAS); B.imu_info = dp<double>(h, BUF_IMUINFO);
     B.imuH = dp<double>(h, BUF_IMUH); B.imu_chi = dp<double>(h, BUF_IMUCHI);
