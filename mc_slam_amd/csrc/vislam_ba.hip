@@ -45,7 +45,7 @@ enum {
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
-    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_N
+    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N
 };
 
 struct ProfEvt {
@@ -293,7 +293,12 @@ void quat_to_R_host(const double* q, double* R) {
     R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
 
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int do_upload(Handle* h, int n, vba_problem* const* probs) {
+    static const bool timing = getenv("VBA_TIMING") != nullptr;
+    const double t_begin = now_ms();
+    double t_struct = 0;
     if (n <= 0) return fail(h, "empty batch");
     HIPCHK(h, hipSetDevice(h->device));
     h->uploaded = false;
@@ -365,7 +370,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         d.hub_vis = P->huber_vis; d.hub_prv = P->huber_prv; d.hub_bias = P->huber_bias;
         d.chi2_th = P->chi2_th; d.depth_min = P->depth_min; d.rho_min = P->rho_min;
         Structure st;
+        const double ts0 = now_ms();
         if (build_structure(h, P, st)) return -1;
+        t_struct += now_ms() - ts0;
         d.tl_step0 = (int)tlstep.size(); d.tl_pair0 = (int)tlpair.size(); d.tl_pan0 = (int)tlpan.size();
         tlstep.insert(tlstep.end(), st.step_begin.begin(), st.step_begin.end());
         tlpanb.insert(tlpanb.end(), st.pan_begin.begin(), st.pan_begin.end());
@@ -496,7 +503,12 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.part = dp<double>(h, BUF_PART);
     B.stop_word = h->stop_dev;
     B.out_outlier = dp<unsigned char>(h, BUF_OUTL); B.out_chi2 = dp<double>(h, BUF_OUTCHI);
+    if (dalloc(h, BUF_DBG, 4096)) return -1;
+    B.dbg = dp<double>(h, BUF_DBG);
+    const double t_enq = now_ms();
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (timing) fprintf(stderr, "[vba] upload %d windows: total %.3f ms (structure %.3f, pack+enqueue %.3f, sync %.3f)\n", n,
+                        now_ms() - t_begin, t_struct, t_enq - t_begin - t_struct, now_ms() - t_enq);
     h->uploaded = true;
     h->ran = false;
     return 0;
@@ -874,7 +886,7 @@ int vba_debug_buf_id(const char* name) {
     static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
-        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK"};
+        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
