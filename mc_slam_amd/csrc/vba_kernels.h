@@ -1029,9 +1029,10 @@ __global__ void __launch_bounds__(64) k_schur_diag3(Batch B, int max_free, int h
 // Restates LinearSolverEigen::solve (linear_solver_eigen.h:94-124) on the dense reduced system.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
-    __shared__ double XI[32 * 34];
+    __shared__ double XI[32 * 34];   // first holds L_kk (stride 33) for the panel solves, then X_I (stride 34)
     __shared__ double XJ[32 * 34];
     __shared__ double rd[32];
+    double* Lk = XI;
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
@@ -1071,13 +1072,9 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
 #pragma unroll
     for (int q = 0; q < 32; q++) a[q] = (q <= r) ? arow[q] : 0.0;
     // L D L^T of the diagonal tile (unit lower L, D on the diagonal), as Eigen's SimplicialLDLT does: negative
-    // pivots are fine, only an exactly zero / non-finite pivot fails (linear_solver_eigen.h:105-111).
-    // The panel rows (and the rhs row) are eliminated IN THE SAME LOOP: they are further rows of the stacked matrix
-    // [A_kk; A_Ik; A_Jk; r_k^T], so column cc of a panel row is divided by the pivot and the row takes the same
-    // rank-1 update with the broadcast u_c2 -- no separate triangular solve, no LDS traffic.  After the loop
-    // x[] holds the row of L_Ik = A_Ik L_kk^-T D^-1 (for the rhs row: z_k / d).
+    // pivots are fine, only an exactly zero / non-finite pivot fails (linear_solver_eigen.h:105-111)
     bool bad = false;
-    double dme = 1.0;  // d_r of this lane's row
+    double rdiag = 1.0;  // 1 / d_r of this lane's row
 #pragma unroll
     for (int cc = 0; cc < 32; cc++) {
         const double piv = rl64(a[cc], cc);
@@ -1087,19 +1084,15 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
         y = y * (2.0 - piv * y);
         const double u = a[cc];                 // a_{r,cc} before the division = l_{r,cc} d_cc
         const double l = u * y;
-        const double lx = x[cc] * y;
-        dme = (r == cc) ? piv : dme;
+        rdiag = (r == cc) ? y : rdiag;
         a[cc] = (r == cc) ? piv : l;
-        x[cc] = lx;
 #pragma unroll
-        for (int c2 = cc + 1; c2 < 32; c2++) {
-            const double uc = rl64(u, c2);
-            a[c2] -= l * uc;
-            x[c2] -= lx * uc;
-        }
+        for (int c2 = cc + 1; c2 < 32; c2++) a[c2] -= l * rl64(u, c2);
     }
     if (hi == 0) {
-        rd[r] = dme;  // d_k
+#pragma unroll
+        for (int q = 0; q < 32; q++) Lk[r * 33 + q] = (q <= r) ? a[q] : 0.0;
+        rd[r] = rdiag;
         if (bx == 0) {
             double* lrow = Lf + (dk + r) * n + dk;
 #pragma unroll
@@ -1109,31 +1102,43 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
     }
     if (bx == 0 && lane == 0 && bad) c.chol_fail = 1;
     __syncthreads();
+    // X' L_kk^T = A with unit-diagonal L (row per lane, column-oriented so the 31-q updates of a step are
+    // independent); the panel factor is L_Ik = X' D^-1, the forward-substituted rhs z_k = L_kk^-1 r_k
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const double xq = x[q];
+#pragma unroll
+        for (int c2 = q + 1; c2 < 32; c2++) x[c2] -= xq * Lk[c2 * 33 + q];
+    }
     if (bx == 0 && lane == 32) {
 #pragma unroll
-        for (int q = 0; q < 32; q++) yv[dk + q] = x[q] * rd[q];  // z_k = L_kk^-1 r_k
+        for (int q = 0; q < 32; q++) yv[dk + q] = x[q];  // z_k
     }
     if (!has_pair) return;
-    double sy = 0.0;  // L_Ik row . z_k ; z_k / d sits in lane 32 of a diagonal pair (wave-uniform control flow here)
+    double xs[32];   // row of L_Ik = X' D^-1
 #pragma unroll
-    for (int q = 0; q < 32; q++) sy += x[q] * (rl64(x[q], 32) * rd[q]);
+    for (int q = 0; q < 32; q++) xs[q] = x[q] * rd[q];
+    double sy = 0.0;  // L_Ik row . z_k ; z_k sits in lane 32 of a diagonal pair (wave-uniform control flow here)
+#pragma unroll
+    for (int q = 0; q < 32; q++) sy += xs[q] * rl64(x[q], 32);
     if (diagp && hi == 0) {
         double* dst = Lf + ((size_t)I * 32 + r) * n + dk;
 #pragma unroll
-        for (int q = 0; q < 32; q++) dst[q] = x[q];  // L_Ik
+        for (int q = 0; q < 32; q++) dst[q] = xs[q];  // L_Ik
         vec[(size_t)I * 32 + r] -= sy;
     }
-    // C_IJ -= L_Ik D L_Jk^T : XI holds the rows of L_Ik, XJ the rows of L_Jk D
+    __syncthreads();  // every lane is done reading L_kk before X_I overwrites it
+    // C_IJ -= L_Ik D L_Jk^T = (X'_I D^-1) X'_J^T : XI holds the scaled rows of tile I, XJ the unscaled rows of tile J
     if (hi == 0) {
 #pragma unroll
-        for (int q = 0; q < 32; q++) XI[r * 34 + q] = x[q];
+        for (int q = 0; q < 32; q++) XI[r * 34 + q] = xs[q];
         if (diagp) {
 #pragma unroll
-            for (int q = 0; q < 32; q++) XJ[r * 34 + q] = x[q] * rd[q];
+            for (int q = 0; q < 32; q++) XJ[r * 34 + q] = x[q];
         }
     } else if (!diagp) {
 #pragma unroll
-        for (int q = 0; q < 32; q++) XJ[r * 34 + q] = x[q] * rd[q];
+        for (int q = 0; q < 32; q++) XJ[r * 34 + q] = x[q];
     }
     __syncthreads();
     const double* XJp = XJ;
