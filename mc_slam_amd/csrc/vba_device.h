@@ -14,7 +14,7 @@
 #define VBA_IMUH 960       // doubles per IMU edge pair: 30x30 local Hessian + 30 rhs (+ pad)
 #define VBA_TRACE 64
 
-// Linearisation products kept in HBM between k_lin and its consumers (variant 2, EdgePRIDP).  A "slot" is one
+// Linearisation products kept in HBM between k_lin2 and its consumers (variant 2, EdgePRIDP).  A "slot" is one
 // (landmark, keyframe) incidence = one H_pl block: observation e -> slot e, reference keyframe of landmark p
 // -> slot n_obs + p.  Jacobians are pre-scaled by sqrt(rho' * invSigma2) and never stored unreduced.
 //   slot record  [0..5] U = W * sqrt(Dinv)  (W = H_pl block, 6x1)   [6] beta = sqrt(Dinv) * b_l   [7] sqrt(Dinv) (ref slot)
@@ -57,7 +57,7 @@ struct WinCtrl {
     int its_done[2];
     int robust_vis;   // Huber on vision edges (stage 1)
     int chol_fail;    // set by the factorisation of the current iteration
-    int step_ok;      // 1: K_update must apply the step of this iteration
+    int step_ok;      // (unused, kept for layout stability of the debug tools)
     int aborted;      // stop flag seen
     int n_trace;
     int n_outliers;

@@ -153,154 +153,10 @@ __global__ void __launch_bounds__(64) k_stage_mark(Batch B) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K_lin: residuals + analytic Jacobians + Huber + per-landmark products, one thread per landmark
-//        (blocks [0, nblk_pt)), and one workgroup per IMU edge pair (blocks [nblk_pt, nblk_pt + n_imu)).
-// Replaces computeActiveErrors (sparse_optimizer.cpp:61-88) + the vision/IMU part of buildSystem
+// Linearisation: residuals + analytic Jacobians + Huber + per-landmark products.  Replaces
+// computeActiveErrors (sparse_optimizer.cpp:61-88) + the vision/IMU part of buildSystem
 // (block_solver.hpp:502-560); Jacobians never reach HBM unreduced: only their products do.
 // ------------------------------------------------------------------------------------------------
-DEVI void lin_point_idp(const Batch& B, const WinDesc& d, const WinCtrl& c, int p, int mode, double& chi) {
-    const size_t gp = d.pt0 + p;
-    double rho = B.pt[3 * gp];
-    const double xb = B.pt[3 * gp + 1], yb = B.pt[3 * gp + 2];
-    if (rho < 1e-6) rho = 1e-6;  // g2otypes.cpp:42-47
-    const double dd = 1.0 / rho;
-    const double P0[3] = {xb * dd, yb * dd, dd};
-    const int rf = B.pt_ref[gp];
-    const double* C0 = B.kfR + 12 * (size_t)(d.kf0 + rf);
-    double R0[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) R0[i] = C0[i];
-    const double t0[3] = {C0[9], C0[10], C0[11]};
-    // c0 = Rcb^T P0 ; b0 = Rcb^T (P0 - tcb) (landmark in the reference body frame); Xw = R0 b0 + t0
-    double c0[3], b0[3], y[3], Xw[3], tb[3];
-    mtv3(d.Rcb, P0, c0);
-    mtv3(d.Rcb, d.tcb, tb);
-    b0[0] = c0[0] - tb[0]; b0[1] = c0[1] - tb[1]; b0[2] = c0[2] - tb[2];
-    mv3(R0, b0, Xw);
-    Xw[0] += t0[0]; Xw[1] += t0[1]; Xw[2] += t0[2];
-    mv3(R0, c0, y);  // Rcic0 P0 = (Rcb Ri^T) y
-    double Hb[9], N0[9];
-    hat3(b0, Hb);
-    mm3(R0, Hb, N0);  // Rcic0 hat(P0 - tcb) Rcb = (Rcb Ri^T) R0 hat(b0)
-    const bool ref_free = rf < d.n_free;
-    const double fx = d.K[0], fy = d.K[1], cx = d.K[2], cy = d.K[3];
-
-    double D = 0, bl = 0, W0[6] = {0, 0, 0, 0, 0, 0}, g0[6] = {0, 0, 0, 0, 0, 0}, G0[21];
-#pragma unroll
-    for (int i = 0; i < 21; i++) G0[i] = 0;
-
-    const int* ob = B.pt_obs_begin + d.pt0 + d.win;  // CSR row of this window (n_pt + 1 entries)
-    const int o0 = ob[p], o1 = ob[p + 1];
-    for (int o = o0; o < o1; o++) {
-        const size_t go = d.obs0 + o;
-        const int kf = B.obs_kf[go];
-        const double* Ci = B.kfR + 12 * (size_t)(d.kf0 + kf);
-        double Ri[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) Ri[i] = Ci[i];
-        const double v[3] = {Xw[0] - Ci[9], Xw[1] - Ci[10], Xw[2] - Ci[11]};
-        double ta[3], Pc[3];
-        mtv3(Ri, v, ta);  // landmark in the observing body frame
-        mv3(d.Rcb, ta, Pc);
-        Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
-        B.depth_e[go] = Pc[2];
-        double* rec = B.erec + VBA_EREC * go;
-        if (B.lvl[go]) {
-            if (mode == LIN_FULL)
-                for (int i = 0; i < 30; i++) rec[i] = 0.0;
-            continue;
-        }
-        const double iz = 1.0 / Pc[2];
-        const double ex = B.obs_uv[2 * go] - (Pc[0] * iz * fx + cx);
-        const double ey = B.obs_uv[2 * go + 1] - (Pc[1] * iz * fy + cy);
-        const double wgt = B.obs_w[go];
-        const double s = ex * (wgt * ex) + ey * (wgt * ey);
-        B.chi2_e[go] = s;
-        double rw = 1.0;
-        if (c.robust_vis) chi += huber(s, d.hub_vis, &rw);
-        else chi += s;
-        if (mode != LIN_FULL) continue;
-        const double sc = sqrt(rw * wgt);
-        // Jpi = [fx/z 0 -x/z*fx/z ; 0 fy/z -y/z*fy/z]   (g2otypes.cpp:112-121)
-        const double Jp[6] = {fx * iz, 0.0, -Pc[0] * iz * fx * iz, 0.0, fy * iz, -Pc[1] * iz * fy * iz};
-        double Jc[6], JA[6];
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int k = 0; k < 3; k++)
-                Jc[3 * r + k] = Jp[3 * r] * d.Rcb[k] + Jp[3 * r + 1] * d.Rcb[3 + k] + Jp[3 * r + 2] * d.Rcb[6 + k];
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int k = 0; k < 3; k++)  // JA = Jc Ri^T
-                JA[3 * r + k] = Jc[3 * r] * Ri[3 * k] + Jc[3 * r + 1] * Ri[3 * k + 1] + Jc[3 * r + 2] * Ri[3 * k + 2];
-        double a[2], Br[12], Bi[12];
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            a[r] = sc * dd * (JA[3 * r] * y[0] + JA[3 * r + 1] * y[1] + JA[3 * r + 2] * y[2]);
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const double jan = JA[3 * r] * N0[k] + JA[3 * r + 1] * N0[3 + k] + JA[3 * r + 2] * N0[6 + k];
-                Br[6 * r + k] = ref_free ? -sc * JA[3 * r + k] : 0.0;
-                Br[6 * r + 3 + k] = ref_free ? sc * jan : 0.0;
-            }
-            // -Jc hat(ta): row r of Jc crossed with ta
-            const double j0 = Jc[3 * r], j1 = Jc[3 * r + 1], j2 = Jc[3 * r + 2];
-            const double h0 = j1 * ta[2] - j2 * ta[1], h1 = j2 * ta[0] - j0 * ta[2], h2 = j0 * ta[1] - j1 * ta[0];
-            const bool of = kf < d.n_free;
-            Bi[6 * r] = of ? sc * JA[3 * r] : 0.0;
-            Bi[6 * r + 1] = of ? sc * JA[3 * r + 1] : 0.0;
-            Bi[6 * r + 2] = of ? sc * JA[3 * r + 2] : 0.0;
-            // (Jc hat(ta))_k = sum_m Jc_m hat(ta)_{mk} = (Jc x ... ) ; -Jc hat(ta) = -(j x ta)^T ... see note
-            Bi[6 * r + 3] = of ? -sc * h0 : 0.0;
-            Bi[6 * r + 4] = of ? -sc * h1 : 0.0;
-            Bi[6 * r + 5] = of ? -sc * h2 : 0.0;
-        }
-        const double r0 = sc * ex, r1 = sc * ey;
-        D += a[0] * a[0] + a[1] * a[1];
-        bl -= a[0] * r0 + a[1] * r1;
-        int gi = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            W0[i] += Br[i] * a[0] + Br[6 + i] * a[1];
-            g0[i] -= Br[i] * r0 + Br[6 + i] * r1;
-#pragma unroll
-            for (int j = i; j < 6; j++) G0[gi++] += Br[i] * Br[j] + Br[6 + i] * Br[6 + j];
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) { rec[i] = Bi[i]; rec[12 + i] = Br[i]; }
-        double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + o);
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            sl[i] = Bi[i] * a[0] + Bi[6 + i] * a[1];          // W (scaled to U below, once D is known)
-            rec[24 + i] = -(Bi[i] * r0 + Bi[6 + i] * r1);
-        }
-    }
-    if (mode == LIN_FULL) {
-        const double sD = (D > 0.0) ? sqrt(1.0 / D) : 0.0;
-        const double beta = sD * bl;
-        for (int o = o0; o < o1; o++) {
-            double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + o);
-            const bool on = !B.lvl[d.obs0 + o];
-#pragma unroll
-            for (int i = 0; i < 6; i++) sl[i] = on ? sl[i] * sD : 0.0;
-            sl[6] = beta;
-            sl[7] = sD;
-        }
-        double* sr = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + d.n_obs + p);
-#pragma unroll
-        for (int i = 0; i < 6; i++) sr[i] = W0[i] * sD;
-        sr[6] = beta;
-        sr[7] = sD;
-        double* pr = B.prec + VBA_PREC * gp;
-#pragma unroll
-        for (int i = 0; i < 21; i++) pr[i] = G0[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) pr[21 + i] = g0[i];
-        pr[27] = D;
-    }
-}
-
 // EdgeNavStatePRV + EdgeNavStateBias of one keyframe pair (the fused 15-D IMU factor): error, chi2, and in
 // LIN_FULL mode the 30x30 local Hessian J^T (rho' Omega) J and rhs in local order
 // [PR_i V_i B_i | PR_j V_j B_j].  One 64-thread workgroup; lane 0 evaluates the Lie-group part.
@@ -455,28 +311,8 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
     }
 }
 
-__global__ void __launch_bounds__(64) k_lin(Batch B, int nblk_pt, int mode) {
-    __shared__ double sm[640];
-    const int w = blockIdx.y;
-    const WinDesc& d = B.desc[w];
-    const WinCtrl& c = B.ctrl[w];
-    if (!c.active) return;
-    if ((int)blockIdx.x < nblk_pt) {
-        const int p = blockIdx.x * 64 + threadIdx.x;
-        if ((int)blockIdx.x * 64 >= d.n_pt) return;
-        double chi = 0.0;
-        if (p < d.n_pt) lin_point_idp(B, d, c, p, mode, chi);
-        const double tot = block_sum<64>(chi, sm);
-        if (threadIdx.x == 0) B.part[d.part0 + blockIdx.x] = tot;
-    } else {
-        const int k = blockIdx.x - nblk_pt;
-        if (k >= d.n_imu) return;
-        lin_imu(B, d, k, mode, sm);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// K_lin2 (inverse-depth variant): the same products as k_lin, but edge-parallel.  A 256-thread workgroup owns a
+// K_lin2 (inverse-depth variant), edge-parallel.  A 256-thread workgroup owns a
 // run of consecutive landmarks with <= 256 edges (ranges built at upload): one lane per EDGE evaluates the
 // residual and Jacobians (coalesced observation loads), the per-landmark sums (D, b_l, W0, g0, G0) are taken by
 // one lane per LANDMARK from LDS, and the 256-B edge records leave through an LDS transpose as contiguous
