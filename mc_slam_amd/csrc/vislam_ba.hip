@@ -229,11 +229,15 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         const bool vis = st.item_begin[pi + 1] > st.item_begin[pi];
         const bool imu = st.pimu_begin[pi + 1] > st.pimu_begin[pi];
         if (!vis && !imu && a != b) continue;
-        const int dim = (imu || a == b) ? pdim : 6;
-        for (int r = 0; r < dim; r++)
-            for (int cc = 0; cc < dim; cc++) {
-                const int ti = vpos_host(pdim, nf, a, r) / VBA_NB, tj = vpos_host(pdim, nf, b, cc) / VBA_NB;
-                T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)] = 1;
+        // a keyframe's PR dofs (0..5) and V/Bias dofs (6..14) are two contiguous runs: each touches at most two tiles
+        const int nsub = ((imu || a == b) && pdim == 15) ? 2 : 1;
+        for (int sr = 0; sr < nsub; sr++)
+            for (int sc = 0; sc < nsub; sc++) {
+                const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
+                const int ti0 = vpos_host(pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(pdim, nf, a, r1) / VBA_NB;
+                const int tj0 = vpos_host(pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(pdim, nf, b, c1) / VBA_NB;
+                for (int ti = ti0; ti <= ti1; ti++)
+                    for (int tj = tj0; tj <= tj1; tj++) T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)] = 1;
             }
     }
     st.step_begin.assign(nb + 1, 0);
@@ -262,10 +266,16 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         const int a = st.pair_a[pi], b = st.pair_b[pi];
         if (a != b) st.off_pair.push_back(pi);
         int mask = 0;
-        for (int r = 0; r < pdim; r++)
-            for (int cc = 0; cc < pdim; cc++) {
-                const int ti = vpos_host(pdim, nf, a, r) / VBA_NB, tj = vpos_host(pdim, nf, b, cc) / VBA_NB;
-                if (T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)]) mask |= 1 << ((r >= 6 ? 2 : 0) + (cc >= 6 ? 1 : 0));
+        const int nsub = (pdim == 15) ? 2 : 1;
+        for (int sr = 0; sr < nsub; sr++)
+            for (int sc = 0; sc < nsub; sc++) {
+                const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
+                const int ti0 = vpos_host(pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(pdim, nf, a, r1) / VBA_NB;
+                const int tj0 = vpos_host(pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(pdim, nf, b, c1) / VBA_NB;
+                bool any = false;
+                for (int ti = ti0; ti <= ti1; ti++)
+                    for (int tj = tj0; tj <= tj1; tj++) any = any || T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)];
+                if (any) mask |= 1 << ((sr ? 2 : 0) + (sc ? 1 : 0));
             }
         st.pair_mask[pi] = mask;
     }
