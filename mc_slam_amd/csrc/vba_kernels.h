@@ -42,6 +42,7 @@ struct Batch {
     const int *tl_step_begin, *tl_pairs, *tl_pan_begin, *tl_pan;
     double* part;
     const volatile int* stop_word;
+    int* alive_cnt;  // pinned host words: [stage * 32 + it] += windows still iterating after control call `it`
     unsigned char* out_outlier;
     double* out_chi2;
     double* dbg;  // 4 KiB scratch for diagnostic builds (in-kernel stamps); never read by the product path
@@ -570,6 +571,7 @@ __global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval) {
     c.chol_fail = 0;
     c.step_ok = active;
     c.it = it + 1;
+    if (active && B.alive_cnt && it < 32) atomicAdd_system(B.alive_cnt + st * 32 + it, 1);  // lets the host skip dead iterations
 }
 
 // ------------------------------------------------------------------------------------------------

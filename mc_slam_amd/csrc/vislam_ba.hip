@@ -512,6 +512,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.off_pair = dp<int>(h, BUF_OFFPAIR); B.pair_mask = dp<int>(h, BUF_PAIRMASK);
     B.part = dp<double>(h, BUF_PART);
     B.stop_word = h->stop_dev;
+    B.alive_cnt = h->stop_dev + 64;
     B.out_outlier = dp<unsigned char>(h, BUF_OUTL); B.out_chi2 = dp<double>(h, BUF_OUTCHI);
     if (dalloc(h, BUF_DBG, 4096)) return -1;
     B.dbg = dp<double>(h, BUF_DBG);
@@ -641,11 +642,26 @@ int enqueue_schedule(Handle* h, const volatile int* stop_flag) {
         if (h->algo == VBA_ALGO_LM) {
             if (enqueue_lm_stage(h, stage, stop_flag)) return -1;
         } else {
+            // The host stays at most two iterations ahead of the device: before enqueuing iteration it it waits for
+            // the control kernel of iteration it-2 and stops enqueuing once no window is iterating any more (the
+            // |dchi2| < 1e-3 stop usually ends stage 2 after 3 of its 10 iterations).  The device never starves:
+            // one full iteration is always queued behind the one being waited for.
+            volatile int* alive = h->stop_host + 64 + stage * 32;
+            std::vector<hipEvent_t> ev(h->max_its[stage], nullptr);
+            const bool pace = !h->profile && h->max_its[stage] <= 32;
             for (int it = 0; it < h->max_its[stage]; it++) {
+                if (pace && it >= 2) {
+                    (void)hipEventSynchronize(ev[it - 2]);
+                    if (alive[it - 2] == 0) break;
+                }
                 enqueue_lin(h, LIN_FULL);
                 {
                     ProfScope ps(h, VBA_PROF_CONTROL);
                     hipLaunchKernelGGL(k_ctrl_gn, dim3(n), dim3(64), 0, h->stream, B, 0);
+                }
+                if (pace) {
+                    ev[it] = get_evt(h);
+                    (void)hipEventRecord(ev[it], h->stream);
                 }
                 enqueue_solve_iteration(h);
             }
@@ -678,6 +694,7 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     const Batch B = h->B;
     const int n = h->n_win;
     *h->stop_host = (stop_flag && *stop_flag) ? 1 : 0;
+    for (int i = 64; i < 128; i++) h->stop_host[i] = 0;
     h->evts.clear();
     h->evt_used = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -814,7 +831,8 @@ int vba_create(int device, void** handle) {
         return -3;
     }
     void* hp = nullptr;
-    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) { delete h; return -4; }
+    if (hipHostMalloc(&hp, 4096, hipHostMallocMapped) != hipSuccess) { delete h; return -4; }
+    memset(hp, 0, 4096);
     h->stop_host = reinterpret_cast<volatile int*>(hp);
     *h->stop_host = 0;
     void* dpw = nullptr;
