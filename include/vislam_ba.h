@@ -127,6 +127,16 @@ int vba_batch_upload(void *handle, int32_t n_windows, vba_problem *const *proble
 int vba_batch_run(void *handle, const volatile int *stop_flag);
 int vba_batch_download(void *handle, int32_t n_windows, vba_problem *const *inout, vba_result *const *out);
 
+/* On-device IMU preintegration: IMUPreintegrator::update (src/IMU/IMUPreintegrator.cpp:63-112) applied
+ * over the samples of n_edges keyframe intervals, the way KeyFrame::ComputePreInt feeds it (src/KeyFrame.cpp:195-252:
+ * the caller lists the samples and their dt, including the duplicated first sample).  gyr/acc are bias-corrected
+ * (measurement - bias of the previous keyframe).  Outputs, per interval: imu_meas[VBA_IMU_MEAS_STRIDE] and the 9x9
+ * covariance in P,V,phi order as the reference keeps it; imu_info_prv (may be NULL) = inverse of the V/phi-swapped
+ * covariance, i.e. exactly what vba_problem.imu_info_prv expects (src/Optimizer.cpp:273-280). */
+int vba_preintegrate(void *handle, int32_t n_edges, const int32_t *sample_begin, const double *gyr, const double *acc,
+                     const double *dt, double gyr_meas_cov, double acc_meas_cov, double *imu_meas, double *cov_pvphi,
+                     double *imu_info_prv);
+
 int vba_set_profile(void *handle, int32_t enable);
 int vba_get_profile(void *handle, vba_profile *out);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VBA_LIB", os.path.join(_HERE, "csrc", "libvislam_ba.s
 _lib = None
 
 EXPORTS = ["vba_create", "vba_destroy", "vba_last_error", "vba_solve", "vba_batch_upload", "vba_batch_run",
-           "vba_batch_download", "vba_set_profile", "vba_get_profile"]
+           "vba_batch_download", "vba_preintegrate", "vba_set_profile", "vba_get_profile"]
 
 
 def load_library():
@@ -35,6 +35,8 @@ def load_library():
     lib.vba_batch_upload.argtypes = [C.c_void_p, C.c_int32, PP]
     lib.vba_batch_run.argtypes = [C.c_void_p, C.c_void_p]
     lib.vba_batch_download.argtypes = [C.c_void_p, C.c_int32, PP, PR]
+    _pd, _pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    lib.vba_preintegrate.argtypes = [C.c_void_p, C.c_int32, _pi, _pd, _pd, _pd, C.c_double, C.c_double, _pd, _pd, _pd]
     lib.vba_set_profile.argtypes = [C.c_void_p, C.c_int32]
     lib.vba_get_profile.argtypes = [C.c_void_p, C.POINTER(abi.vba_profile)]
     for n in EXPORTS:
@@ -105,6 +107,23 @@ class LocalBA:
         if self.lib.vba_batch_download(self.h, n, self._parr, rarr) != 0:
             raise self._err("vba_batch_download")
         return self._probs, [r.get() for r in rbs]
+
+    def preintegrate(self, sample_begin, gyr, acc, dt, want_info=True):
+        """vba_preintegrate: (imu_meas [E,61], cov_PVphi [E,9,9], info_PphiV [E,9,9] or None)"""
+        import numpy as np
+        sb = np.ascontiguousarray(sample_begin, dtype=np.int32)
+        g = np.ascontiguousarray(gyr, dtype=np.float64).reshape(-1, 3)
+        a = np.ascontiguousarray(acc, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(dt, dtype=np.float64)
+        E = len(sb) - 1
+        meas = np.zeros((E, abi.IMU_MEAS_STRIDE)); cov = np.zeros((E, 81)); info = np.zeros((E, 81))
+        P = lambda x, t: x.ctypes.data_as(C.POINTER(t))
+        rc = self.lib.vba_preintegrate(self.h, E, P(sb, C.c_int32), P(g, C.c_double), P(a, C.c_double), P(d, C.c_double),
+                                       abi.GYR_MEAS_COV, abi.ACC_MEAS_COV, P(meas, C.c_double), P(cov, C.c_double),
+                                       P(info, C.c_double) if want_info else None)
+        if rc != 0:
+            raise self._err("vba_preintegrate")
+        return meas, cov.reshape(E, 9, 9), (info.reshape(E, 9, 9) if want_info else None)
 
     def set_profile(self, on=True):
         self.lib.vba_set_profile(self.h, 1 if on else 0)

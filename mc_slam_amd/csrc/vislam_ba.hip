@@ -7,6 +7,7 @@
 // point fails with an error.
 #include "../../include/vislam_ba.h"
 #include "vba_kernels_lm.h"
+#include "vba_preint.h"
 
 #include <algorithm>
 #include <chrono>
@@ -59,6 +60,7 @@ struct Handle {
     std::vector<hipStream_t> xstreams;  // extra streams: one per window group of a large batch
     std::string err;
     DevBuf buf[BUF_N];
+    DevBuf preint;  // arena of vba_preintegrate
     Batch B;
     std::vector<WinDesc> desc;
     std::vector<WinCtrl> hctrl;
@@ -851,6 +853,7 @@ int vba_destroy(void* handle) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto& b : h->buf) b.release();
+    h->preint.release();
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
     for (auto st : h->xstreams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (h->stop_host) (void)hipHostFree((void*)h->stop_host);
@@ -919,6 +922,45 @@ int vba_debug_buf_id(const char* name) {
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
     return -1;
+}
+
+int vba_preintegrate(void* handle, int32_t n_edges, const int32_t* sample_begin, const double* gyr, const double* acc,
+                     const double* dt, double gyr_meas_cov, double acc_meas_cov, double* imu_meas, double* cov_pvphi,
+                     double* imu_info_prv) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    if (n_edges <= 0 || !sample_begin || !gyr || !acc || !dt || !imu_meas || !cov_pvphi) return fail(h, "vba_preintegrate: bad arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int ns = sample_begin[n_edges];
+    for (int e = 0; e < n_edges; e++)
+        if (sample_begin[e] > sample_begin[e + 1] || sample_begin[e] < 0) return fail(h, "vba_preintegrate: sample_begin is not a CSR");
+    // a small private arena: inputs | outputs
+    const size_t b_sb = ((size_t)(n_edges + 1) * 4 + 255) / 256 * 256, b_v = ((size_t)ns * 24 + 255) / 256 * 256, b_d = ((size_t)ns * 8 + 255) / 256 * 256;
+    const size_t b_m = (size_t)n_edges * 61 * 8, b_c = (size_t)n_edges * 81 * 8;
+    const size_t total = b_sb + 2 * b_v + b_d + b_m + 2 * b_c + 1024;
+    HIPCHK(h, h->preint.ensure(total));
+    char* base = reinterpret_cast<char*>(h->preint.p);
+    int* d_sb = reinterpret_cast<int*>(base);
+    double* d_g = reinterpret_cast<double*>(base + b_sb);
+    double* d_a = reinterpret_cast<double*>(base + b_sb + b_v);
+    double* d_dt = reinterpret_cast<double*>(base + b_sb + 2 * b_v);
+    double* d_m = reinterpret_cast<double*>(base + b_sb + 2 * b_v + b_d);
+    double* d_c = d_m + (size_t)n_edges * 61;
+    double* d_i = d_c + (size_t)n_edges * 81;
+    HIPCHK(h, hipMemcpyAsync(d_sb, sample_begin, (size_t)(n_edges + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    if (ns > 0) {
+        HIPCHK(h, hipMemcpyAsync(d_g, gyr, (size_t)ns * 24, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_a, acc, (size_t)ns * 24, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(d_dt, dt, (size_t)ns * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(k_preint, dim3(n_edges), dim3(128), 0, h->stream, n_edges, d_sb, d_g, d_a, d_dt, gyr_meas_cov, acc_meas_cov,
+                       d_m, d_c, imu_info_prv ? d_i : nullptr);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(imu_meas, d_m, b_m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(cov_pvphi, d_c, b_c, hipMemcpyDeviceToHost, h->stream));
+    if (imu_info_prv) HIPCHK(h, hipMemcpyAsync(imu_info_prv, d_i, b_c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 int vba_set_profile(void* handle, int32_t enable) {

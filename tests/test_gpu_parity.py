@@ -222,3 +222,26 @@ def test_c4_noise_free_terminates_at_truth(ba):
     q, r = ba.solve(p)
     assert r.its_done == (1, 1) and r.n_outliers == 0 and r.status == 0
     assert np.abs(q.kf_pose - p.truth["pose"]).max() < 1e-6
+
+
+def test_on_device_preintegration_matches_oracle_and_numpy(ba, oracle):
+    """A15: IMUPreintegrator::update on the GPU vs the C oracle (sample by sample) and the numpy twin."""
+    rng = np.random.default_rng(9)
+    lens = [50, 51, 1, 37, 0, 200]
+    sb = np.concatenate([[0], np.cumsum(lens)])
+    n = int(sb[-1])
+    gyr = rng.normal(0, 0.3, (n, 3)); acc = rng.normal(0, 1.0, (n, 3)) + [0, 0, 9.8]
+    dt = np.full(n, 0.005); dt[0] = 0.0   # KeyFrame::ComputePreInt's leading (sample, t_imu0 - t_prevKF) call
+    meas, cov, info = ba.preintegrate(sb, gyr, acc, dt)
+    for e, L in enumerate(lens):
+        s0, s1 = sb[e], sb[e + 1]
+        m_c, c_c = oracle.preint(gyr[s0:s1], acc[s0:s1], dt[s0:s1])
+        np.testing.assert_allclose(meas[e], m_c, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(cov[e], c_c, rtol=1e-10, atol=1e-24)
+        if L > 1:
+            np.testing.assert_allclose(info[e], oracle.prv_information(c_c), rtol=1e-6)
+    m_np, c_np = synth.preintegrate(gyr[None, :50], acc[None, :50], dt[None, :50])
+    np.testing.assert_allclose(meas[0], m_np[0], rtol=1e-11, atol=1e-13)
+    # the information it returns is what vba_problem.imu_info_prv expects
+    p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31)
+    assert info.shape[1:] == (9, 9) and p.imu_info_prv.shape[1] == 81
