@@ -7,7 +7,9 @@
 #include <stdint.h>
 
 #define VBA_NB 32          // block size of the dense reduced-system factorisation
-#define VBA_EREC 32        // doubles per edge record   (256 B)
+#define VBA_EREC 32        // doubles per edge record, XYZ variants (256 B)
+#define VBA_EREC1 16       // doubles per edge record, inverse-depth variant (128 B = one cache line): Bi(12), r(2)
+#define VBA_N0REC 16       // doubles per landmark: N0 = R0 hat(b0) (9), so that Br = [-A | A N0] is rebuilt by the reader
 #define VBA_PREC 32        // doubles per point record  (256 B)
 #define VBA_SLOT 8         // doubles per slot record   (64 B = one line), inverse-depth landmarks
 #define VBA_SLOT3 24       // doubles per slot record, XYZ landmarks: U (6x3), beta (3), pad
@@ -251,4 +253,16 @@ DEVI double block_sum(double v, double* sm) {
     const double r = sm[0];
     __syncthreads();
     return r;
+}
+
+// the same for a 256-thread workgroup with 4 doubles of LDS: fixed butterfly inside each wave, then the four
+// wave sums in order
+DEVI double block_sum256(double v, double* sm4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int t = threadIdx.x;
+    __syncthreads();
+    if ((t & 63) == 0) sm4[t >> 6] = v;
+    __syncthreads();
+    return ((sm4[0] + sm4[1]) + sm4[2]) + sm4[3];
 }

@@ -24,7 +24,7 @@ struct Batch {
     const double *obs_uv, *obs_w;
     unsigned char* lvl;
     double *chi2_e, *depth_e, *chi2_f;  // chi2_f: chi2 recomputed at the final estimates (LM: chi2_e may be stale)
-    double *erec, *prec, *slot;
+    double *erec, *prec, *slot, *n0rec;
     // IMU factors
     const int *imu_i, *imu_j;
     const double *imu_meas, *imu_info;
@@ -42,7 +42,7 @@ struct Batch {
     const int *tl_step_begin, *tl_pairs, *tl_pan_begin, *tl_pan;
     double* part;
     const volatile int* stop_word;
-    int* alive_cnt;  // pinned host words: [stage * 32 + it] += windows still iterating after control call `it`
+    int* alive_cnt;  // pinned host words: [stage * 32 + it] = 1 if a window is still iterating after control call `it`
     unsigned char* out_outlier;
     double* out_chi2;
     double* dbg;  // 4 KiB scratch for diagnostic builds (in-kernel stamps); never read by the product path
@@ -319,14 +319,15 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
 // one lane per LANDMARK from LDS, and the 256-B edge records leave through an LDS transpose as contiguous
 // 16-B chunks instead of 64 scattered records per store instruction.
 // ------------------------------------------------------------------------------------------------
-#define LIN2_ES 31   // LDS row stride (doubles) of one edge: [0..11] Bi [12..23] Br [24..25] a [26..27] r -> later [24..29] g
+#define LIN2_ES 15   // LDS row stride (doubles) of one edge: phase B/C [0..5] A [6..7] a [8..9] r ; phase D/E [0..11] Bi [12..13] r
 #define LIN2_PS 19   // LDS row stride of one landmark: dd, y(3), Xw(3), N0(9), ref_free, sD, beta
+#define LIN2_LDS ((256 * LIN2_ES + 64 * LIN2_PS + 4) * 8)   // 40 480 B: four workgroups per CU
 
 __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
     extern __shared__ double lsm[];
     double* ER = lsm;                       // 256 x LIN2_ES
     double* PT = lsm + 256 * LIN2_ES;       // 64 x LIN2_PS
-    double* red = PT + 64 * LIN2_PS;        // 256
+    double* red = PT + 64 * LIN2_PS;        // 4
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
@@ -377,7 +378,8 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
         q[16] = (rf < d.n_free) ? 1.0 : 0.0;
     }
     __syncthreads();
-    // B. one lane per edge
+    // B. one lane per edge.  With A = sqrt(rho' w) J_pi R_cb R_i^T (2x3) the two pose Jacobians of the edge are
+    //    Bi = [A | -sqrt(.) (J_pi R_cb) x ta] (observer) and Br = A [-I | N0] (reference keyframe, N0 per landmark).
     double chi = 0.0;
     double Bi[12], a[2] = {0, 0}, r2[2] = {0, 0};
 #pragma unroll
@@ -399,9 +401,7 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
         mv3(d.Rcb, ta, Pc);
         Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
         B.depth_e[go] = Pc[2];
-        double Br[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) Br[i] = 0.0;
+        double A[6] = {0, 0, 0, 0, 0, 0};
         if (!B.lvl[go]) {
             const double iz = 1.0 / Pc[2];
             const double ex = B.obs_uv[2 * go] - (Pc[0] * iz * fx + cx);
@@ -416,28 +416,21 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
                 on = true;
                 const double sc = sqrt(rw * wgt);
                 const double Jp[6] = {fx * iz, 0.0, -Pc[0] * iz * fx * iz, 0.0, fy * iz, -Pc[1] * iz * fy * iz};
-                double Jc[6], JA[6];
+                double Jc[6];
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++)
 #pragma unroll
                     for (int k = 0; k < 3; k++)
                         Jc[3 * rr + k] = Jp[3 * rr] * d.Rcb[k] + Jp[3 * rr + 1] * d.Rcb[3 + k] + Jp[3 * rr + 2] * d.Rcb[6 + k];
-#pragma unroll
-                for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-                        JA[3 * rr + k] = Jc[3 * rr] * Ri[3 * k] + Jc[3 * rr + 1] * Ri[3 * k + 1] + Jc[3 * rr + 2] * Ri[3 * k + 2];
-                const bool ref_free = q[16] != 0.0, of = kf < d.n_free;
+                const bool of = kf < d.n_free;
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
-                    a[rr] = sc * q[0] * (JA[3 * rr] * q[1] + JA[3 * rr + 1] * q[2] + JA[3 * rr + 2] * q[3]);
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
-                        const double jan = JA[3 * rr] * q[7 + k] + JA[3 * rr + 1] * q[10 + k] + JA[3 * rr + 2] * q[13 + k];
-                        Br[6 * rr + k] = ref_free ? -sc * JA[3 * rr + k] : 0.0;
-                        Br[6 * rr + 3 + k] = ref_free ? sc * jan : 0.0;
-                        Bi[6 * rr + k] = of ? sc * JA[3 * rr + k] : 0.0;
+                        A[3 * rr + k] = sc * (Jc[3 * rr] * Ri[3 * k] + Jc[3 * rr + 1] * Ri[3 * k + 1] + Jc[3 * rr + 2] * Ri[3 * k + 2]);
+                        Bi[6 * rr + k] = of ? A[3 * rr + k] : 0.0;
                     }
+                    a[rr] = q[0] * (A[3 * rr] * q[1] + A[3 * rr + 1] * q[2] + A[3 * rr + 2] * q[3]);
                     const double j0 = Jc[3 * rr], j1 = Jc[3 * rr + 1], j2 = Jc[3 * rr + 2];
                     Bi[6 * rr + 3] = of ? -sc * (j1 * ta[2] - j2 * ta[1]) : 0.0;
                     Bi[6 * rr + 4] = of ? -sc * (j2 * ta[0] - j0 * ta[2]) : 0.0;
@@ -449,42 +442,68 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
         if (mode == LIN_FULL) {
             double* er = ER + t * LIN2_ES;
 #pragma unroll
-            for (int i = 0; i < 12; i++) { er[i] = Bi[i]; er[12 + i] = Br[i]; }
-            er[24] = a[0]; er[25] = a[1]; er[26] = r2[0]; er[27] = r2[1];
+            for (int i = 0; i < 6; i++) er[i] = A[i];
+            er[6] = a[0]; er[7] = a[1]; er[8] = r2[0]; er[9] = r2[1];
         }
     }
     if (mode != LIN_FULL) {
-        const double tot = block_sum<256>(chi, red);
+        const double tot = block_sum256(chi, red);
         if (t == 0) B.part[d.part0 + lb] = tot;
         return;
     }
     __syncthreads();
-    // C. one lane per landmark: sums over its edges (fixed order)
+    // C. one lane per landmark: sums over its edges (fixed order): D, b_l and, for the reference keyframe,
+    //    sum Br^T Br = Q^T (sum A^T A) Q, sum Br^T a = Q^T sum A^T a, sum Br^T r = Q^T sum A^T r with Q = [-I | N0]
     if (t < npb) {
         const int p = p0 + t;
         const size_t gp = d.pt0 + p;
-        double D = 0, bl = 0, W0[6] = {0, 0, 0, 0, 0, 0}, g0[6] = {0, 0, 0, 0, 0, 0}, G0[21];
-#pragma unroll
-        for (int i = 0; i < 21; i++) G0[i] = 0;
+        double D = 0, bl = 0, M[6] = {0, 0, 0, 0, 0, 0}, wa[3] = {0, 0, 0}, wr[3] = {0, 0, 0};
         for (int o = ob[p] - e0; o < ob[p + 1] - e0; o++) {
             const double* er = ER + o * LIN2_ES;
-            const double a0 = er[24], a1 = er[25], q0 = er[26], q1 = er[27];
+            const double a0 = er[6], a1 = er[7], q0 = er[8], q1 = er[9];
             D += a0 * a0 + a1 * a1;
             bl -= a0 * q0 + a1 * q1;
             int gi = 0;
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                const double b0 = er[12 + i], b1 = er[18 + i];
-                W0[i] += b0 * a0 + b1 * a1;
-                g0[i] -= b0 * q0 + b1 * q1;
+            for (int i = 0; i < 3; i++) {
+                const double b0 = er[i], b1 = er[3 + i];
+                wa[i] += b0 * a0 + b1 * a1;
+                wr[i] += b0 * q0 + b1 * q1;
 #pragma unroll
-                for (int j = i; j < 6; j++) G0[gi++] += b0 * er[12 + j] + b1 * er[18 + j];
+                for (int j = i; j < 3; j++) M[gi++] += b0 * er[j] + b1 * er[3 + j];
             }
         }
         const double sD = (D > 0.0) ? sqrt(1.0 / D) : 0.0;
         const double beta = sD * bl;
-        PT[t * LIN2_PS + 17] = sD;
-        PT[t * LIN2_PS + 18] = beta;
+        double* q = PT + t * LIN2_PS;
+        q[17] = sD;
+        q[18] = beta;
+        const double rfm = q[16];  // 1: reference keyframe is free, 0: fixed (no Hessian block)
+        double N0[9], Ms[9], MN[9], W0[6], g0[6], G0[21];
+#pragma unroll
+        for (int i = 0; i < 9; i++) N0[i] = q[7 + i];
+        Ms[0] = M[0]; Ms[1] = M[1]; Ms[2] = M[2]; Ms[3] = M[1]; Ms[4] = M[3]; Ms[5] = M[4]; Ms[6] = M[2]; Ms[7] = M[4]; Ms[8] = M[5];
+        mm3(Ms, N0, MN);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            W0[k] = -wa[k] * rfm;
+            g0[k] = wr[k] * rfm;
+            W0[3 + k] = (N0[k] * wa[0] + N0[3 + k] * wa[1] + N0[6 + k] * wa[2]) * rfm;
+            g0[3 + k] = -(N0[k] * wr[0] + N0[3 + k] * wr[1] + N0[6 + k] * wr[2]) * rfm;
+        }
+        {
+            int gi = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = i; j < 6; j++) {
+                    double v;
+                    if (i < 3 && j < 3) v = Ms[3 * i + j];
+                    else if (i < 3) v = -MN[3 * i + (j - 3)];
+                    else v = N0[i - 3] * MN[j - 3] + N0[3 + i - 3] * MN[3 + j - 3] + N0[6 + i - 3] * MN[6 + j - 3];
+                    G0[gi++] = v * rfm;
+                }
+        }
         double* sr = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + d.n_obs + p);
 #pragma unroll
         for (int i = 0; i < 6; i++) sr[i] = W0[i] * sD;
@@ -496,35 +515,39 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
 #pragma unroll
         for (int i = 0; i < 6; i++) pr[21 + i] = g0[i];
         pr[27] = D;
+        double* nr = B.n0rec + VBA_N0REC * gp;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nr[i] = N0[i];
     }
     __syncthreads();
-    // D. one lane per edge: slot record, g into the LDS row
+    // D. one lane per edge: slot record; Bi and r into the LDS row for the transposed store
     if (t < ne) {
         const double sD = PT[pl * LIN2_PS + 17], beta = PT[pl * LIN2_PS + 18];
         double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + e0 + t);
         double* er = ER + t * LIN2_ES;
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            sl[i] = on ? (Bi[i] * a[0] + Bi[6 + i] * a[1]) * sD : 0.0;
-            er[24 + i] = -(Bi[i] * r2[0] + Bi[6 + i] * r2[1]);
-        }
+        for (int i = 0; i < 6; i++) sl[i] = on ? (Bi[i] * a[0] + Bi[6 + i] * a[1]) * sD : 0.0;
         sl[6] = beta;
         sl[7] = sD;
+#pragma unroll
+        for (int i = 0; i < 12; i++) er[i] = Bi[i];
+        er[12] = r2[0]; er[13] = r2[1];
     }
     __syncthreads();
-    // E. edge records out, as contiguous 16-B chunks
+    // E. edge records out (Bi and the weighted residual r; the reader rebuilds g = -Bi^T r and Br = [-A | A N0]),
+    //    as contiguous 16-B chunks
     {
-        double* dst = B.erec + VBA_EREC * (size_t)(d.obs0 + e0);
-        const int nch = ne * (VBA_EREC / 2);
+        double* dst = B.erec + VBA_EREC1 * (size_t)(d.obs0 + e0);
+        const int nch = ne * (VBA_EREC1 / 2);
         for (int ch = t; ch < nch; ch += 256) {
-            const int row = ch / (VBA_EREC / 2), col = (ch % (VBA_EREC / 2)) * 2;
+            const int row = ch / (VBA_EREC1 / 2), col = (ch % (VBA_EREC1 / 2)) * 2;
             double2 v;
-            v.x = (col < 30) ? ER[row * LIN2_ES + col] : 0.0;
-            v.y = (col + 1 < 30) ? ER[row * LIN2_ES + col + 1] : 0.0;
-            *reinterpret_cast<double2*>(dst + (size_t)row * VBA_EREC + col) = v;
+            v.x = (col < 14) ? ER[row * LIN2_ES + col] : 0.0;
+            v.y = (col < 14) ? ER[row * LIN2_ES + col + 1] : 0.0;
+            *reinterpret_cast<double2*>(dst + (size_t)row * VBA_EREC1 + col) = v;
         }
     }
-    const double tot = block_sum<256>(chi, red);
+    const double tot = block_sum256(chi, red);
     if (t == 0) B.part[d.part0 + lb] = tot;
 }
 
@@ -571,7 +594,8 @@ __global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval) {
     c.chol_fail = 0;
     c.step_ok = active;
     c.it = it + 1;
-    if (active && B.alive_cnt && it < 32) atomicAdd_system(B.alive_cnt + st * 32 + it, 1);  // lets the host skip dead iterations
+    if (active && B.alive_cnt && it < 32)  // lets the host skip dead iterations; a posted store, not a PCIe atomic
+        __hip_atomic_store(B.alive_cnt + st * 32 + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -615,6 +639,16 @@ DEVI void schur_write_block(const Batch& B, const WinDesc& d, const WinCtrl& c, 
     // sub-blocks that no tile of the factor ever reads (structurally zero in L under the V/Bias-first order) are
     // not written at all: bit0 PRxPR, bit1 PRxVB, bit2 VBxPR, bit3 VBxVB (mask built with the tile lists at upload)
     const int mask = B.pair_mask[d.pair0 + pr];
+    if (mask == 1 && !diag && qb == qe) {  // only the 6x6 PR x PR sub-block lands in a tile the factor reads, no IMU term
+        for (int q = t; q < 36; q += nt) {
+            const int r = q / 6, col = q % 6;
+            const int gr = vpos(d, a, r), gc = vpos(d, b, col);
+            const double s = blk[r * bstride + col];
+            if (gr >= gc) S[(size_t)gr * n + gc] = s;
+            else S[(size_t)gc * n + gr] = s;
+        }
+        return;
+    }
     for (int q = t; q < P * P; q += nt) {
         const int r = q / P, col = q % P;
         if (!((mask >> ((r >= 6 ? 2 : 0) + (col >= 6 ? 1 : 0))) & 1)) continue;
@@ -667,8 +701,11 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4) {
     for (int i = 0; i < 36; i++) acc[i] = 0;
     const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
+    int2 nxt = make_int2(0, 0);
+    if (ib + l16 < ie) nxt = items[ib + l16];
     for (int it = ib + l16; it < ie; it += LP) {
-        const int2 itm = items[it];
+        const int2 itm = nxt;  // indices were fetched one trip ahead: one dependent round trip per item, not two
+        if (it + LP < ie) nxt = items[it + LP];
         const int sa = itm.x, sb = itm.y;
         const double* qa = slots + SS * (size_t)sa;
         const double* qb = slots + SS * (size_t)sb;
@@ -684,32 +721,30 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4) {
         if (LD == 1) {
             // direct H_pp terms of the pairs that involve the landmark's reference keyframe (sorted to the end
             // of a pair's list)
-            if (sa >= d.n_obs) {         // a = reference KF, b = observer: Br^T Bi of edge sb
-                const double* rb = B.erec + VBA_EREC * (size_t)(d.obs0 + sb);
+            if (sa >= d.n_obs || sb >= d.n_obs) {
+                // one of the two is the landmark's reference keyframe: the edge of the other one adds Br^T Bi (a = ref)
+                // or Bi^T Br (b = ref), with Br = [-A | A N0] rebuilt from the record's A = Bi[:, 0:3]
+                const bool a_ref = sa >= d.n_obs;
+                const double* re = B.erec + VBA_EREC1 * (size_t)(d.obs0 + (a_ref ? sb : sa));
+                const double* n0 = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + (a_ref ? sa : sb) - d.n_obs);
+                double N0[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) N0[i] = n0[i];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    double bi[6];
+                    double bi[6], br[6];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) bi[j] = rb[6 * h + j];
+                    for (int j = 0; j < 6; j++) bi[j] = re[6 * h + j];
 #pragma unroll
-                    for (int i = 0; i < 6; i++) {
-                        const double br = rb[12 + 6 * h + i];
-#pragma unroll
-                        for (int j = 0; j < 6; j++) acc[6 * i + j] += br * bi[j];
+                    for (int k = 0; k < 3; k++) {
+                        br[k] = -bi[k];
+                        br[3 + k] = bi[0] * N0[k] + bi[1] * N0[3 + k] + bi[2] * N0[6 + k];
                     }
-                }
-            } else if (sb >= d.n_obs) {  // a = observer, b = reference KF: Bi^T Br of edge sa
-                const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    double br[6];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) br[j] = ra[12 + 6 * h + j];
 #pragma unroll
                     for (int i = 0; i < 6; i++) {
-                        const double bi = ra[6 * h + i];
+                        const double x = a_ref ? br[i] : bi[i];
 #pragma unroll
-                        for (int j = 0; j < 6; j++) acc[6 * i + j] += bi * br[j];
+                        for (int j = 0; j < 6; j++) acc[6 * i + j] += x * (a_ref ? bi[j] : br[j]);
                     }
                 }
             }
@@ -761,16 +796,19 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
     if (a >= d.n_free) return;
     const int t = threadIdx.x;
     const int pr = a * d.n_free - a * (a - 1) / 2;  // index of pair (a,a)
-    double acc[36], rhs[6], bp[6], hd[6];
+    double acc[21], rhs[6], bp[6], hd[6];  // the block is symmetric: upper triangle only, row-major (i <= j)
 #pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] = 0;
+    for (int i = 0; i < 21; i++) acc[i] = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) rhs[i] = bp[i] = hd[i] = 0;
     const int ib = B.item_begin[d.pair0 + d.win + pr], ie = B.item_begin[d.pair0 + d.win + pr + 1];
     const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
+    int nxt = 0;
+    if (ib + t < ie) nxt = items[ib + t].x;
     for (int it = ib + t; it < ie; it += 64) {
-        const int sa = items[it].x;
+        const int sa = nxt;
+        if (it + 64 < ie) nxt = items[it + 64].x;
         const double* qa = slots + SS * (size_t)sa;
         double UA[6 * LD], beta[LD];
 #pragma unroll
@@ -779,49 +817,52 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
         for (int l = 0; l < LD; l++) beta[l] = qa[6 * LD + l];
         if (LD == 1 && sa >= d.n_obs) {
             const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + sa - d.n_obs);
-            int gi = 0;
 #pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = i; j < 6; j++) {
-                    const double g = pr_[gi++];
-                    acc[6 * i + j] += g;
-                    if (j != i) acc[6 * j + i] += g;
-                    if (j == i) hd[i] += g;
-                }
+            for (int g = 0; g < 21; g++) acc[g] += pr_[g];
+            hd[0] += pr_[0]; hd[1] += pr_[6]; hd[2] += pr_[11]; hd[3] += pr_[15]; hd[4] += pr_[18]; hd[5] += pr_[20];
 #pragma unroll
             for (int i = 0; i < 6; i++) bp[i] += pr_[21 + i];
         } else {
-            const double* ra = B.erec + VBA_EREC * (size_t)(d.obs0 + sa);
+            const double* ra = B.erec + ((LD == 1) ? VBA_EREC1 : VBA_EREC) * (size_t)(d.obs0 + sa);
+            const double r0 = (LD == 1) ? ra[12] : 0.0, r1 = (LD == 1) ? ra[13] : 0.0;
+            double b0[6], b1[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { b0[i] = ra[i]; b1[i] = ra[6 + i]; }
+            int gi = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
 #pragma unroll
-                for (int j = 0; j < 6; j++) acc[6 * i + j] += ra[i] * ra[j] + ra[6 + i] * ra[6 + j];
-                hd[i] += ra[i] * ra[i] + ra[6 + i] * ra[6 + i];
-                bp[i] += ra[24 + i];
+                for (int j = i; j < 6; j++) acc[gi++] += b0[i] * b0[j] + b1[i] * b1[j];
+                hd[i] += b0[i] * b0[i] + b1[i] * b1[i];
+                bp[i] += (LD == 1) ? -(b0[i] * r0 + b1[i] * r1) : ra[24 + i];
             }
         }
+        int gi = 0;
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+        for (int i = 0; i < 6; i++) {
 #pragma unroll
-            for (int l = 0; l < LD; l++) {
-                rhs[i] -= UA[LD * i + l] * beta[l];
+            for (int l = 0; l < LD; l++) rhs[i] -= UA[LD * i + l] * beta[l];
 #pragma unroll
-                for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA[LD * i + l] * UA[LD * j + l];
+            for (int j = i; j < 6; j++) {
+#pragma unroll
+                for (int l = 0; l < LD; l++) acc[gi] -= UA[LD * i + l] * UA[LD * j + l];
+                gi++;
             }
+        }
     }
 #pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] = wave_sum(acc[i]);
+    for (int i = 0; i < 21; i++) acc[i] = wave_sum(acc[i]);
 #pragma unroll
     for (int i = 0; i < 6; i++) { rhs[i] = wave_sum(rhs[i]); bp[i] = wave_sum(bp[i]); hd[i] = wave_sum(hd[i]); }
     const int P = d.pdim;
     for (int q = t; q < P * P; q += 64) blk[q] = 0.0;
     __syncthreads();
     if (t == 0) {
+        int gi = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) blk[i * P + j] = acc[6 * i + j];
+            for (int j = i; j < 6; j++) { blk[i * P + j] = acc[gi]; blk[j * P + i] = acc[gi]; gi++; }
             sh_r[i] = rhs[i]; sh_b[i] = bp[i]; sh_h[i] = hd[i];
         }
     }
