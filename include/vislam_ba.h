@@ -32,6 +32,10 @@ extern "C" {
 #define VBA_ALGO_GN 0 /* OptimizationAlgorithmGaussNewton with the |dchi2|<1e-3 stop (gauss_newton.cpp:97) */
 #define VBA_ALGO_LM 1 /* OptimizationAlgorithmLevenberg, g2o lambda/rho schedule (levenberg.cpp:61-164)    */
 
+#define VBA_PROTO_LOCAL 0  /* optimize(its_stage1); outlier pass; optimize(its_stage2): the LocalBA functions */
+#define VBA_PROTO_SINGLE 1 /* one optimize(its_stage1), no outlier pass: BundleAdjustment / GlobalBundleAdjustmentNavStatePRV
+                            * (src/Optimizer.cpp:3377-3607, 629-933) */
+
 #define VBA_IMU_MEAS_STRIDE 61 /* dt, dP(3), dV(3), dR(9 row-major), JPg, JPa, JVg, JVa, JRg (9 each, row-major) */
 #define VBA_TRACE_MAX 64
 
@@ -74,6 +78,12 @@ typedef struct vba_problem {
     double chi2_th;           /* 5.991 */
     double depth_min;         /* isDepthPositive threshold: 0.01 (EdgePRIDP, g2otypes.h:122-127) or 0.0 */
     double rho_min;           /* 2e-6 (variant 2 outlier gate, src/Optimizer.cpp:484) */
+    /* --- global bundle adjustment; all zero / NULL = the local-BA protocol above --- */
+    int32_t protocol;         /* VBA_PROTO_* */
+    int32_t robust;           /* VBA_PROTO_SINGLE only: bRobust -- Huber on every edge (1) or none at all (0) */
+    const uint8_t *kf_fix;    /* NULL or [n_kf]: per-vertex setFixed() of the keyframes listed as free: bit0 PR, bit1 V,
+                               * bit2 Bias (GlobalBundleAdjustmentNavStatePRV fixes PR and Bias of keyframe 0 but not
+                               * its V: src/Optimizer.cpp:667-685) */
 } vba_problem;
 
 typedef struct vba_result {

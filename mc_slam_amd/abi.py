@@ -11,6 +11,7 @@ from typing import Optional
 import numpy as np
 
 VARIANT_SE3_XYZ, VARIANT_PRV_XYZ, VARIANT_PRV_IDP = 0, 1, 2
+PROTO_LOCAL, PROTO_SINGLE = 0, 1
 ALGO_GN, ALGO_LM = 0, 1
 IMU_MEAS_STRIDE = 61
 TRACE_MAX = 64
@@ -46,6 +47,7 @@ class vba_problem(C.Structure):
         ("huber_vis", C.c_double), ("huber_prv", C.c_double), ("huber_bias", C.c_double),
         ("algo", C.c_int32), ("its_stage1", C.c_int32), ("its_stage2", C.c_int32),
         ("chi2_th", C.c_double), ("depth_min", C.c_double), ("rho_min", C.c_double),
+        ("protocol", C.c_int32), ("robust", C.c_int32), ("kf_fix", _pu8),
     ]
 
 
@@ -107,6 +109,9 @@ class Problem:
     huber_vis: float = HUBER_VIS
     huber_prv: float = HUBER_PRV
     huber_bias: float = HUBER_BIAS
+    protocol: int = 0                          # PROTO_LOCAL / PROTO_SINGLE
+    robust: int = 1
+    kf_fix: Optional[np.ndarray] = None        # [n_kf] uint8: bit0 PR, bit1 V, bit2 Bias fixed
     truth: dict = field(default_factory=dict)  # generator ground truth (not part of the ABI)
 
     def __post_init__(self):
@@ -159,6 +164,11 @@ class Problem:
         s.huber_vis, s.huber_prv, s.huber_bias = self.huber_vis, self.huber_prv, self.huber_bias
         s.algo, s.its_stage1, s.its_stage2 = self.algo, self.its_stage1, self.its_stage2
         s.chi2_th, s.depth_min, s.rho_min = self.chi2_th, self.depth_min, self.rho_min
+        s.protocol, s.robust = self.protocol, self.robust
+        if self.kf_fix is not None:
+            self.kf_fix = np.ascontiguousarray(self.kf_fix, dtype=np.uint8)
+            assert self.kf_fix.shape == (self.n_kf,)
+            s.kf_fix = p(self.kf_fix, _pu8)
         return s
 
 

@@ -49,6 +49,8 @@ struct WinDesc {
     double inv_bg, inv_ba;
     double hub_vis, hub_prv, hub_bias;
     double chi2_th, depth_min, rho_min;
+    int protocol;    // VBA_PROTO_*: 1 = one optimize(its[0]) and no outlier pass (global BA)
+    int robust;      // protocol 1: Huber on every edge, or on none
 };
 
 struct WinCtrl {

@@ -25,6 +25,7 @@ struct Batch {
     unsigned char* lvl;
     double *chi2_e, *depth_e, *chi2_f;  // chi2_f: chi2 recomputed at the final estimates (LM: chi2_e may be stale)
     double *erec, *prec, *slot, *n0rec;
+    const unsigned char* kf_fix;  // [n_kf] per-vertex setFixed() of listed-free keyframes: bit0 PR, bit1 V, bit2 Bias
     // IMU factors
     const int *imu_i, *imu_j;
     const double *imu_meas, *imu_info;
@@ -67,6 +68,19 @@ DEVI void kf_cache(const Batch& B, const WinDesc& d, int a) {
     C[9] = T[0]; C[10] = T[1]; C[11] = T[2];
 }
 
+// free vertices of keyframe kf: bit0 PR, bit1 V, bit2 Bias (0 for the keyframes listed as fixed)
+DEVI int kf_free(const Batch& B, const WinDesc& d, int kf) {
+    if (kf >= d.n_free) return 0;
+    return 7 & ~(int)B.kf_fix[d.kf0 + kf];
+}
+// allVerticesFixed edges are dropped (sparse_optimizer.cpp:236): bit0 EdgeNavStatePRV (PR_i PR_j V_i V_j Bias_i),
+// bit1 EdgeNavStateBias (Bias_i Bias_j)
+DEVI int imu_act(const Batch& B, const WinDesc& d, int i, int j) {
+    const int fi = kf_free(B, d, i), fj = kf_free(B, d, j);
+    return ((fi | (fj & 3)) ? 1 : 0) | (((fi | fj) & 4) ? 2 : 0);
+}
+DEVI bool imu_robust(const WinDesc& d) { return !(d.protocol == 1 && !d.robust); }
+
 __global__ void __launch_bounds__(64) k_reset(Batch B) {
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
@@ -90,7 +104,8 @@ __global__ void __launch_bounds__(64) k_reset(Batch B) {
         WinCtrl& c = B.ctrl[w];
         c.stage = 0; c.it = 0; c.active = 0; c.status = 0;
         c.its_done[0] = c.its_done[1] = 0;
-        c.robust_vis = 1; c.chol_fail = 0; c.step_ok = 0; c.aborted = 0;
+        c.robust_vis = (d.protocol == 1) ? (d.robust != 0) : 1;
+        c.chol_fail = 0; c.step_ok = 0; c.aborted = 0;
         c.n_trace = 0; c.n_outliers = 0;
         c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0;
         c.lambda = 0; c.ni = 2; c.chi_prev = 0; c.chi_ini = 0;
@@ -113,6 +128,8 @@ __global__ void __launch_bounds__(64) k_stage_clear(Batch B, int stage) {
         if (stage == 0) {
             if (stop) { c.aborted = 1; c.status = 2; c.active = 0; }  // src/Optimizer.cpp:453-455
             else c.active = 1;
+        } else if (d.protocol == 1) {
+            c.active = 0;  // BundleAdjustment: a single optimize(nIterations), no second stage (:3517, :835)
         } else {
             if (c.aborted || stop) {  // :462-470 -- skip stage 2
                 if (!c.aborted) { c.aborted = 1; c.status = 1; }
@@ -134,21 +151,22 @@ __global__ void __launch_bounds__(64) k_stage_mark(Batch B) {
     int* va = B.var_act + d.vec0;
     if (t < d.n_obs && !B.lvl[d.obs0 + t]) {
         const int kf = B.obs_kf[d.obs0 + t];
-        if (kf < d.n_free)
+        if (kf_free(B, d, kf) & 1)
             for (int i = 0; i < 6; i++) va[vpos(d, kf, i)] = 1;
         if (d.variant == 2) {
             const int rf = B.pt_ref[d.pt0 + B.obs_pt[d.obs0 + t]];
-            if (rf < d.n_free)
+            if (kf_free(B, d, rf) & 1)
                 for (int i = 0; i < 6; i++) va[vpos(d, rf, i)] = 1;
         }
     }
     if (t < d.n_imu) {
         const int i = B.imu_i[d.imu0 + t], j = B.imu_j[d.imu0 + t];
-        if (i < d.n_free || j < d.n_free) {  // allVerticesFixed edges are dropped
-            if (i < d.n_free)
-                for (int k = 0; k < 15; k++) va[vpos(d, i, k)] = 1;
-            if (j < d.n_free)
-                for (int k = 0; k < 15; k++) va[vpos(d, j, k)] = 1;
+        const int fi = kf_free(B, d, i), fj = kf_free(B, d, j), act = imu_act(B, d, i, j);
+        // the PRV edge touches PR_i, PR_j, V_i, V_j, Bias_i; the bias edge Bias_i, Bias_j
+        for (int k = 0; k < 15; k++) {
+            const int part = (k < 6) ? 0 : ((k < 9) ? 1 : 2);
+            if (((fi >> part) & 1) && ((act & 1) || (part == 2 && (act & 2)))) va[vpos(d, i, k)] = 1;
+            if (((fj >> part) & 1) && ((part < 2 && (act & 1)) || (part == 2 && (act & 2)))) va[vpos(d, j, k)] = 1;
         }
     }
 }
@@ -167,9 +185,10 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
     double* J = sm;            // 9 x 30
     double* Om = sm + 270;     // 9 x 9 weighted information
     double* T = sm + 351;      // 9 x 30 = Om J
-    double* er = sm + 621;     // 9 err + 6 bias err + 2 weights(bias wg, wa scaled)
+    double* er = sm + 621;     // 9 err + 6 bias err + 2 weights(bias wg, wa scaled) + 30 column masks
     const int t = threadIdx.x;
-    if (i >= d.n_free && j >= d.n_free) return;  // edge between two fixed keyframes: not in the active set
+    const int act = imu_act(B, d, i, j);
+    if (!act) return;  // every vertex fixed: not in the active set
     const double* meas = B.imu_meas + 61 * gk;
     if (t == 0) {
         const double* Ti = B.pose + 7 * (size_t)(d.kf0 + i);
@@ -216,8 +235,9 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
             for (int b = 0; b < 9; b++) tt += info[9 * a + b] * e[b];
             s += e[a] * tt;
         }
-        double rw, rwb;
-        const double rob = huber(s, d.hub_prv, &rw);
+        double rw = 1.0, rwb = 1.0;
+        const bool rk = imu_robust(d);
+        const double rob = rk ? huber(s, d.hub_prv, &rw) : s;
         double eb[6];
         for (int m = 0; m < 3; m++) {
             eb[m] = (bj[m] + bj[6 + m]) - (bi[m] + bi[6 + m]);
@@ -225,14 +245,22 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
         }
         const double wg = d.inv_bg / dT, wa = d.inv_ba / dT;
         const double sb = wg * (eb[0] * eb[0] + eb[1] * eb[1] + eb[2] * eb[2]) + wa * (eb[3] * eb[3] + eb[4] * eb[4] + eb[5] * eb[5]);
-        const double robb = huber(sb, d.hub_bias, &rwb);
+        const double robb = rk ? huber(sb, d.hub_bias, &rwb) : sb;
         double* ch = B.imu_chi + 4 * gk;
-        ch[0] = rob; ch[1] = robb; ch[2] = s; ch[3] = sb;
+        ch[0] = (act & 1) ? rob : 0.0; ch[1] = (act & 2) ? robb : 0.0; ch[2] = (act & 1) ? s : 0.0; ch[3] = (act & 2) ? sb : 0.0;
         if (mode == LIN_FULL) {
             for (int a = 0; a < 9; a++) er[a] = e[a];
             for (int a = 0; a < 6; a++) er[9 + a] = eb[a];
-            er[15] = rwb * wg; er[16] = rwb * wa;
-            for (int a = 0; a < 81; a++) Om[a] = rw * info[a];
+            er[15] = (act & 2) ? rwb * wg : 0.0; er[16] = (act & 2) ? rwb * wa : 0.0;
+            {   // column mask of the 30 local variables: 0 where the vertex is fixed through kf_fix
+                const int fi = (i < d.n_free) ? kf_free(B, d, i) : 7, fj = (j < d.n_free) ? kf_free(B, d, j) : 7;
+                for (int q = 0; q < 15; q++) {
+                    const int part = (q < 6) ? 0 : ((q < 9) ? 1 : 2);
+                    er[17 + q] = ((fi >> part) & 1) ? 1.0 : 0.0;
+                    er[32 + q] = ((fj >> part) & 1) ? 1.0 : 0.0;
+                }
+            }
+            for (int a = 0; a < 81; a++) Om[a] = (act & 1) ? rw * info[a] : 0.0;
             for (int a = 0; a < 270; a++) J[a] = 0.0;
             // Jacobians (g2otypes.cpp:296-359); local columns: PR_i 0..5, V_i 6..8, B_i 9..14, PR_j 15..20, V_j 21..23
             double RiT[9], RjT[9], JrI[9], H1[9], H2[9], T1[9], T2[9];
@@ -297,7 +325,7 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
             const double sr = (r < 15) ? -1.0 : 1.0, scn = (col < 15) ? -1.0 : 1.0;
             s += sr * scn * wq;
         }
-        H[q] = s;
+        H[q] = s * er[17 + r] * er[17 + col];
     }
     if (t < 30) {  // rhs = -J^T Om e  (+ bias edge)
         double s = 0;
@@ -308,7 +336,7 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
             const double sr = (t < 15) ? -1.0 : 1.0;
             s -= sr * wq * er[9 + rb];
         }
-        H[900 + t] = s;
+        H[900 + t] = s * er[17 + t];
     }
 }
 
@@ -375,7 +403,7 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
         for (int i = 0; i < 3; i++) { q[1 + i] = y[i]; q[4 + i] = Xw[i]; }
 #pragma unroll
         for (int i = 0; i < 9; i++) q[7 + i] = N0[i];
-        q[16] = (rf < d.n_free) ? 1.0 : 0.0;
+        q[16] = (kf_free(B, d, rf) & 1) ? 1.0 : 0.0;
     }
     __syncthreads();
     // B. one lane per edge.  With A = sqrt(rho' w) J_pi R_cb R_i^T (2x3) the two pose Jacobians of the edge are
@@ -422,7 +450,7 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
 #pragma unroll
                     for (int k = 0; k < 3; k++)
                         Jc[3 * rr + k] = Jp[3 * rr] * d.Rcb[k] + Jp[3 * rr + 1] * d.Rcb[3 + k] + Jp[3 * rr + 2] * d.Rcb[6 + k];
-                const bool of = kf < d.n_free;
+                const bool of = kf_free(B, d, kf) & 1;
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
 #pragma unroll
@@ -1345,6 +1373,7 @@ __global__ void __launch_bounds__(64) k_final_edges(Batch B) {
         const double s = B.chi2_e[go];
         bool bad = (s > d.chi2_th) || !(B.depth_e[go] > d.depth_min);
         if (d.variant == 2 && (B.pt[3 * (size_t)(d.pt0 + B.obs_pt[go])] < d.rho_min || B.lvl[go])) bad = true;
+        if (d.protocol == 1) bad = false;  // global BA classifies nothing
         B.out_outlier[go] = bad ? 1 : 0;
         B.out_chi2[go] = s;
         if (!B.lvl[go]) chi = B.chi2_f ? B.chi2_f[go] : s;

@@ -61,7 +61,7 @@ DEVI void lin_point_xyz(const Batch& B, const WinDesc& d, const WinCtrl& c, int 
         const double x = Pc[0], y = Pc[1], z = Pc[2];
         const double Jp[6] = {fx * iz, 0.0, -x * iz * fx * iz, 0.0, fy * iz, -y * iz * fy * iz};
         double A[6], Bi[12];
-        const bool of = kf < d.n_free;
+        const bool of = kf_free(B, d, kf) & 1;
         if (d.variant == 0) {
             // types_six_dof_expmap.cpp:124-138: J_point = -(1/z) tmp R ; J_pose closed form (rotation, then translation)
 #pragma unroll
@@ -141,7 +141,7 @@ DEVI double block_max(double v, double* sm) {
 }
 
 __global__ void __launch_bounds__(64) k_lin_xyz(Batch B, int nblk_pt, int mode) {
-    __shared__ double sm[640];
+    __shared__ double sm[672];
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];

@@ -46,7 +46,7 @@ enum {
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
-    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_N
+    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_N
 };
 
 struct ProfEvt {
@@ -317,6 +317,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->n_win = n;
     h->desc.assign(n, WinDesc());
     std::vector<double> pose, vel, bias, pt, uv, ow, meas, info;
+    std::vector<unsigned char> kffix;
     std::vector<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
     std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, offpair, pairmask;
     h->step_grid.clear();
@@ -342,8 +343,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         if (P->n_kf_free <= 0 || P->n_kf_free > P->n_kf || P->n_pt < 0 || P->n_obs < 0) return fail(h, "bad sizes");
         if (w > 0 && (P->variant != probs[0]->variant || P->algo != probs[0]->algo)) return fail(h, "mixed batch");
         if (P->its_stage1 > 30 || P->its_stage2 > 30 || P->its_stage1 < 0 || P->its_stage2 < 0) return fail(h, "its out of range");
+        if (P->protocol != VBA_PROTO_LOCAL && P->protocol != VBA_PROTO_SINGLE) return fail(h, "unknown protocol");
         WinDesc& d = h->desc[w];
         d.variant = P->variant; d.algo = P->algo;
+        d.protocol = P->protocol; d.robust = P->robust;
         d.win = w;
         d.n_kf = P->n_kf; d.n_free = P->n_kf_free; d.n_pt = P->n_pt; d.n_obs = P->n_obs;
         d.n_imu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
@@ -398,6 +401,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         }
         h->tile_updates += (double)st.tpairs.size();
         pose.insert(pose.end(), P->kf_pose, P->kf_pose + 7 * (size_t)d.n_kf);
+        for (int k = 0; k < d.n_kf; k++) kffix.push_back(P->kf_fix ? (unsigned char)(P->kf_fix[k] & 7) : 0);
         if (P->kf_vel) vel.insert(vel.end(), P->kf_vel, P->kf_vel + 3 * (size_t)d.n_kf);
         else vel.insert(vel.end(), 3 * (size_t)d.n_kf, 0.0);
         if (P->kf_bias) bias.insert(bias.end(), P->kf_bias, P->kf_bias + 12 * (size_t)d.n_kf);
@@ -451,6 +455,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (h2d(h, BUF_DESC, h->desc)) return -1;
     if (dalloc(h, BUF_CTRL, sizeof(WinCtrl) * n)) return -1;
     if (h2d(h, BUF_POSE0, pose) || h2d(h, BUF_VEL0, vel) || h2d(h, BUF_BIAS0, bias) || h2d(h, BUF_PT0, pt)) return -1;
+    if (h2d(h, BUF_KFFIX, kffix)) return -1;
     if (dalloc(h, BUF_POSE, pose.size() * 8) || dalloc(h, BUF_VEL, vel.size() * 8) || dalloc(h, BUF_BIAS, bias.size() * 8)) return -1;
     if (dalloc(h, BUF_POSEBK, pose.size() * 8) || dalloc(h, BUF_VELBK, vel.size() * 8) || dalloc(h, BUF_BIASBK, bias.size() * 8)) return -1;
     if (dalloc(h, BUF_KFR, (size_t)kf0 * 12 * 8) || dalloc(h, BUF_PT, pt.size() * 8) || dalloc(h, BUF_PTBK, pt.size() * 8)) return -1;
@@ -500,7 +505,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.obs_uv = dp<double>(h, BUF_OBSUV); B.obs_w = dp<double>(h, BUF_OBSW);
     B.lvl = dp<unsigned char>(h, BUF_LVL); B.chi2_e = dp<double>(h, BUF_CHI2E); B.depth_e = dp<double>(h, BUF_DEPTH);
     B.chi2_f = (probs[0]->variant == VBA_VARIANT_PRV_IDP) ? nullptr : dp<double>(h, BUF_CHI2F);
-    B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC); B.slot = dp<double>(h, BUF_SLOT); B.n0rec = dp<double>(h, BUF_N0REC);
+    B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC); B.slot = dp<double>(h, BUF_SLOT); B.n0rec = dp<double>(h, BUF_N0REC); B.kf_fix = dp<unsigned char>(h, BUF_KFFIX);
     B.imu_i = dp<int>(h, BUF_IMUI); B.imu_j = dp<int>(h, BUF_IMUJ);
     B.imu_meas = dp<double>(h, BUF_IMUMEAS); B.imu_info = dp<double>(h, BUF_IMUINFO);
     B.imuH = dp<double>(h, BUF_IMUH); B.imu_chi = dp<double>(h, BUF_IMUCHI);
@@ -919,7 +924,7 @@ int vba_debug_buf_id(const char* name) {
     static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
-        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC"};
+        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;

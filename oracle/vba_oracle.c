@@ -639,6 +639,8 @@ typedef struct {
     double *S, *bs, *x;     /* reduced system, x = [np + nl] */
     unsigned char *pt_act;  /* [npt] landmark in the active set */
     unsigned char *var_act; /* [np] pose scalar variable belongs to an active vertex */
+    const unsigned char *fix; /* P->kf_fix or NULL: per-vertex setFixed() of listed-free keyframes */
+    int imu_robust;         /* Huber on the PRV / bias edges (always, except bRobust = false in global BA) */
     int solver_perm;        /* 1: order V/Bias blocks first for the skyline LDLT */
     int *perm;              /* [np] */
     double *Lwork;          /* [np*np] */
@@ -646,7 +648,14 @@ typedef struct {
     double *ywork;
 } ctx;
 
-static int kf_col(const ctx *c, int kf) { return kf < c->nfree ? kf * c->pdim : -1; }
+/* first column of vertex `part` (0 PR, 1 V, 2 Bias) of keyframe kf in H_pp, or -1 if that vertex is fixed */
+static int vcol(const ctx *c, int kf, int part) {
+    static const int off[3] = {0, 6, 9};
+    if (kf >= c->nfree) return -1;
+    if (c->fix && ((c->fix[kf] >> part) & 1)) return -1;
+    return kf * c->pdim + off[part];
+}
+static int kf_col(const ctx *c, int kf) { return vcol(c, kf, 0); }
 
 static double chi2_2(const double *e, double w) { return e[0] * (w * e[0]) + e[1] * (w * e[1]); }
 
@@ -660,8 +669,17 @@ static double quadform(const double *e, const double *Om, int d) {
     return s;
 }
 
-static int imu_edge_active(const ctx *c, int k) { /* allVerticesFixed -> dropped, sparse_optimizer.cpp:236 */
-    return c->P->imu_kf_i[k] < c->nfree || c->P->imu_kf_j[k] < c->nfree;
+/* allVerticesFixed -> the edge is dropped from the active set, sparse_optimizer.cpp:236.  bit0: EdgeNavStatePRV
+ * (PR_i, PR_j, V_i, V_j, Bias_i), bit1: EdgeNavStateBias (Bias_i, Bias_j) */
+static int imu_edge_active(const ctx *c, int k) {
+    const int i = c->P->imu_kf_i[k], j = c->P->imu_kf_j[k];
+    const int prv = vcol(c, i, 0) >= 0 || vcol(c, j, 0) >= 0 || vcol(c, i, 1) >= 0 || vcol(c, j, 1) >= 0 || vcol(c, i, 2) >= 0;
+    const int bias = vcol(c, i, 2) >= 0 || vcol(c, j, 2) >= 0;
+    return prv | (bias << 1);
+}
+static void huber_or_not(int on, double s, double delta, double *rho) {
+    if (on) vbo_huber(s, delta, rho);
+    else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
 }
 
 /* vision residual of observation o of point p at the working state; returns camera-frame depth */
@@ -697,10 +715,15 @@ static void init_active(ctx *c) {
             }
         }
     for (int k = 0; k < c->nimu; k++) {
-        if (!imu_edge_active(c, k)) continue;
-        int ci = kf_col(c, P->imu_kf_i[k]), cj = kf_col(c, P->imu_kf_j[k]);
-        if (ci >= 0) memset(c->var_act + ci, 1, 15); /* PR_i, V_i, Bias_i */
-        if (cj >= 0) memset(c->var_act + cj, 1, 15); /* PR_j, V_j (PRV) and Bias_j (bias edge) */
+        const int act = imu_edge_active(c, k);
+        const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
+        static const int dims[3] = {6, 3, 6};
+        for (int part = 0; part < 3; part++) {
+            const int ci = vcol(c, i, part), cj = vcol(c, j, part);
+            /* PRV touches PR_i, PR_j, V_i, V_j, Bias_i; the bias edge Bias_i, Bias_j */
+            if (ci >= 0 && ((act & 1) || (part == 2 && (act & 2)))) memset(c->var_act + ci, 1, dims[part]);
+            if (cj >= 0 && ((part < 2 && (act & 1)) || (part == 2 && (act & 2)))) memset(c->var_act + cj, 1, dims[part]);
+        }
     }
 }
 
@@ -710,19 +733,24 @@ static double compute_errors(ctx *c) {
     const vba_problem *P = c->P;
     double chi = 0, rho[3];
     for (int k = 0; k < c->nimu; k++) {
-        if (!imu_edge_active(c, k)) continue;
+        const int act = imu_edge_active(c, k);
+        if (!act) continue;
         const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
         const double *meas = P->imu_meas + VBA_IMU_MEAS_STRIDE * k;
-        vbo_edge_prv_error(c->pose + 7 * i, c->pose + 7 * j, c->vel + 3 * i, c->vel + 3 * j, c->bias + 12 * i, meas, P->g_w,
-                           c->imu_err + 9 * k);
-        vbo_huber(quadform(c->imu_err + 9 * k, P->imu_info_prv + 81 * k, 9), P->huber_prv, rho);
-        chi += rho[0];
-        vbo_edge_bias_error(c->bias + 12 * i, c->bias + 12 * j, c->bias_err + 6 * k);
-        const double *e = c->bias_err + 6 * k;
-        const double wg = P->inv_bg_rw2 / meas[0], wa = P->inv_ba_rw2 / meas[0];
-        const double s = wg * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + wa * (e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
-        vbo_huber(s, P->huber_bias, rho);
-        chi += rho[0];
+        if (act & 1) {
+            vbo_edge_prv_error(c->pose + 7 * i, c->pose + 7 * j, c->vel + 3 * i, c->vel + 3 * j, c->bias + 12 * i, meas, P->g_w,
+                               c->imu_err + 9 * k);
+            huber_or_not(c->imu_robust, quadform(c->imu_err + 9 * k, P->imu_info_prv + 81 * k, 9), P->huber_prv, rho);
+            chi += rho[0];
+        }
+        if (act & 2) {
+            vbo_edge_bias_error(c->bias + 12 * i, c->bias + 12 * j, c->bias_err + 6 * k);
+            const double *e = c->bias_err + 6 * k;
+            const double wg = P->inv_bg_rw2 / meas[0], wa = P->inv_ba_rw2 / meas[0];
+            const double s = wg * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + wa * (e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
+            huber_or_not(c->imu_robust, s, P->huber_bias, rho);
+            chi += rho[0];
+        }
     }
     for (int p = 0; p < c->npt; p++)
         for (int o = P->pt_obs_begin[p]; o < P->pt_obs_begin[p + 1]; o++) {
@@ -786,33 +814,33 @@ static void build_system(ctx *c) {
     if (c->Wref) memset(c->Wref, 0, sizeof(double) * (size_t)c->npt * 6);
     double rho[3];
     for (int k = 0; k < c->nimu; k++) {
-        if (!imu_edge_active(c, k)) continue;
+        const int act = imu_edge_active(c, k);
+        if (!act) continue;
         const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
-        const int ci = kf_col(c, i), cj = kf_col(c, j);
         const double *meas = P->imu_meas + VBA_IMU_MEAS_STRIDE * k;
-        {   /* EdgeNavStatePRV */
+        if (act & 1) {   /* EdgeNavStatePRV */
             double J0[54], J1[54], J2[27], J3[27], J4[54], Om[81], omr[9];
             const double *e = c->imu_err + 9 * k;
             vbo_edge_prv_jac(c->pose + 7 * i, c->pose + 7 * j, c->vel + 3 * i, c->vel + 3 * j, c->bias + 12 * i, meas,
                              P->g_w, e, J0, J1, J2, J3, J4);
             const double *info = P->imu_info_prv + 81 * k;
-            vbo_huber(quadform(e, info, 9), P->huber_prv, rho); /* base_multi_edge.hpp:36-48 */
+            huber_or_not(c->imu_robust, quadform(e, info, 9), P->huber_prv, rho); /* base_multi_edge.hpp:36-48 */
             for (int a = 0; a < 81; a++) Om[a] = rho[1] * info[a];
             for (int a = 0; a < 9; a++) {
                 double s = 0;
                 for (int bb = 0; bb < 9; bb++) s += info[9 * a + bb] * e[bb];
                 omr[a] = -s * rho[1];
             }
-            const int col[5] = {ci, cj, ci < 0 ? -1 : ci + 6, cj < 0 ? -1 : cj + 6, ci < 0 ? -1 : ci + 9};
+            const int col[5] = {vcol(c, i, 0), vcol(c, j, 0), vcol(c, i, 1), vcol(c, j, 1), vcol(c, i, 2)};
             const int dim[5] = {6, 6, 3, 3, 6};
             const double *const Js[5] = {J0, J1, J2, J3, J4};
             accum_pose(c, 9, Om, omr, 5, col, dim, Js);
         }
-        {   /* EdgeNavStateBias (BaseBinaryEdge, base_binary_edge.hpp:55-120): J = -I, +I */
+        if (act & 2) {   /* EdgeNavStateBias (BaseBinaryEdge, base_binary_edge.hpp:55-120): J = -I, +I */
             const double *e = c->bias_err + 6 * k;
             const double wg = P->inv_bg_rw2 / meas[0], wa = P->inv_ba_rw2 / meas[0];
             const double s = wg * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + wa * (e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
-            vbo_huber(s, P->huber_bias, rho);
+            huber_or_not(c->imu_robust, s, P->huber_bias, rho);
             double Om[36], omr[6], Ji[36], Jj[36];
             memset(Om, 0, sizeof Om);
             memset(Ji, 0, sizeof Ji);
@@ -824,7 +852,7 @@ static void build_system(ctx *c) {
                 Ji[7 * a] = -1.0;
                 Jj[7 * a] = 1.0;
             }
-            const int col[2] = {ci < 0 ? -1 : ci + 9, cj < 0 ? -1 : cj + 9};
+            const int col[2] = {vcol(c, i, 2), vcol(c, j, 2)};
             const int dim[2] = {6, 6};
             const double *const Js[2] = {Ji, Jj};
             accum_pose(c, 6, Om, omr, 2, col, dim, Js);
@@ -1182,6 +1210,7 @@ int vba_oracle_solve(vba_problem *P, vba_result *out, const volatile int *stop, 
     c->P = P;
     c->variant = P->variant;
     c->nkf = P->n_kf; c->nfree = P->n_kf_free; c->npt = P->n_pt; c->nobs = P->n_obs;
+    c->fix = P->kf_fix; c->imu_robust = !(P->protocol == VBA_PROTO_SINGLE && !P->robust);
     c->nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
     c->pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
     c->np = c->pdim * c->nfree;
@@ -1225,12 +1254,13 @@ int vba_oracle_solve(vba_problem *P, vba_result *out, const volatile int *stop, 
 
     int failed = 0;
     /* stage 1: all edges level 0, Huber everywhere; optimize(its_stage1)  (src/Optimizer.cpp:458-459) */
-    c->vis_robust = 1;
+    const int single = P->protocol == VBA_PROTO_SINGLE; /* BundleAdjustment: one optimize(nIterations), :3517 / :835 */
+    c->vis_robust = single ? (P->robust != 0) : 1;
     init_active(c);
     out->its_done[0] = (P->algo == VBA_ALGO_LM) ? optimize_lm(c, P->its_stage1, stop, out, &failed)
                                                  : optimize_gn(c, P->its_stage1, stop, out, &failed);
-    int do_more = !(stop && *stop); /* :462-466 */
-    if (!do_more) out->status = VBA_ABORTED_AFTER_STAGE1;
+    int do_more = !single && !(stop && *stop); /* :462-466 */
+    if (!do_more && !single) out->status = VBA_ABORTED_AFTER_STAGE1;
     if (do_more) {
         /* outlier pass :475-490 (reads e->chi2() from the stored _error, recomputes the depth) */
         for (int p = 0; p < c->npt; p++)
@@ -1256,21 +1286,23 @@ int vba_oracle_solve(vba_problem *P, vba_result *out, const volatile int *stop, 
             const double chi = chi2_2(c->err + 2 * o, P->obs_w[o]);
             int bad = (chi > P->chi2_th) || !(z > P->depth_min);
             if (c->variant == VBA_VARIANT_PRV_IDP && (c->pt[3 * p] < P->rho_min || c->lvl[o] != 0)) bad = 1;
+            if (single) bad = 0; /* global BA classifies nothing */
             if (out->obs_outlier) out->obs_outlier[o] = (uint8_t)bad;
             if (out->obs_chi2) out->obs_chi2[o] = chi;
             out->n_outliers += bad;
             if (!c->lvl[o]) out->chi2_vis += chi2_2(e, P->obs_w[o]); /* recomputed at the final estimates (N3) */
         }
     for (int k = 0; k < c->nimu; k++) {
-        if (!imu_edge_active(c, k)) continue;
+        const int act = imu_edge_active(c, k);
+        if (!act) continue;
         const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
         const double *meas = P->imu_meas + VBA_IMU_MEAS_STRIDE * k;
         double e9[9], e6[6];
         vbo_edge_prv_error(c->pose + 7 * i, c->pose + 7 * j, c->vel + 3 * i, c->vel + 3 * j, c->bias + 12 * i, meas, P->g_w, e9);
-        out->chi2_prv += quadform(e9, P->imu_info_prv + 81 * k, 9);
+        if (act & 1) out->chi2_prv += quadform(e9, P->imu_info_prv + 81 * k, 9);
         vbo_edge_bias_error(c->bias + 12 * i, c->bias + 12 * j, e6);
         const double wg = P->inv_bg_rw2 / meas[0], wa = P->inv_ba_rw2 / meas[0];
-        out->chi2_bias += wg * (e6[0] * e6[0] + e6[1] * e6[1] + e6[2] * e6[2]) + wa * (e6[3] * e6[3] + e6[4] * e6[4] + e6[5] * e6[5]);
+        if (act & 2) out->chi2_bias += wg * (e6[0] * e6[0] + e6[1] * e6[1] + e6[2] * e6[2]) + wa * (e6[3] * e6[3] + e6[4] * e6[4] + e6[5] * e6[5]);
     }
     /* write back free entries */
     memcpy(P->kf_pose, c->pose, 56 * c->nfree);
@@ -1296,6 +1328,7 @@ int vba_oracle_linearize(vba_problem *P, double lambda, double *Hfull, double *b
     memset(c, 0, sizeof C);
     c->P = P; c->variant = P->variant;
     c->nkf = P->n_kf; c->nfree = P->n_kf_free; c->npt = P->n_pt; c->nobs = P->n_obs;
+    c->fix = P->kf_fix; c->imu_robust = !(P->protocol == VBA_PROTO_SINGLE && !P->robust);
     c->nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
     c->pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
     c->np = c->pdim * c->nfree;
@@ -1376,24 +1409,26 @@ int vba_oracle_eval(vba_problem *P, int robust_vis, double *out, double *obs_chi
     memset(c, 0, sizeof C);
     c->P = P; c->variant = P->variant;
     c->nkf = P->n_kf; c->nfree = P->n_kf_free; c->npt = P->n_pt; c->nobs = P->n_obs;
+    c->fix = P->kf_fix; c->imu_robust = !(P->protocol == VBA_PROTO_SINGLE && !P->robust);
     c->nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
     c->pose = P->kf_pose; c->vel = P->kf_vel; c->bias = P->kf_bias; c->pt = P->pt;
     double rho[3];
     out[0] = out[1] = out[2] = out[3] = 0;
     for (int k = 0; k < c->nimu; k++) {
-        if (!imu_edge_active(c, k)) continue;
+        const int act = imu_edge_active(c, k);
+        if (!act) continue;
         const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
         const double *meas = P->imu_meas + VBA_IMU_MEAS_STRIDE * k;
         double e9[9], e6[6];
         vbo_edge_prv_error(c->pose + 7 * i, c->pose + 7 * j, c->vel + 3 * i, c->vel + 3 * j, c->bias + 12 * i, meas, P->g_w, e9);
         const double s = quadform(e9, P->imu_info_prv + 81 * k, 9);
-        vbo_huber(s, P->huber_prv, rho);
-        out[0] += rho[0]; out[2] += s;
+        huber_or_not(c->imu_robust, s, P->huber_prv, rho);
+        if (act & 1) { out[0] += rho[0]; out[2] += s; }
         vbo_edge_bias_error(c->bias + 12 * i, c->bias + 12 * j, e6);
         const double wg = P->inv_bg_rw2 / meas[0], wa = P->inv_ba_rw2 / meas[0];
         const double sb = wg * (e6[0] * e6[0] + e6[1] * e6[1] + e6[2] * e6[2]) + wa * (e6[3] * e6[3] + e6[4] * e6[4] + e6[5] * e6[5]);
-        vbo_huber(sb, P->huber_bias, rho);
-        out[0] += rho[0]; out[3] += sb;
+        huber_or_not(c->imu_robust, sb, P->huber_bias, rho);
+        if (act & 2) { out[0] += rho[0]; out[3] += sb; }
     }
     for (int p = 0; p < c->npt; p++)
         for (int o = P->pt_obs_begin[p]; o < P->pt_obs_begin[p + 1]; o++) {

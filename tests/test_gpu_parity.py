@@ -245,3 +245,48 @@ def test_on_device_preintegration_matches_oracle_and_numpy(ba, oracle):
     # the information it returns is what vba_problem.imu_info_prv expects
     p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31)
     assert info.shape[1:] == (9, 9) and p.imu_info_prv.shape[1] == 81
+
+
+# ---- global bundle adjustment: one optimize(n), optional kernels, per-vertex fixed flags ----
+def _gba(variant, robust, n_kf=12, n_pt=500, n_obs=3000, seed=50, its=20, outlier_frac=0.02):
+    p = synth.make_window(variant, algo=abi.ALGO_LM, n_kf=n_kf, n_fixed=0 if variant != abi.VARIANT_SE3_XYZ else 1,
+                          n_pt=n_pt, n_obs=n_obs, seed=seed, outlier_frac=outlier_frac)
+    p.protocol, p.robust, p.its_stage1, p.its_stage2 = abi.PROTO_SINGLE, robust, its, 0
+    p.huber_vis = float(np.float32(np.sqrt(5.99)))     # thHuber2D of BundleAdjustment, src/Optimizer.cpp:3414
+    if variant != abi.VARIANT_SE3_XYZ:                 # keyframe 0: PR and Bias fixed, V free (:667-685)
+        p.kf_fix = np.zeros(p.n_kf, np.uint8); p.kf_fix[0] = 0b101
+    return p
+
+
+@pytest.mark.parametrize("variant,robust,seed", [
+    (abi.VARIANT_SE3_XYZ, 1, 50), (abi.VARIANT_SE3_XYZ, 0, 51),
+    (abi.VARIANT_PRV_XYZ, 1, 52), (abi.VARIANT_PRV_XYZ, 0, 53),
+])
+def test_global_ba_protocol_matches_oracle(ba, oracle, variant, robust, seed):
+    """BundleAdjustment (src/Optimizer.cpp:3377-3607) and GlobalBundleAdjustmentNavStatePRV (:629-933)."""
+    p = _gba(variant, robust, seed=seed)
+    q, r = ba.solve(p)
+    qo, ro = oracle.solve(p)
+    _check(p, q, r, qo, ro)
+    assert r.its_done[1] == 0 and r.n_outliers == 0
+    assert abs(r.lambda_final - ro.lambda_final) <= 1e-6 * ro.lambda_final
+    if variant == abi.VARIANT_PRV_XYZ:
+        assert (q.kf_pose[0] == p.kf_pose[0]).all() and (q.kf_bias[0] == p.kf_bias[0]).all()
+        assert (q.kf_vel[0] != p.kf_vel[0]).any()
+        np.testing.assert_allclose(q.kf_bias, qo.kf_bias, atol=1e-7)
+
+
+def test_global_ba_map_scale_properties(ba, oracle):
+    """A 150-keyframe map (n_p = 2250: the oracle's dense solve would take minutes): size-independent properties --
+    the robust cost the solver reports equals the oracle's residual evaluation at the returned state, it went down,
+    the gauge keyframe did not move, reruns are bit-identical."""
+    p = _gba(abi.VARIANT_PRV_XYZ, 1, n_kf=150, n_pt=12000, n_obs=80000, seed=60, its=10)
+    q, r = ba.solve(p)
+    q2, r2 = ba.solve(p)
+    assert r.status == 0 and r.its_done[0] >= 2 and r.its_done[1] == 0
+    assert (q.kf_pose == q2.kf_pose).all() and r.chi2_vis == r2.chi2_vis
+    out = oracle.evaluate(q, robust_vis=1)
+    assert abs(out[1] - r.chi2_vis) <= 1e-9 * r.chi2_vis and abs(out[2] - r.chi2_prv) <= 1e-7 * max(r.chi2_prv, 1e-9)
+    assert abs(out[0] - r.chi2_trace[-1]) <= 1e-9 * out[0]
+    assert r.chi2_trace[-1] < 0.5 * r.chi2_trace[0]
+    assert (q.kf_pose[0] == p.kf_pose[0]).all()

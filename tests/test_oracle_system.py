@@ -104,3 +104,49 @@ def test_gn_terminates_on_small_chi2_change(oracle):
     q, r = oracle.solve(p)
     # noise-free start at truth: first iteration changes the robust chi2 by < 1e-3 -> Terminate (gauss_newton.cpp:97)
     assert r.its_done == (1, 1) and r.n_outliers == 0
+
+
+# ---- global bundle adjustment protocol: per-vertex setFixed + single optimize(n) ----
+@pytest.mark.parametrize("variant", [2, 1])
+def test_per_vertex_fixed_flags_remove_exactly_those_columns(oracle, variant):
+    """GlobalBundleAdjustmentNavStatePRV fixes PR and Bias of keyframe 0 but leaves its V free (src/Optimizer.cpp:667-685)."""
+    kw = dict(MINI[variant]); kw.update(n_fixed=0)
+    p = synth.make_window(variant, **kw)
+    lam = 2.0
+    n, H0, b0, x0, chi0 = oracle.linearize(p, lam)
+    q = p.copy()
+    q.kf_fix = np.zeros(p.n_kf, np.uint8); q.kf_fix[0] = 0b101; q.kf_fix[2] = 0b010
+    n, H1, b1, x1, chi1 = oracle.linearize(q, lam)
+    assert chi1 == chi0
+    fixed = np.zeros(n, bool)
+    fixed[0:6] = True; fixed[9:15] = True          # PR_0, Bias_0
+    fixed[2 * 15 + 6:2 * 15 + 9] = True            # V_2
+    Hm = H0.copy(); Hm[fixed, :] = 0; Hm[:, fixed] = 0
+    bm = b0.copy(); bm[fixed] = 0
+    np.testing.assert_allclose(H1, Hm, rtol=1e-13, atol=1e-12)
+    np.testing.assert_allclose(b1, bm, rtol=1e-13, atol=1e-12)
+    fr = ~fixed
+    xs = np.linalg.solve(H0[np.ix_(fr, fr)] + lam * np.eye(fr.sum()), b0[fr])
+    np.testing.assert_allclose(x1[fr], xs, rtol=1e-7, atol=1e-10 * np.abs(xs).max())
+    assert (x1[fixed] == 0).all()
+
+
+@pytest.mark.parametrize("variant,robust", [(0, 1), (0, 0), (1, 1), (1, 0)])
+def test_single_optimize_protocol_of_global_ba(oracle, variant, robust):
+    """BundleAdjustment / GlobalBundleAdjustmentNavStatePRV: one optimize(n) with LM, no outlier pass (:3517, :835)."""
+    kw = dict(MINI[variant]); kw.update(n_kf=10, n_pt=300, n_obs=1500, outlier_frac=0.0, n_fixed=0 if variant == 1 else 1)
+    p = synth.make_window(variant, **kw)
+    p.protocol, p.robust, p.its_stage1, p.its_stage2 = abi.PROTO_SINGLE, robust, 12, 10
+    if variant == 1:
+        p.kf_fix = np.zeros(p.n_kf, np.uint8); p.kf_fix[0] = 0b101
+    q, r = oracle.solve(p)
+    assert r.status == 0 and r.its_done[1] == 0 and 1 <= r.its_done[0] <= 12 and r.n_outliers == 0
+    assert r.chi2_trace[-1] < r.chi2_trace[0]
+    if variant == 1:   # fixed vertices untouched, the free V of keyframe 0 moved
+        assert (q.kf_pose[0] == p.kf_pose[0]).all() and (q.kf_bias[0] == p.kf_bias[0]).all()
+        assert (q.kf_vel[0] != p.kf_vel[0]).any()
+    # robust = 0 means NO kernel anywhere: the trace is the plain chi2, so its last entry equals the sum of the parts
+    if not robust:
+        e0 = oracle.evaluate(p, robust_vis=0)
+        assert abs(r.chi2_trace[0] - (e0[1] + e0[2] + e0[3])) <= 1e-12 * r.chi2_trace[0]
+        assert abs(r.chi2_trace[-1] - (r.chi2_vis + r.chi2_prv + r.chi2_bias)) <= 1e-9 * r.chi2_trace[-1]
