@@ -397,4 +397,208 @@ void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap
     if (pLM) pLM->SetMapUpdateFlagInTracking(true);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Global bundle adjustment.  Same factors as the local windows at map scale, one optimize(nIterations) with
+// Levenberg-Marquardt, no outlier pass (VBA_PROTO_SINGLE).
+// ------------------------------------------------------------------------------------------------
+namespace {
+// landmarks + monocular reprojection edges of a whole map (src/Optimizer.cpp:776-833 / :3417-3513)
+void PackMapPoints(const std::vector<MapPoint*>& vpMP, std::map<KeyFrame*, int>& kfIdx, PackedWindow& W) {
+    W.begin.push_back(0);
+    for (MapPoint* pMP : vpMP) {
+        if (pMP->isBad()) continue;
+        const size_t e0 = W.obsKF.size();
+        for (auto& mit : pMP->GetObservations()) {
+            KeyFrame* pKF = mit.first;
+            if (pKF->isBad() || !kfIdx.count(pKF)) continue;       // "|| pKF->mnId > maxKFid"
+            if (pKF->mvuRight[mit.second] >= 0) continue;          // stereo: not supported here
+            const KeyPoint& kpUn = pKF->mvKeysUn[mit.second];
+            W.obsKF.push_back(kfIdx[pKF]);
+            W.uv.push_back(kpUn.pt.x); W.uv.push_back(kpUn.pt.y);
+            W.w.push_back(pKF->mvInvLevelSigma2[kpUn.octave]);
+            W.vEdgeKF.push_back(pKF);
+            W.vEdgeMP.push_back(pMP);
+            W.P.K[0] = pKF->fx; W.P.K[1] = pKF->fy; W.P.K[2] = pKF->cx; W.P.K[3] = pKF->cy;
+        }
+        if (W.obsKF.size() == e0) continue;                        // nEdges == 0: vbNotIncludedMP, vertex removed
+        double Pw[3];
+        pMP->GetWorldPos(Pw);
+        W.pt.insert(W.pt.end(), {Pw[0], Pw[1], Pw[2]});
+        W.ref.push_back(0);
+        W.vMP.push_back(pMP);
+        W.begin.push_back((int32_t)W.obsKF.size());
+    }
+}
+
+bool RunGlobal(PackedWindow& W, bool* pbStopFlag, const char* who) {
+    void* h = handle();
+    if (!h) { std::cerr << who << ": no HIP device, global BA skipped (the backend has no CPU path)" << std::endl; return false; }
+    StopMirror stop(pbStopFlag);
+    if (vba_solve(h, &W.P, &W.R, pbStopFlag ? stop.ptr() : nullptr) != 0) {
+        std::cerr << who << ": " << vba_last_error(h) << std::endl;
+        return false;
+    }
+    return true;  // a raised stop flag leaves the estimates untouched; the reference still writes them back
+}
+
+void WriteBackMapPoints(PackedWindow& W, const unsigned long nLoopKF) {   // :915-931 / :3583-3604
+    for (size_t p = 0; p < W.vMP.size(); p++) {
+        const float Pw[3] = {(float)W.pt[3 * p], (float)W.pt[3 * p + 1], (float)W.pt[3 * p + 2]};
+        if (nLoopKF == 0) {
+            W.vMP[p]->SetWorldPos(Pw);
+            W.vMP[p]->UpdateNormalAndDepth();
+        } else {
+            for (int i = 0; i < 3; i++) W.vMP[p]->mPosGBA[i] = Pw[i];
+            W.vMP[p]->mnBAGlobalForKF = nLoopKF;
+        }
+    }
+}
+}  // namespace
+
+bool Optimizer::PackGlobalBundleAdjustmentNavStatePRV(Map* pMap, const Vector3d& gw, int nIterations, bool bRobust, PackedWindow& W) {
+    W = PackedWindow();
+    std::memset(&W.P, 0, sizeof W.P);
+    std::map<KeyFrame*, int> kfIdx;
+    for (KeyFrame* pKF : pMap->GetAllKeyFrames()) {                                                               // :661-690
+        if (pKF->isBad()) continue;
+        kfIdx[pKF] = (int)W.vKF.size();
+        W.vKF.push_back(pKF);
+        const NavState& ns = pKF->GetNavState();
+        const Vector3d P = ns.Get_P(), V = ns.Get_V(), bg = ns.Get_BiasGyr(), ba = ns.Get_BiasAcc(), dbg = ns.Get_dBias_Gyr(), dba = ns.Get_dBias_Acc();
+        const Quaterniond q = ns.Get_R();
+        W.pose.insert(W.pose.end(), {P[0], P[1], P[2], q[0], q[1], q[2], q[3]});
+        W.vel.insert(W.vel.end(), {V[0], V[1], V[2]});
+        W.bias.insert(W.bias.end(), {bg[0], bg[1], bg[2], ba[0], ba[1], ba[2], dbg[0], dbg[1], dbg[2], dba[0], dba[1], dba[2]});
+        W.kfFix.push_back(pKF->mnId == 0 ? 0x5 : 0x0);   // PR and Bias of keyframe 0 fixed, its V free (:667-685)
+    }
+    if (W.vKF.empty()) return false;
+    W.P.n_kf_free = (int32_t)W.vKF.size();
+    for (KeyFrame* pKF1 : W.vKF) {                                                                                // :700-770
+        KeyFrame* pKF0 = pKF1->GetPrevKeyFrame();
+        if (!pKF0 || !kfIdx.count(pKF0)) continue;
+        const IMUPreintegrator& pre = pKF1->GetIMUPreInt();
+        double info[81];
+        if (!PRVInformation(pre.getCovPVPhi(), info)) continue;
+        W.imuI.push_back(kfIdx[pKF0]);
+        W.imuJ.push_back(kfIdx[pKF1]);
+        W.meas.push_back(pre.getDeltaTime());
+        for (double v : pre.getDeltaP()) W.meas.push_back(v);
+        for (double v : pre.getDeltaV()) W.meas.push_back(v);
+        for (double v : pre.getDeltaR()) W.meas.push_back(v);
+        for (double v : pre.getJPBiasg()) W.meas.push_back(v);
+        for (double v : pre.getJPBiasa()) W.meas.push_back(v);
+        for (double v : pre.getJVBiasg()) W.meas.push_back(v);
+        for (double v : pre.getJVBiasa()) W.meas.push_back(v);
+        for (double v : pre.getJRBiasg()) W.meas.push_back(v);
+        W.info.insert(W.info.end(), info, info + 81);
+    }
+    PackMapPoints(pMap->GetAllMapPoints(), kfIdx, W);
+    W.P.variant = VBA_VARIANT_PRV_XYZ;
+    W.P.algo = VBA_ALGO_LM;                                                                                       // :652
+    Matrix3d Rcb; Vector3d tcb;
+    ConfigParam::GetEigT_cb(Rcb, tcb);
+    const Quaterniond qcb = MatrixToQuat(Rcb.data());
+    for (int i = 0; i < 3; i++) { W.P.T_cb[i] = tcb[i]; W.P.g_w[i] = gw[i]; }
+    for (int i = 0; i < 4; i++) W.P.T_cb[3 + i] = qcb[i];
+    W.P.depth_min = 0.0;
+    FinishProblem(W);
+    W.P.protocol = VBA_PROTO_SINGLE;
+    W.P.robust = bRobust ? 1 : 0;
+    W.P.its_stage1 = nIterations; W.P.its_stage2 = 0;                                                             // :836
+    W.P.huber_vis = (double)(float)std::sqrt(5.99);                                                               // thHuber2D, :773
+    W.P.kf_fix = W.kfFix.data();
+    return true;
+}
+
+void Optimizer::GlobalBundleAdjustmentNavStatePRV(Map* pMap, const Vector3d& gw, int nIterations, bool* pbStopFlag,
+                                                  const unsigned long nLoopKF, const bool bRobust) {
+    PackedWindow& W = t_last;
+    if (!PackGlobalBundleAdjustmentNavStatePRV(pMap, gw, nIterations, bRobust, W)) return;
+    if (!RunGlobal(W, pbStopFlag, "GlobalBundleAdjustmentNavStatePRV")) return;
+    for (size_t i = 0; i < W.vKF.size(); i++) {                                                                   // :842-893
+        KeyFrame* pKF = W.vKF[i];
+        NavState ns = pKF->GetNavState();
+        ns.Set_Pos({{W.pose[7 * i], W.pose[7 * i + 1], W.pose[7 * i + 2]}});
+        ns.Set_Rot({{W.pose[7 * i + 3], W.pose[7 * i + 4], W.pose[7 * i + 5], W.pose[7 * i + 6]}});
+        ns.Set_Vel({{W.vel[3 * i], W.vel[3 * i + 1], W.vel[3 * i + 2]}});
+        ns.Set_DeltaBiasGyr({{W.bias[12 * i + 6], W.bias[12 * i + 7], W.bias[12 * i + 8]}});
+        ns.Set_DeltaBiasAcc({{W.bias[12 * i + 9], W.bias[12 * i + 10], W.bias[12 * i + 11]}});
+        if (nLoopKF == 0) {
+            pKF->SetNavState(ns);
+            pKF->UpdatePoseFromNS();
+        } else {   // the map kept growing meanwhile: results parked for LoopClosing to propagate (:873-891)
+            KeyFrame tmp;
+            tmp.SetNavState(ns);
+            tmp.UpdatePoseFromNS();          // same float32 chain: Twb * Tbc, inverted
+            pKF->mNavStateGBA = ns;
+            pKF->mTcwGBA = tmp.GetPose();
+            pKF->mnBAGlobalForKF = nLoopKF;
+        }
+    }
+    WriteBackMapPoints(W, nLoopKF);
+}
+
+bool Optimizer::PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations,
+                                     bool bRobust, PackedWindow& W) {
+    W = PackedWindow();
+    std::memset(&W.P, 0, sizeof W.P);
+    std::map<KeyFrame*, int> kfIdx;
+    std::vector<KeyFrame*> fixed;
+    for (KeyFrame* pKF : vpKFs) {                                                                                 // :3400-3412
+        if (pKF->isBad()) continue;
+        if (pKF->mnId == 0) { fixed.push_back(pKF); continue; }   // vSE3->setFixed(pKF->mnId == 0)
+        kfIdx[pKF] = (int)W.vKF.size();
+        W.vKF.push_back(pKF);
+    }
+    W.P.n_kf_free = (int32_t)W.vKF.size();
+    for (KeyFrame* k : fixed) { kfIdx[k] = (int)W.vKF.size(); W.vKF.push_back(k); }
+    if (W.P.n_kf_free == 0) return false;
+    for (KeyFrame* k : W.vKF) {  // Converter::toSE3Quat(pKF->GetPose())
+        double R[9], t[3];
+        k->GetRotation(R);
+        k->GetTranslation(t);
+        Quaterniond q = MatrixToQuat(R);
+        if (q[3] < 0) for (auto& v : q) v = -v;
+        W.pose.insert(W.pose.end(), {t[0], t[1], t[2], q[0], q[1], q[2], q[3]});
+        W.vel.insert(W.vel.end(), {0, 0, 0});
+        W.bias.insert(W.bias.end(), 12, 0.0);
+    }
+    PackMapPoints(vpMP, kfIdx, W);
+    W.P.variant = VBA_VARIANT_SE3_XYZ;
+    W.P.algo = VBA_ALGO_LM;                                                                                       // :3393
+    W.P.T_cb[6] = 1.0;
+    W.P.depth_min = 0.0;
+    FinishProblem(W);
+    W.P.protocol = VBA_PROTO_SINGLE;
+    W.P.robust = bRobust ? 1 : 0;
+    W.P.its_stage1 = nIterations; W.P.its_stage2 = 0;                                                             // :3518
+    W.P.huber_vis = (double)(float)std::sqrt(5.99);                                                               // thHuber2D, :3414
+    return true;
+}
+
+void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations,
+                                 bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {
+    PackedWindow& W = t_last;
+    if (!PackBundleAdjustment(vpKFs, vpMP, nIterations, bRobust, W)) return;
+    if (!RunGlobal(W, pbStopFlag, "BundleAdjustment")) return;
+    for (int i = 0; i < W.P.n_kf_free; i++) {                                                                     // :3521-3541, Converter::toCvMat(SE3Quat)
+        const Matrix3d R = QuatToMatrix({{W.pose[7 * i + 3], W.pose[7 * i + 4], W.pose[7 * i + 5], W.pose[7 * i + 6]}});
+        Mat4f T{};
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) T[4 * r + c] = (float)R[3 * r + c];
+            T[4 * r + 3] = (float)W.pose[7 * i + r];
+        }
+        T[15] = 1.0f;
+        if (nLoopKF == 0) W.vKF[i]->SetPose(T);
+        else { W.vKF[i]->mTcwGBA = T; W.vKF[i]->mnBAGlobalForKF = nLoopKF; }
+    }
+    // the fixed keyframe is written back too in the reference (its estimate did not move): a float32 round trip
+    WriteBackMapPoints(W, nLoopKF);
+}
+
+void Optimizer::GlobalBundleAdjustment(Map* pMap, int nIterations, bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {
+    BundleAdjustment(pMap->GetAllKeyFrames(), pMap->GetAllMapPoints(), nIterations, pbStopFlag, nLoopKF, bRobust);   // :3346-3354
+}
+
 }  // namespace ORB_SLAM2

@@ -23,7 +23,7 @@ struct PackedWindow {
     std::vector<KeyFrame*> vEdgeKF;      // per observation edge
     std::vector<MapPoint*> vEdgeMP;
     std::vector<double> refXY;           // variant 2: normalised reference pixel per landmark
-    std::vector<uint8_t> outlier;
+    std::vector<uint8_t> outlier, kfFix;
     std::vector<double> chi2;
     vba_result R;
 };
@@ -35,6 +35,18 @@ public:
                               const Vector3d& gw, LocalMapping* pLM = NULL);
     // include/Optimizer.h:74
     static void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, LocalMapping* pLM = NULL);
+
+    // include/Optimizer.h:33-35, :62-68: global bundle adjustment.  Monocular observations only, as
+    // everywhere in this backend (the reference's VI variant prints "Stereo not supported", src/Optimizer.cpp:819).
+    static void GlobalBundleAdjustmentNavStatePRV(Map* pMap, const Vector3d& gw, int nIterations, bool* pbStopFlag,
+                                                  const unsigned long nLoopKF, const bool bRobust);
+    static void GlobalBundleAdjustment(Map* pMap, int nIterations = 5, bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0,
+                                       const bool bRobust = true);
+    static void BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations = 5,
+                                 bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true);
+    static bool PackGlobalBundleAdjustmentNavStatePRV(Map* pMap, const Vector3d& gw, int nIterations, bool bRobust, PackedWindow& W);
+    static bool PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations,
+                                     bool bRobust, PackedWindow& W);
 
     // graph extraction only (what the two entry points hand to vba_solve); exposed for tests
     static bool PackLocalBAPRVIDP(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw, PackedWindow& W);

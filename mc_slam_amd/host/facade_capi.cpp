@@ -115,6 +115,49 @@ int fc_local_ba_vision(void* m, long cur, int stop) {
     Optimizer::LocalBundleAdjustment(M->kfs.at(cur).get(), &bstop, &M->map, &M->lm);
     return 0;
 }
+static void fill_map(FcMap* M) {
+    M->map.mspKeyFrames.clear(); M->map.mspMapPoints.clear();
+    for (auto& k : M->kfs) M->map.mspKeyFrames.push_back(k.second.get());
+    for (auto& p : M->mps) M->map.mspMapPoints.push_back(p.second.get());
+}
+// mode 0: run; 1: extraction only (no GPU needed)
+int fc_global_ba_prv(void* m, const double* gw, int nIterations, long nLoopKF, int bRobust, int stop, int mode) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    fill_map(M);
+    bool bstop = stop != 0;
+    const Vector3d g{{gw[0], gw[1], gw[2]}};
+    if (mode == 1) return Optimizer::PackGlobalBundleAdjustmentNavStatePRV(&M->map, g, nIterations, bRobust != 0, Optimizer::LastWindowMutable()) ? 0 : -1;
+    Optimizer::GlobalBundleAdjustmentNavStatePRV(&M->map, g, nIterations, &bstop, (unsigned long)nLoopKF, bRobust != 0);
+    return 0;
+}
+int fc_global_ba_vision(void* m, int nIterations, long nLoopKF, int bRobust, int stop, int mode) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    fill_map(M);
+    bool bstop = stop != 0;
+    if (mode == 1) return Optimizer::PackBundleAdjustment(M->map.GetAllKeyFrames(), M->map.GetAllMapPoints(), nIterations, bRobust != 0, Optimizer::LastWindowMutable()) ? 0 : -1;
+    Optimizer::GlobalBundleAdjustment(&M->map, nIterations, &bstop, (unsigned long)nLoopKF, bRobust != 0);
+    return 0;
+}
+int fc_get_gba(void* m, long id, double* nav22, float* T16, long* nLoop) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    KeyFrame* k = M->kfs.at(id).get();
+    const NavState& ns = k->mNavStateGBA;
+    const Vector3d P = ns.Get_P(), V = ns.Get_V(), bg = ns.Get_BiasGyr(), ba = ns.Get_BiasAcc(), dbg = ns.Get_dBias_Gyr(), dba = ns.Get_dBias_Acc();
+    const Quaterniond q = ns.Get_R();
+    const double v[22] = {P[0], P[1], P[2], q[0], q[1], q[2], q[3], V[0], V[1], V[2], bg[0], bg[1], bg[2], ba[0], ba[1], ba[2],
+                          dbg[0], dbg[1], dbg[2], dba[0], dba[1], dba[2]};
+    std::memcpy(nav22, v, sizeof v);
+    std::memcpy(T16, k->mTcwGBA.data(), 64);
+    *nLoop = (long)k->mnBAGlobalForKF;
+    return 0;
+}
+int fc_get_mappoint_gba(void* m, long id, float* Pw, long* nLoop) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    MapPoint* p = M->mps.at(id).get();
+    std::memcpy(Pw, p->mPosGBA, 12);
+    *nLoop = (long)p->mnBAGlobalForKF;
+    return 0;
+}
 int fc_get_nav(void* m, long id, double* nav22, float* T16) {
     FcMap* M = reinterpret_cast<FcMap*>(m);
     KeyFrame* k = M->kfs.at(id).get();

@@ -110,6 +110,10 @@ typedef std::map<KeyFrame*, size_t, cmpKeyFrameId> mapMapPointObs;
 class Map {
 public:
     std::mutex mMutexMapUpdate;  // include/Map.h:72
+    std::vector<KeyFrame*> GetAllKeyFrames() { return mspKeyFrames; }    // include/Map.h:44 (a std::set there: id order)
+    std::vector<MapPoint*> GetAllMapPoints() { return mspMapPoints; }    // include/Map.h:45
+    std::vector<KeyFrame*> mspKeyFrames;
+    std::vector<MapPoint*> mspMapPoints;
 };
 
 class LocalMapping {
@@ -131,6 +135,7 @@ public:
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
     KeyFrame* GetPrevKeyFrame() { return mpPrevKeyFrame; }
     const NavState& GetNavState() { return mNavState; }
+    void SetNavState(const NavState& ns) { mNavState = ns; }
     const IMUPreintegrator& GetIMUPreInt() { return mIMUPreInt; }
     bool isBad() { return mbBad; }
     // float32 camera pose T_cw, kept in sync by UpdatePoseFromNS / SetPose (src/KeyFrame.cpp:96-114)
@@ -190,6 +195,10 @@ public:
     IMUPreintegrator mIMUPreInt;
     bool mbBad = false;
     Mat4f Tcw{};
+    // results of a global BA that runs while the map keeps growing (include/KeyFrame.h:180-186)
+    NavState mNavStateGBA;
+    Mat4f mTcwGBA{};
+    long unsigned int mnBAGlobalForKF = 0;
 };
 
 class MapPoint {
@@ -210,6 +219,8 @@ public:
     float mWorldPos[3] = {0, 0, 0};
     bool mbBad = false;
     int nNormalUpdates = 0;
+    float mPosGBA[3] = {0, 0, 0};          // include/MapPoint.h:90-91
+    long unsigned int mnBAGlobalForKF = 0;
 };
 
 inline bool cmpKeyFrameId::operator()(const KeyFrame* a, const KeyFrame* b) const { return a->mnId < b->mnId; }

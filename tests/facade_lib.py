@@ -30,6 +30,10 @@ def lib():
         l.fc_add_observation.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_float, C.c_float, C.c_int]
         l.fc_local_ba_prvidp.argtypes = [C.c_void_p, _pl, C.c_int, _pd, C.c_int, C.c_int]
         l.fc_local_ba_vision.argtypes = [C.c_void_p, C.c_long, C.c_int]
+        l.fc_global_ba_prv.argtypes = [C.c_void_p, _pd, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int]
+        l.fc_global_ba_vision.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int]
+        l.fc_get_gba.argtypes = [C.c_void_p, C.c_long, _pd, _pf, _pl]
+        l.fc_get_mappoint_gba.argtypes = [C.c_void_p, C.c_long, _pf, _pl]
         l.fc_get_nav.argtypes = [C.c_void_p, C.c_long, _pd, _pf]
         l.fc_get_mappoint.argtypes = [C.c_void_p, C.c_long, _pf, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         l.fc_map_updated.argtypes = [C.c_void_p]
@@ -118,6 +122,22 @@ class FacadeMap:
         ids = self.window_ids()
         return self.L.fc_local_ba_prvidp(self.m, ids.ctypes.data_as(_pl), len(ids), _d(self.p.g_w), stop, 1 if extract_only else 0)
 
+    def global_ba_prv(self, n_it=20, loop_kf=0, robust=True, stop=0, extract_only=False):
+        return self.L.fc_global_ba_prv(self.m, _d(self.p.g_w), n_it, loop_kf, int(robust), stop, 1 if extract_only else 0)
+
+    def global_ba_vision(self, n_it=20, loop_kf=0, robust=True, stop=0, extract_only=False):
+        return self.L.fc_global_ba_vision(self.m, n_it, loop_kf, int(robust), stop, 1 if extract_only else 0)
+
+    def gba(self, kf_id):
+        nav = np.zeros(22); T = np.zeros(16, dtype=np.float32); n = C.c_long(0)
+        self.L.fc_get_gba(self.m, kf_id, nav.ctypes.data_as(_pd), T.ctypes.data_as(_pf), C.byref(n))
+        return nav, T.reshape(4, 4), n.value
+
+    def mappoint_gba(self, q):
+        Pw = np.zeros(3, dtype=np.float32); n = C.c_long(0)
+        self.L.fc_get_mappoint_gba(self.m, q, Pw.ctypes.data_as(_pf), C.byref(n))
+        return Pw, n.value
+
     def local_ba_vision(self, stop=0):
         p = self.p
         free = sorted(self.tidx[i] for i in range(p.n_kf_free))
@@ -151,5 +171,6 @@ def last_problem() -> abi.Problem:
         T_cb=np.array(s.T_cb[:]), g_w=np.array(s.g_w[:]), imu_kf_i=arr(s.imu_kf_i, s.n_imu, np.int32),
         imu_kf_j=arr(s.imu_kf_j, s.n_imu, np.int32), imu_meas=arr(s.imu_meas, 61 * s.n_imu), imu_info_prv=arr(s.imu_info_prv, 81 * s.n_imu),
         algo=s.algo, its_stage1=s.its_stage1, its_stage2=s.its_stage2, chi2_th=s.chi2_th, depth_min=s.depth_min, rho_min=s.rho_min,
-        huber_vis=s.huber_vis, huber_prv=s.huber_prv, huber_bias=s.huber_bias)
+        huber_vis=s.huber_vis, huber_prv=s.huber_prv, huber_bias=s.huber_bias, protocol=s.protocol, robust=s.robust,
+        kf_fix=(np.ctypeslib.as_array(s.kf_fix, shape=(s.n_kf,)).copy() if s.kf_fix else None))
     return pr

@@ -155,3 +155,92 @@ def _reordered(p, fm, order):
         begin.append(len(okf)); pts.append(np.float32(p.pt[q]).astype(np.float64))
     return abi.Problem(variant=0, n_kf_free=len(order), kf_pose=np.array(pose), pt=np.array(pts), pt_obs_begin=begin, obs_kf=okf,
                        obs_uv=np.array(ouv), obs_w=ow, K=np.float32(p.K).astype(np.float64), algo=abi.ALGO_LM, depth_min=0.0)
+
+
+# ---- global bundle adjustment through the facade ----
+def _gmap(variant):
+    return synth.make_window(variant, algo=abi.ALGO_LM, n_kf=10, n_fixed=0 if variant == abi.VARIANT_PRV_XYZ else 1,
+                             n_pt=300, n_obs=1800, seed=63, outlier_frac=0.02)
+
+
+def test_global_ba_extraction():
+    p = _gmap(abi.VARIANT_PRV_XYZ)
+    fm = facade.FacadeMap(p)
+    assert fm.global_ba_prv(n_it=20, robust=False, extract_only=True) == 0
+    e = facade.last_problem()
+    assert (e.variant, e.algo, e.protocol, e.robust, e.its_stage1, e.its_stage2) == (1, abi.ALGO_LM, abi.PROTO_SINGLE, 0, 20, 0)
+    assert e.n_kf_free == e.n_kf == p.n_kf and e.n_imu == p.n_kf - 1 and e.n_pt == p.n_pt and e.n_obs == p.n_obs
+    assert list(e.kf_fix) == [5] + [0] * (p.n_kf - 1)       # mnId 0: PR and Bias fixed, V free
+    assert e.huber_vis == float(np.float32(np.sqrt(5.99)))
+    _mp, kf_ids = facade.last_ids()
+    assert list(kf_ids) == list(range(p.n_kf))             # id order
+    rows = [list(fm.tidx).index(t) for t in kf_ids]
+    np.testing.assert_array_equal(e.kf_pose, p.kf_pose[rows])
+    np.testing.assert_array_equal(e.kf_vel, p.kf_vel[rows])
+    np.testing.assert_allclose(e.pt, p.pt.astype(np.float32), rtol=0, atol=0)   # MapPoint positions are float32 in the map
+    fm.close()
+    # vision-only: keyframe 0 goes to the fixed rows
+    p = _gmap(abi.VARIANT_SE3_XYZ)
+    fm = facade.FacadeMap(p)
+    assert fm.global_ba_vision(n_it=10, extract_only=True) == 0
+    e = facade.last_problem()
+    _mp, kf_ids = facade.last_ids()
+    assert (e.variant, e.protocol, e.robust, e.its_stage1) == (0, abi.PROTO_SINGLE, 1, 10)
+    assert e.n_kf_free == p.n_kf - 1 and kf_ids[-1] == 0 and e.kf_fix is None
+    fm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loop_kf", [0, 7])
+def test_facade_global_ba_prv_equals_direct_solve(loop_kf):
+    from mc_slam_amd import backend
+    p = _gmap(abi.VARIANT_PRV_XYZ)
+    fm = facade.FacadeMap(p)
+    fm.global_ba_prv(n_it=12, robust=True, extract_only=True)
+    e = facade.last_problem()
+    ba = backend.LocalBA(0)
+    q, r = ba.solve(e)
+    ba.close()
+    assert r.status == 0 and r.its_done[0] >= 2
+    before = [fm.nav(t)[0].copy() for t in range(p.n_kf)]
+    fm.global_ba_prv(n_it=12, loop_kf=loop_kf, robust=True)
+    for i in range(p.n_kf):
+        live, T = fm.nav(i)
+        parked, Tg, n = fm.gba(i)
+        got, Tgot = (live, T) if loop_kf == 0 else (parked, Tg)
+        assert (got[:7] == q.kf_pose[i]).all() and (got[7:10] == q.kf_vel[i]).all() and (got[16:22] == q.kf_bias[i, 6:]).all()
+        Rwb = synth.quat_to_rot(got[3:7]); R_bc, p_bc = p.truth["R_bc"], p.truth["p_bc"]
+        Rcw = (Rwb @ R_bc).T
+        np.testing.assert_allclose(Tgot[:3, :3], Rcw, atol=2e-6)
+        np.testing.assert_allclose(Tgot[:3, 3], -Rcw @ (Rwb @ p_bc + got[:3]), atol=2e-5)
+        if loop_kf:   # the live map is untouched, results parked with the loop keyframe id (src/Optimizer.cpp:873-891)
+            assert (live == before[i]).all() and n == loop_kf
+    mp_ids, _kf = facade.last_ids()
+    for j in range(0, len(mp_ids), 13):
+        Pw, _n, upd = fm.mappoint(int(mp_ids[j]))
+        Pg, n = fm.mappoint_gba(int(mp_ids[j]))
+        if loop_kf == 0:
+            assert upd == 1 and (Pw == q.pt[j].astype(np.float32)).all()
+        else:
+            assert upd == 0 and n == loop_kf and (Pg == q.pt[j].astype(np.float32)).all()
+    fm.close()
+
+
+@pytest.mark.gpu
+def test_facade_global_ba_vision_equals_direct_solve():
+    from mc_slam_amd import backend
+    p = _gmap(abi.VARIANT_SE3_XYZ)
+    fm = facade.FacadeMap(p)
+    fm.global_ba_vision(n_it=10, robust=True, extract_only=True)
+    e = facade.last_problem()
+    ba = backend.LocalBA(0)
+    q, r = ba.solve(e)
+    ba.close()
+    fm.global_ba_vision(n_it=10, robust=True)
+    res = facade.lib().fc_last_result().contents
+    assert tuple(res.its_done) == r.its_done and r.its_done[1] == 0
+    _mp, kf_ids = facade.last_ids()
+    for row in range(e.n_kf_free):
+        T = fm.pose_tcw(int(kf_ids[row]))
+        np.testing.assert_array_equal(T[:3, 3], q.kf_pose[row, :3].astype(np.float32))
+    fm.close()
