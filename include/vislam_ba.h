@@ -147,6 +147,46 @@ int vba_preintegrate(void *handle, int32_t n_edges, const int32_t *sample_begin,
                      const double *dt, double gyr_meas_cov, double acc_meas_cov, double *imu_meas, double *cov_pvphi,
                      double *imu_info_prv);
 
+/* ---- IMU-aided per-frame pose optimisation ----
+ * Optimizer::PoseOptimization(Frame*, KeyFrame* pLastKF, IMUPreintegrator, gw, bComputeMarg)   src/Optimizer.cpp:2046-2317
+ * Optimizer::PoseOptimization(Frame*, Frame*   pLastFrame, IMUPreintegrator, gw, bComputeMarg) src/Optimizer.cpp:1671-2044
+ * Everything between the vertex set-up and the write-back: the four optimize(10) rounds of Levenberg-Marquardt on the
+ * 15- or 30-dimensional system, the chi2 > 5.991 reclassification after every round, the kernel removal after the third,
+ * and computeMarginals.  One call solves a batch of independent frames (one workgroup per frame). */
+#define VBA_NAV_STRIDE 22 /* NavState: P(3) q(4, xyzw) V(3) bg(3) ba(3) dbg(3) dba(3)   src/IMU/NavState.h:124-138 */
+typedef struct vba_frame_problem {
+    int32_t last_is_frame;  /* 0: last keyframe, fixed (:2082-2097).  1: last frame, free, tied to its marginal prior (:1710-1747) */
+    int32_t compute_marg;   /* bComputeMarg */
+    int32_t n_obs;          /* monocular correspondences of the frame (mvpMapPoints[i] != NULL, mvuRight[i] < 0) */
+    int32_t n_obs_last;     /* those of the last frame (last_is_frame only) */
+    double nav[VBA_NAV_STRIDE];      /* in: pFrame->GetNavState(); out: the optimised state (P, R, V, dbg, dba change) */
+    double nav_last[VBA_NAV_STRIDE]; /* pLastKF / pLastFrame NavState; never written back by the reference */
+    const double *obs_pw;   /* [n_obs][3] MapPoint world positions */
+    const double *obs_uv;   /* [n_obs][2] undistorted keypoints */
+    const double *obs_w;    /* [n_obs] invSigma2 */
+    const double *last_pw, *last_uv, *last_w; /* the same for the last frame */
+    double K[4];            /* fx fy cx cy */
+    double T_cb[7];         /* as in vba_problem */
+    double g_w[3];
+    double imu_meas[VBA_IMU_MEAS_STRIDE]; /* imupreint (last -> current) */
+    double imu_cov_pvphi[81];             /* its covariance; information of EdgeNavStatePVR = inverse, same P,V,phi order */
+    double prior_nav[VBA_NAV_STRIDE];     /* pLastFrame->mNavStatePrior (last_is_frame) */
+    double prior_info[225];               /* pLastFrame->mMargCovInv, row-major 15x15, order P V phi bg ba */
+    double inv_bg_rw2, inv_ba_rw2;
+} vba_frame_problem;
+
+typedef struct vba_frame_result {
+    int32_t n_inliers;      /* the function's return value: nInitialCorrespondences - nBad (0 if fewer than 3 correspondences) */
+    int32_t status;         /* VBA_OK */
+    int32_t its_done[4];    /* LM iterations of each round */
+    uint8_t *outlier;       /* [n_obs] caller-allocated: pFrame->mvbOutlier */
+    uint8_t *outlier_last;  /* [n_obs_last] caller-allocated or NULL: pLastFrame->mvbOutlier */
+    double chi2_round[4];   /* activeRobustChi2 at the end of each round (diagnostic) */
+    double marg_cov_inv[225]; /* pFrame->mMargCovInv when compute_marg (pFrame->mNavStatePrior = the returned nav) */
+} vba_frame_result;
+
+int vba_pose_optimize(void *handle, int32_t n_frames, vba_frame_problem *const *inout, vba_frame_result *const *out);
+
 int vba_set_profile(void *handle, int32_t enable);
 int vba_get_profile(void *handle, vba_profile *out);
 

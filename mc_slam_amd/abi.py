@@ -202,3 +202,109 @@ class ResultBuf:
         return Result(s.chi2_vis, s.chi2_prv, s.chi2_bias, (s.its_done[0], s.its_done[1]), s.n_outliers, s.status,
                       self.outlier[:self.n_obs].copy(), self.chi2[:self.n_obs].copy(),
                       np.array(s.chi2_trace[:s.n_trace]), s.lambda_final)
+
+
+# ---- IMU-aided per-frame pose optimisation (include/vislam_ba.h: vba_frame_problem / vba_frame_result) ----
+NAV_STRIDE = 22
+
+
+class vba_frame_problem(C.Structure):
+    _fields_ = [
+        ("last_is_frame", C.c_int32), ("compute_marg", C.c_int32), ("n_obs", C.c_int32), ("n_obs_last", C.c_int32),
+        ("nav", C.c_double * NAV_STRIDE), ("nav_last", C.c_double * NAV_STRIDE),
+        ("obs_pw", _pd), ("obs_uv", _pd), ("obs_w", _pd), ("last_pw", _pd), ("last_uv", _pd), ("last_w", _pd),
+        ("K", C.c_double * 4), ("T_cb", C.c_double * 7), ("g_w", C.c_double * 3),
+        ("imu_meas", C.c_double * IMU_MEAS_STRIDE), ("imu_cov_pvphi", C.c_double * 81),
+        ("prior_nav", C.c_double * NAV_STRIDE), ("prior_info", C.c_double * 225),
+        ("inv_bg_rw2", C.c_double), ("inv_ba_rw2", C.c_double),
+    ]
+
+
+class vba_frame_result(C.Structure):
+    _fields_ = [
+        ("n_inliers", C.c_int32), ("status", C.c_int32), ("its_done", C.c_int32 * 4),
+        ("outlier", _pu8), ("outlier_last", _pu8), ("chi2_round", C.c_double * 4), ("marg_cov_inv", C.c_double * 225),
+    ]
+
+
+@dataclass
+class FrameProblem:
+    """One PoseOptimization(Frame*, KeyFrame*|Frame*, IMUPreintegrator, gw, bComputeMarg) call as flat arrays."""
+    nav: np.ndarray
+    nav_last: np.ndarray
+    obs_pw: np.ndarray
+    obs_uv: np.ndarray
+    obs_w: np.ndarray
+    K: np.ndarray
+    T_cb: np.ndarray
+    g_w: np.ndarray
+    imu_meas: np.ndarray
+    imu_cov_pvphi: np.ndarray
+    last_is_frame: int = 0
+    compute_marg: int = 1
+    last_pw: Optional[np.ndarray] = None
+    last_uv: Optional[np.ndarray] = None
+    last_w: Optional[np.ndarray] = None
+    prior_nav: Optional[np.ndarray] = None
+    prior_info: Optional[np.ndarray] = None
+    truth: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        self.nav = _f64(self.nav); self.nav_last = _f64(self.nav_last)
+        self.obs_pw = _f64(self.obs_pw, (-1, 3)); self.obs_uv = _f64(self.obs_uv, (-1, 2)); self.obs_w = _f64(self.obs_w)
+        self.last_pw = _f64(self.last_pw if self.last_pw is not None else np.zeros((0, 3)), (-1, 3))
+        self.last_uv = _f64(self.last_uv if self.last_uv is not None else np.zeros((0, 2)), (-1, 2))
+        self.last_w = _f64(self.last_w if self.last_w is not None else np.zeros(0))
+        self.prior_nav = _f64(self.prior_nav if self.prior_nav is not None else np.zeros(NAV_STRIDE))
+        self.prior_info = _f64(self.prior_info if self.prior_info is not None else np.zeros((15, 15)), (15, 15))
+        self.K = _f64(self.K); self.T_cb = _f64(self.T_cb); self.g_w = _f64(self.g_w)
+        self.imu_meas = _f64(self.imu_meas); self.imu_cov_pvphi = _f64(self.imu_cov_pvphi, (9, 9))
+
+    n_obs = property(lambda self: self.obs_pw.shape[0])
+    n_obs_last = property(lambda self: self.last_pw.shape[0])
+
+    def copy(self):
+        import copy as _c
+        q = _c.copy(self)
+        q.nav = self.nav.copy()
+        return q
+
+    def as_struct(self) -> vba_frame_problem:
+        s = vba_frame_problem()
+        s.last_is_frame, s.compute_marg, s.n_obs, s.n_obs_last = self.last_is_frame, self.compute_marg, self.n_obs, self.n_obs_last
+        s.nav[:] = self.nav.tolist(); s.nav_last[:] = self.nav_last.tolist()
+        p = lambda a: a.ctypes.data_as(_pd)
+        s.obs_pw, s.obs_uv, s.obs_w = p(self.obs_pw), p(self.obs_uv), p(self.obs_w)
+        s.last_pw, s.last_uv, s.last_w = p(self.last_pw), p(self.last_uv), p(self.last_w)
+        s.K[:] = self.K.tolist(); s.T_cb[:] = self.T_cb.tolist(); s.g_w[:] = self.g_w.tolist()
+        s.imu_meas[:] = self.imu_meas.tolist(); s.imu_cov_pvphi[:] = self.imu_cov_pvphi.reshape(-1).tolist()
+        s.prior_nav[:] = self.prior_nav.tolist(); s.prior_info[:] = self.prior_info.reshape(-1).tolist()
+        s.inv_bg_rw2, s.inv_ba_rw2 = 1.0 / GYR_BIAS_RW2, 1.0 / ACC_BIAS_RW2
+        return s
+
+
+@dataclass
+class FrameResult:
+    n_inliers: int
+    status: int
+    its_done: tuple
+    outlier: np.ndarray
+    outlier_last: np.ndarray
+    chi2_round: np.ndarray
+    marg_cov_inv: np.ndarray
+    nav: np.ndarray
+
+
+class FrameResultBuf:
+    def __init__(self, f: FrameProblem):
+        self.o = np.zeros(max(f.n_obs, 1), dtype=np.uint8)
+        self.ol = np.zeros(max(f.n_obs_last, 1), dtype=np.uint8)
+        self.n, self.nl = f.n_obs, f.n_obs_last
+        self.s = vba_frame_result()
+        self.s.outlier = self.o.ctypes.data_as(_pu8)
+        self.s.outlier_last = self.ol.ctypes.data_as(_pu8)
+
+    def get(self, st: vba_frame_problem) -> FrameResult:
+        s = self.s
+        return FrameResult(s.n_inliers, s.status, tuple(s.its_done), self.o[:self.n].copy(), self.ol[:self.nl].copy(),
+                           np.array(s.chi2_round[:]), np.array(s.marg_cov_inv[:]).reshape(15, 15), np.array(st.nav[:]))

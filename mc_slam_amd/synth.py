@@ -373,3 +373,36 @@ def config_c3(seed=3, n_kf=50, n_pt=5000, n_obs=30000):
 def config_c4(seed=4):
     """Synthetic VI graph: 200 KF / 50k pts / 500k obs + IMU chain."""
     return make_window(abi.VARIANT_PRV_IDP, n_kf=200, n_fixed=1, n_pt=50000, n_obs=500000, seed=seed)
+
+
+def make_frame(seed=5, n_obs=300, last_is_frame=False, compute_marg=True, noise=True, outlier_frac=0.1, pt_noise=0.01):
+    """One tracked frame for the IMU-aided PoseOptimization (src/Optimizer.cpp:1671-2317): the last keyframe / frame,
+    the preintegration up to the current frame, n_obs map points seen by both, a perturbed initial state."""
+    w = make_window(abi.VARIANT_PRV_XYZ, n_kf=3, n_fixed=1, n_pt=n_obs, n_obs=3 * n_obs, seed=seed, noise=noise,
+                    outlier_frac=outlier_frac)
+    rng = np.random.default_rng(seed + 7919)
+    LAST, CUR = 0, 1                     # problem rows of time 1 and time 2
+    k = [i for i in range(w.n_imu) if w.imu_kf_i[i] == LAST and w.imu_kf_j[i] == CUR][0]
+    perm = [0, 1, 2, 6, 7, 8, 3, 4, 5]
+    cov = np.linalg.inv(w.imu_info_prv[k].reshape(9, 9))[np.ix_(perm, perm)]
+    pts = w.truth["pts_w"] + (rng.normal(0, pt_noise, (n_obs, 3)) if noise else 0.0)
+    e_pt = np.repeat(np.arange(w.n_pt), np.diff(w.pt_obs_begin))
+    sel_c, sel_l = w.obs_kf == CUR, w.obs_kf == LAST
+    nav = lambda i: np.concatenate([w.kf_pose[i], w.kf_vel[i], w.kf_bias[i]])
+    gt = w.truth
+    nav_last = nav(LAST)
+    if not last_is_frame:   # the last keyframe is trusted: ground truth pose
+        nav_last[:7] = gt["pose"][LAST]; nav_last[7:10] = gt["vel"][LAST]
+    kw = dict(nav=nav(CUR), nav_last=nav_last, obs_pw=pts[e_pt[sel_c]], obs_uv=w.obs_uv[sel_c], obs_w=w.obs_w[sel_c],
+              K=w.K, T_cb=w.T_cb, g_w=w.g_w, imu_meas=w.imu_meas[k], imu_cov_pvphi=cov,
+              last_is_frame=int(last_is_frame), compute_marg=int(compute_marg))
+    if last_is_frame:
+        sig = np.array([0.02] * 3 + [0.05] * 3 + [0.01] * 3 + [1e-3] * 3 + [1e-2] * 3)
+        L = np.diag(1.0 / sig) + np.tril(rng.normal(0, 0.05, (15, 15)), -1) / sig[None, :]
+        prior = nav_last.copy()
+        prior[:3] = gt["pose"][LAST][:3] + rng.normal(0, 0.01, 3)
+        kw.update(last_pw=pts[e_pt[sel_l]], last_uv=w.obs_uv[sel_l], last_w=w.obs_w[sel_l], prior_nav=prior, prior_info=L.T @ L)
+    f = abi.FrameProblem(**kw)
+    f.truth = dict(nav=np.concatenate([gt["pose"][CUR], gt["vel"][CUR]]), is_outlier=gt["is_outlier"][sel_c],
+                   is_outlier_last=gt["is_outlier"][sel_l])
+    return f

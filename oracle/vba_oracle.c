@@ -1458,3 +1458,439 @@ void vbo_oplus_se3(double *T7, const double *d6) { /* VertexSE3Expmap::oplusImpl
 }
 void vbo_quat_to_R(const double *q, double *R) { quat_to_R(q, R); }
 void vbo_R_to_quat(const double *R, double *q) { R_to_quat(R, q); }
+
+/* =================================================================================================
+ * IMU-aided per-frame pose optimisation: CPU restatement of
+ * Optimizer::PoseOptimization(Frame*, KeyFrame*|Frame*, IMUPreintegrator, gw, bComputeMarg), src/Optimizer.cpp:1671-2317.
+ * Hessian order: [frame PVR (9) | frame Bias (6) | last-frame PVR (9) | last-frame Bias (6)].
+ * ================================================================================================= */
+typedef struct {
+    const vba_frame_problem *F;
+    int n;                   /* 15 or 30 */
+    double cur[22], last[22], cur_bk[22], last_bk[22];
+    unsigned char *lvl, *lvl_last; /* g2o edge level: 1 = outside the active set */
+    double *err, *err_last;  /* stored _error of the mono edges */
+    int vis_robust;
+    double e_pvr[9], e_bias[6], e_prior[15];
+    double info_pvr[81];
+    double H[900], b[30], x[30], Hlast[900];
+} fctx;
+
+/* VertexNavStatePVR::oplusImpl -> NavState::IncSmallPVR (NavState.cpp:81-96); VertexNavStateBias -> IncSmallBias (:100-109) */
+static void nav_oplus(double *nav, const double *dpvr, const double *dbias) {
+    for (int k = 0; k < 3; k++) { nav[k] += dpvr[k]; nav[7 + k] += dpvr[3 + k]; }
+    double dq[4];
+    vbo_so3_exp(dpvr + 6, dq);
+    so3_mul(nav + 3, dq, nav + 3);
+    for (int k = 0; k < 6; k++) nav[16 + k] += dbias[k];
+}
+
+/* EdgeNavStatePVRPointXYZOnlyPose: error (g2otypes.h, computeError) + Jacobian (g2otypes.cpp:792-837), J is 2x9 [P V R] */
+static double frame_mono(const vba_frame_problem *F, const double *nav, const double *Pw, const double *uv, double *e, double *J) {
+    double Rwb[9], Rcb[9], d[3], t1[3], Pc[3];
+    quat_to_R(nav + 3, Rwb);
+    quat_to_R(F->T_cb + 3, Rcb);
+    for (int k = 0; k < 3; k++) d[k] = Pw[k] - nav[k];
+    double RwbT[9];
+    m3_T(Rwb, RwbT);
+    m3_vec(RwbT, d, t1);
+    m3_vec(Rcb, t1, Pc); /* Paux */
+    const double Paux[3] = {Pc[0], Pc[1], Pc[2]};
+    for (int k = 0; k < 3; k++) Pc[k] += F->T_cb[k];
+    const double fx = F->K[0], fy = F->K[1], cx = F->K[2], cy = F->K[3];
+    const double iz = 1.0 / Pc[2];
+    e[0] = uv[0] - (fx * Pc[0] * iz + cx);
+    e[1] = uv[1] - (fy * Pc[1] * iz + cy);
+    if (J) {
+        const double Jpi[6] = {fx * iz, 0, -Pc[0] * iz * fx * iz, 0, fy * iz, -Pc[1] * iz * fy * iz};
+        double M[9], HA[9], HR[9];
+        m3_mul(Rcb, RwbT, M);       /* JdPwb = -Jpi * (-Rcb Rwb^T) = Jpi M */
+        hat(Paux, HA);
+        m3_mul(HA, Rcb, HR);        /* JdRwb = -Jpi * hat(Paux) Rcb */
+        memset(J, 0, 18 * sizeof(double));
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 3; c++) {
+                double s1 = 0, s2 = 0;
+                for (int k = 0; k < 3; k++) { s1 += Jpi[3 * r + k] * M[3 * k + c]; s2 += Jpi[3 * r + k] * HR[3 * k + c]; }
+                J[9 * r + c] = s1;
+                J[9 * r + 6 + c] = -s2;
+            }
+    }
+    return Pc[2];
+}
+
+/* EdgeNavStatePVR::computeError (g2otypes.cpp:529-585): the PRV residual with rows ordered rP, rV, rPhi */
+static void frame_pvr_error(const vba_frame_problem *F, const double *ni, const double *nj, double *e) {
+    double t[9];
+    vbo_edge_prv_error(ni, nj, ni + 7, nj + 7, ni + 10, F->imu_meas, F->g_w, t); /* rP, rPhi, rV */
+    for (int k = 0; k < 3; k++) { e[k] = t[k]; e[3 + k] = t[6 + k]; e[6 + k] = t[3 + k]; }
+}
+/* EdgeNavStatePVR::linearizeOplus (:587-701): Ji, Jj 9x9 (columns P V R), Jb 9x6 */
+static void frame_pvr_jac(const vba_frame_problem *F, const double *ni, const double *nj, const double *e, double *Ji, double *Jj, double *Jb) {
+    double t[9], JPRi[54], JPRj[54], JVi[27], JVj[27], JBi[54];
+    for (int k = 0; k < 3; k++) { t[k] = e[k]; t[6 + k] = e[3 + k]; t[3 + k] = e[6 + k]; }
+    vbo_edge_prv_jac(ni, nj, ni + 7, nj + 7, ni + 10, F->imu_meas, F->g_w, t, JPRi, JPRj, JVi, JVj, JBi);
+    static const int rowmap[9] = {0, 1, 2, 6, 7, 8, 3, 4, 5}; /* PVR row r <- PRV row */
+    for (int r = 0; r < 9; r++) {
+        const int s = rowmap[r];
+        for (int c = 0; c < 3; c++) {
+            Ji[9 * r + c] = JPRi[6 * s + c]; Ji[9 * r + 3 + c] = JVi[3 * s + c]; Ji[9 * r + 6 + c] = JPRi[6 * s + 3 + c];
+            Jj[9 * r + c] = JPRj[6 * s + c]; Jj[9 * r + 3 + c] = JVj[3 * s + c]; Jj[9 * r + 6 + c] = JPRj[6 * s + 3 + c];
+        }
+        for (int c = 0; c < 6; c++) Jb[6 * r + c] = JBi[6 * s + c];
+    }
+}
+/* EdgeNavStatePriorPVRBias::computeError (:839-871) */
+static void frame_prior_error(const vba_frame_problem *F, const double *nl, double *e) {
+    const double *pr = F->prior_nav;
+    for (int k = 0; k < 3; k++) { e[k] = pr[k] - nl[k]; e[3 + k] = pr[7 + k] - nl[7 + k]; }
+    double qi[4], q[4];
+    so3_inv(pr + 3, qi);
+    so3_mul(qi, nl + 3, q);
+    vbo_so3_log(q, e + 6);
+    for (int k = 0; k < 3; k++) {
+        e[9 + k] = (pr[10 + k] + pr[16 + k]) - (nl[10 + k] + nl[16 + k]);
+        e[12 + k] = (pr[13 + k] + pr[19 + k]) - (nl[13 + k] + nl[19 + k]);
+    }
+}
+
+/* computeActiveErrors + activeRobustChi2 */
+static double frame_errors(fctx *c) {
+    const vba_frame_problem *F = c->F;
+    double chi = 0, rho[3];
+    if (F->last_is_frame) {
+        frame_prior_error(F, c->last, c->e_prior);
+        vbo_huber(quadform(c->e_prior, F->prior_info, 15), (double)(float)sqrt(30.5779), rho);
+        chi += rho[0];
+    }
+    frame_pvr_error(F, c->last, c->cur, c->e_pvr);
+    vbo_huber(quadform(c->e_pvr, c->info_pvr, 9), (double)(float)sqrt(21.666), rho);
+    chi += rho[0];
+    vbo_edge_bias_error(c->last + 10, c->cur + 10, c->e_bias);
+    {
+        const double wg = F->inv_bg_rw2 / F->imu_meas[0], wa = F->inv_ba_rw2 / F->imu_meas[0];
+        const double *e = c->e_bias;
+        vbo_huber(wg * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + wa * (e[3] * e[3] + e[4] * e[4] + e[5] * e[5]), (double)(float)sqrt(16.812), rho);
+        chi += rho[0];
+    }
+    const double dm = (double)(float)sqrt(5.991);
+    for (int i = 0; i < F->n_obs; i++) {
+        if (c->lvl[i]) continue;
+        frame_mono(F, c->cur, F->obs_pw + 3 * i, F->obs_uv + 2 * i, c->err + 2 * i, NULL);
+        const double s = chi2_2(c->err + 2 * i, F->obs_w[i]);
+        if (c->vis_robust) { vbo_huber(s, dm, rho); chi += rho[0]; } else chi += s;
+    }
+    if (F->last_is_frame)
+        for (int i = 0; i < F->n_obs_last; i++) {
+            if (c->lvl_last[i]) continue;
+            frame_mono(F, c->last, F->last_pw + 3 * i, F->last_uv + 2 * i, c->err_last + 2 * i, NULL);
+            const double s = chi2_2(c->err_last + 2 * i, F->last_w[i]);
+            if (c->vis_robust) { vbo_huber(s, dm, rho); chi += rho[0]; } else chi += s;
+        }
+    return chi;
+}
+
+static void frame_accum(fctx *c, int d, const double *Om, const double *e, double rw, int nb, const int *col, const int *dim, const double *const *J) {
+    const int n = c->n;
+    double Oe[15];
+    for (int a = 0; a < d; a++) {
+        double s = 0;
+        for (int k = 0; k < d; k++) s += Om[a * d + k] * e[k];
+        Oe[a] = s * rw;
+    }
+    for (int i = 0; i < nb; i++) {
+        if (col[i] < 0) continue;
+        for (int a = 0; a < dim[i]; a++) {
+            double s = 0;
+            for (int k = 0; k < d; k++) s += J[i][k * dim[i] + a] * Oe[k];
+            c->b[col[i] + a] -= s;
+        }
+        for (int j = 0; j < nb; j++) {
+            if (col[j] < 0) continue;
+            for (int a = 0; a < dim[i]; a++)
+                for (int bb = 0; bb < dim[j]; bb++) {
+                    double s = 0;
+                    for (int k = 0; k < d; k++)
+                        for (int l = 0; l < d; l++) s += J[i][k * dim[i] + a] * (rw * Om[k * d + l]) * J[j][l * dim[j] + bb];
+                    c->H[(col[i] + a) * n + col[j] + bb] += s;
+                }
+        }
+    }
+}
+
+static void frame_build(fctx *c) {
+    const vba_frame_problem *F = c->F;
+    const int n = c->n, lf = F->last_is_frame;
+    memset(c->H, 0, sizeof c->H);
+    memset(c->b, 0, sizeof c->b);
+    double rho[3];
+    if (lf) {
+        double J0[135], J1[90], JrI[9];
+        memset(J0, 0, sizeof J0);
+        memset(J1, 0, sizeof J1);
+        vbo_so3_jrinv(c->e_prior + 6, JrI);
+        for (int k = 0; k < 3; k++) { J0[9 * k + k] = -1.0; J0[9 * (3 + k) + 3 + k] = -1.0; }
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++) J0[9 * (6 + r) + 6 + cc] = JrI[3 * r + cc];
+        for (int k = 0; k < 6; k++) J1[6 * (9 + k) + k] = -1.0;
+        vbo_huber(quadform(c->e_prior, F->prior_info, 15), (double)(float)sqrt(30.5779), rho);
+        const int col[2] = {15, 24}, dim[2] = {9, 6};
+        const double *const Js[2] = {J0, J1};
+        frame_accum(c, 15, F->prior_info, c->e_prior, rho[1], 2, col, dim, Js);
+    }
+    {
+        double Ji[81], Jj[81], Jb[54];
+        frame_pvr_jac(F, c->last, c->cur, c->e_pvr, Ji, Jj, Jb);
+        vbo_huber(quadform(c->e_pvr, c->info_pvr, 9), (double)(float)sqrt(21.666), rho);
+        const int col[3] = {lf ? 15 : -1, 0, lf ? 24 : -1}, dim[3] = {9, 9, 6};
+        const double *const Js[3] = {Ji, Jj, Jb};
+        frame_accum(c, 9, c->info_pvr, c->e_pvr, rho[1], 3, col, dim, Js);
+    }
+    {
+        double Om[36], Ji[36], Jj[36];
+        memset(Om, 0, sizeof Om); memset(Ji, 0, sizeof Ji); memset(Jj, 0, sizeof Jj);
+        const double wg = F->inv_bg_rw2 / F->imu_meas[0], wa = F->inv_ba_rw2 / F->imu_meas[0];
+        const double *e = c->e_bias;
+        for (int a = 0; a < 6; a++) { Om[7 * a] = a < 3 ? wg : wa; Ji[7 * a] = -1.0; Jj[7 * a] = 1.0; }
+        vbo_huber(wg * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + wa * (e[3] * e[3] + e[4] * e[4] + e[5] * e[5]), (double)(float)sqrt(16.812), rho);
+        const int col[2] = {lf ? 24 : -1, 9}, dim[2] = {6, 6};
+        const double *const Js[2] = {Ji, Jj};
+        frame_accum(c, 6, Om, e, rho[1], 2, col, dim, Js);
+    }
+    const double dm = (double)(float)sqrt(5.991);
+    for (int pass = 0; pass < (lf ? 2 : 1); pass++) {
+        const int N = pass ? F->n_obs_last : F->n_obs;
+        const unsigned char *lvl = pass ? c->lvl_last : c->lvl;
+        const double *pw = pass ? F->last_pw : F->obs_pw, *uv = pass ? F->last_uv : F->obs_uv, *w = pass ? F->last_w : F->obs_w;
+        const double *nav = pass ? c->last : c->cur;
+        const int c0 = pass ? 15 : 0;
+        for (int i = 0; i < N; i++) {
+            if (lvl[i]) continue;
+            double e[2], J[18];
+            frame_mono(F, nav, pw + 3 * i, uv + 2 * i, e, J);
+            double rw = 1.0;
+            if (c->vis_robust) { vbo_huber(chi2_2(e, w[i]), dm, rho); rw = rho[1]; }
+            const double Wt = rw * w[i];
+            for (int a = 0; a < 9; a++) {
+                c->b[c0 + a] -= J[a] * Wt * e[0] + J[9 + a] * Wt * e[1];
+                for (int bb = 0; bb < 9; bb++) c->H[(c0 + a) * n + c0 + bb] += J[a] * Wt * J[bb] + J[9 + a] * Wt * J[9 + bb];
+            }
+        }
+    }
+}
+
+/* LinearSolverCholmod::solve: L L^T, "not positive definite" -> false (linear_solver_cholmod.h:86-125) */
+static int chol_solve_dense(int n, const double *A, const double *rhs, double *x) {
+    double L[900];
+    for (int j = 0; j < n; j++) {
+        double d = A[j * n + j];
+        for (int k = 0; k < j; k++) d -= L[j * n + k] * L[j * n + k];
+        if (!(d > 0.0) || !isfinite(d)) return 0;
+        d = sqrt(d);
+        L[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[i * n + j];
+            for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = s / d;
+        }
+    }
+    double y[30];
+    for (int i = 0; i < n; i++) {
+        double s = rhs[i];
+        for (int k = 0; k < i; k++) s -= L[i * n + k] * y[k];
+        y[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k];
+        x[i] = s / L[i * n + i];
+    }
+    return 1;
+}
+
+static int frame_lm(fctx *c, int iterations, double *chi_out) {
+    const int n = c->n;
+    int cj = 0, nBad = 0;
+    double lambda = 0, ni = 2, cur = 0;
+    for (int it = 0; it < iterations; it++) {
+        cur = frame_errors(c);
+        const double iniChi = cur;
+        double tempChi = cur;
+        frame_build(c);
+        memcpy(c->Hlast, c->H, sizeof c->H);
+        if (it == 0) {
+            double mx = 0;
+            for (int i = 0; i < n; i++) mx = fmax(fabs(c->H[i * n + i]), mx);
+            lambda = 1e-5 * mx;
+            ni = 2;
+            nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            memcpy(c->cur_bk, c->cur, sizeof c->cur);
+            memcpy(c->last_bk, c->last, sizeof c->last);
+            double A[900];
+            memcpy(A, c->H, sizeof A);
+            for (int i = 0; i < n; i++) A[i * n + i] += lambda;
+            const int ok2 = chol_solve_dense(n, A, c->b, c->x);
+            if (ok2) {
+                nav_oplus(c->cur, c->x, c->x + 9);
+                if (n == 30) nav_oplus(c->last, c->x + 15, c->x + 24);
+            }
+            tempChi = frame_errors(c);
+            if (!ok2) tempChi = DBL_MAX;
+            rho = cur - tempChi;
+            double scale = 0;
+            for (int j = 0; j < n; j++) scale += c->x[j] * (lambda * c->x[j] + c->b[j]);
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2;
+                cur = tempChi;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                memcpy(c->cur, c->cur_bk, sizeof c->cur);
+                memcpy(c->last, c->last_bk, sizeof c->last);
+            }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        ++cj;
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - cur) * 1e3 < iniChi) nBad++;
+        else nBad = 0;
+        if (nBad >= 3) break;
+    }
+    *chi_out = cur;
+    return cj;
+}
+
+static void dense_inverse(int n, const double *A, double *Ai) { /* Gauss-Jordan with partial pivoting */
+    double M[30][60];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) { M[i][j] = A[i * n + j]; M[i][n + j] = (i == j) ? 1.0 : 0.0; }
+    for (int cc = 0; cc < n; cc++) {
+        int p = cc;
+        for (int r = cc + 1; r < n; r++)
+            if (fabs(M[r][cc]) > fabs(M[p][cc])) p = r;
+        if (p != cc)
+            for (int j = 0; j < 2 * n; j++) { const double t = M[cc][j]; M[cc][j] = M[p][j]; M[p][j] = t; }
+        const double inv = 1.0 / M[cc][cc];
+        for (int j = 0; j < 2 * n; j++) M[cc][j] *= inv;
+        for (int r = 0; r < n; r++) {
+            if (r == cc) continue;
+            const double f = M[r][cc];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 2 * n; j++) M[r][j] -= f * M[cc][j];
+        }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Ai[i * n + j] = M[i][n + j];
+}
+
+int vba_oracle_pose_optimize(vba_frame_problem *F, vba_frame_result *out) {
+    memset(out->its_done, 0, sizeof out->its_done);
+    memset(out->chi2_round, 0, sizeof out->chi2_round);
+    memset(out->marg_cov_inv, 0, sizeof out->marg_cov_inv);
+    out->status = VBA_OK;
+    out->n_inliers = 0;
+    for (int i = 0; i < F->n_obs; i++) out->outlier[i] = 0; /* pFrame->mvbOutlier[i] = false, :2147 */
+    if (F->n_obs < 3) return 0;                              /* nInitialCorrespondences < 3, :2178 */
+    fctx C, *c = &C;
+    memset(c, 0, sizeof C);
+    c->F = F;
+    c->n = F->last_is_frame ? 30 : 15;
+    c->lvl = calloc(F->n_obs + 1, 1);
+    c->err = calloc(2 * F->n_obs + 2, 8);
+    c->lvl_last = calloc(F->n_obs_last + 1, 1);
+    c->err_last = calloc(2 * F->n_obs_last + 2, 8);
+    dense_inverse(9, F->imu_cov_pvphi, c->info_pvr);       /* Matrix9d InvCovPVR = imupreint.getCovPVPhi().inverse() */
+    if (F->last_is_frame && out->outlier_last)
+        for (int i = 0; i < F->n_obs_last; i++) out->outlier_last[i] = 0;
+    c->vis_robust = 1;
+    int nBad = 0;
+    for (int it = 0; it < 4; it++) {
+        memcpy(c->cur, F->nav, sizeof c->cur);             /* setEstimate(pFrame->GetNavState()) before every round */
+        memcpy(c->last, F->nav_last, sizeof c->last);
+        out->its_done[it] = frame_lm(c, 10, &out->chi2_round[it]);
+        const double dm2 = 5.991;
+        for (int pass = 0; pass < (F->last_is_frame ? 2 : 1); pass++) {
+            const int N = pass ? F->n_obs_last : F->n_obs;
+            unsigned char *lvl = pass ? c->lvl_last : c->lvl;
+            double *err = pass ? c->err_last : c->err;
+            int bad = 0;
+            for (int i = 0; i < N; i++) {
+                if (lvl[i]) /* outliers are outside the active set: their error is recomputed at the final estimate */
+                    frame_mono(F, pass ? c->last : c->cur, (pass ? F->last_pw : F->obs_pw) + 3 * i, (pass ? F->last_uv : F->obs_uv) + 2 * i, err + 2 * i, NULL);
+                const float chi2 = (float)chi2_2(err + 2 * i, (pass ? F->last_w : F->obs_w)[i]); /* const float chi2 = e->chi2() */
+                if (chi2 > (float)dm2) { lvl[i] = 1; bad++; } else lvl[i] = 0;
+            }
+            if (!pass) nBad = bad;
+        }
+        if (it == 2) c->vis_robust = 0;                    /* e->setRobustKernel(0) */
+        if (F->n_obs + F->n_obs_last * (F->last_is_frame ? 1 : 0) + 2 + (F->last_is_frame ? 1 : 0) < 10) break; /* optimizer.edges().size() < 10 */
+    }
+    memcpy(F->nav, c->cur, 10 * sizeof(double));            /* P, R, V of the PVR vertex */
+    memcpy(F->nav + 16, c->cur + 16, 6 * sizeof(double));   /* dbg, dba of the bias vertex */
+    for (int i = 0; i < F->n_obs; i++) out->outlier[i] = c->lvl[i];
+    if (F->last_is_frame && out->outlier_last)
+        for (int i = 0; i < F->n_obs_last; i++) out->outlier_last[i] = c->lvl_last[i];
+    out->n_inliers = F->n_obs - nBad;
+    if (F->compute_marg) {
+        /* computeMarginals on the Hessian of the last linearisation (lambda already restored) */
+        double Hi[900];
+        dense_inverse(c->n, c->Hlast, Hi);
+        if (!F->last_is_frame) {
+            /* margCovInv = blockdiag(spinv(0,0)^-1, spinv(1,1)^-1), :2251-2253 */
+            double A[81], Ai[81], B[36], Bi[36];
+            for (int i = 0; i < 9; i++)
+                for (int j = 0; j < 9; j++) A[9 * i + j] = Hi[i * c->n + j];
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) B[6 * i + j] = Hi[(9 + i) * c->n + 9 + j];
+            dense_inverse(9, A, Ai);
+            dense_inverse(6, B, Bi);
+            for (int i = 0; i < 9; i++)
+                for (int j = 0; j < 9; j++) out->marg_cov_inv[15 * i + j] = Ai[9 * i + j];
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) out->marg_cov_inv[15 * (9 + i) + 9 + j] = Bi[6 * i + j];
+        } else {
+            /* the joint 15x15 marginal of the frame, inverted (:2011-2018; the reference asks g2o for the diagonal
+             * blocks only and then reads the off-diagonal ones too -- the intent, the full joint marginal, is restated) */
+            double A[225];
+            for (int i = 0; i < 15; i++)
+                for (int j = 0; j < 15; j++) A[15 * i + j] = Hi[i * c->n + j];
+            dense_inverse(15, A, out->marg_cov_inv);
+        }
+    }
+    free(c->lvl); free(c->err); free(c->lvl_last); free(c->err_last);
+    return 0;
+}
+
+/* test hook: robust chi2, H and b of the frame problem at F->nav / F->nav_last (all edges active, kernels on) */
+int vba_oracle_frame_linearize(vba_frame_problem *F, double *H, double *b, double *chi) {
+    fctx C, *c = &C;
+    memset(c, 0, sizeof C);
+    c->F = F;
+    c->n = F->last_is_frame ? 30 : 15;
+    c->lvl = calloc(F->n_obs + 1, 1);
+    c->err = calloc(2 * F->n_obs + 2, 8);
+    c->lvl_last = calloc(F->n_obs_last + 1, 1);
+    c->err_last = calloc(2 * F->n_obs_last + 2, 8);
+    dense_inverse(9, F->imu_cov_pvphi, c->info_pvr);
+    c->vis_robust = 1;
+    memcpy(c->cur, F->nav, sizeof c->cur);
+    memcpy(c->last, F->nav_last, sizeof c->last);
+    *chi = frame_errors(c);
+    if (H) {
+        frame_build(c);
+        memcpy(H, c->H, sizeof(double) * c->n * c->n);
+        memcpy(b, c->b, sizeof(double) * c->n);
+    }
+    free(c->lvl); free(c->err); free(c->lvl_last); free(c->err_last);
+    return c->n;
+}
+void vbo_nav_oplus(double *nav, const double *dpvr, const double *dbias) { nav_oplus(nav, dpvr, dbias); }

@@ -197,3 +197,31 @@ def prv_information(cov):
     rc = f(P(_a(cov).reshape(-1)), P(info))
     assert rc == 0
     return info.reshape(9, 9)
+
+
+# ---- IMU-aided per-frame pose optimisation ----
+def pose_optimize(f: abi.FrameProblem):
+    """vba_oracle_pose_optimize on a copy: FrameResult (with the optimised nav)"""
+    s = f.as_struct()
+    rb = abi.FrameResultBuf(f)
+    fn = lib().vba_oracle_pose_optimize
+    fn.restype = C.c_int
+    rc = fn(C.byref(s), C.byref(rb.s))
+    assert rc == 0
+    return rb.get(s)
+
+
+def frame_linearize(f: abi.FrameProblem, want_H=True):
+    n = 30 if f.last_is_frame else 15
+    H = np.zeros((n, n)); b = np.zeros(n); chi = C.c_double(0)
+    s = f.as_struct()
+    fn = lib().vba_oracle_frame_linearize
+    fn.restype = C.c_int
+    fn(C.byref(s), P(H) if want_H else None, P(b), C.cast(C.pointer(chi), _pd))
+    return H, b, chi.value
+
+
+def nav_oplus(nav, dpvr, dbias):
+    out = np.array(nav, dtype=np.float64).copy()
+    call("vbo_nav_oplus", out, _a(dpvr), _a(dbias))
+    return out

@@ -1,0 +1,73 @@
+"""CPU pins of the oracle's IMU-aided PoseOptimization restatement (src/Optimizer.cpp:1671-2317).
+Parity unpinned like the rest of the oracle (the reference has no fixtures): Jacobians and assembly are pinned by
+finite differences of the robust cost through the vertex retractions, the protocol by its observable properties."""
+import numpy as np
+import pytest
+
+from mc_slam_amd import abi, synth
+
+
+@pytest.mark.parametrize("lif", [False, True])
+def test_b_is_minus_half_gradient_and_H_is_gauss_newton(oracle, lif):
+    f = synth.make_frame(seed=11, n_obs=60, last_is_frame=lif)
+    H, b, chi0 = oracle.frame_linearize(f)
+    n = H.shape[0]
+    np.testing.assert_allclose(H, H.T, rtol=1e-10, atol=1e-6)
+    assert np.linalg.eigvalsh(H).min() > 0
+    h = 1e-6
+    for i in range(n):
+        vals = []
+        for sgn in (+1, -1):
+            d = np.zeros(n); d[i] = sgn * h
+            g = f.copy()
+            g.nav = oracle.nav_oplus(f.nav, d[0:9], d[9:15])
+            if lif:
+                g.nav_last = oracle.nav_oplus(f.nav_last, d[15:24], d[24:30])
+            vals.append(oracle.frame_linearize(g, want_H=False)[2])
+        grad = (vals[0] - vals[1]) / (2 * h)
+        assert abs(-0.5 * grad - b[i]) <= 2e-4 * max(1.0, abs(b[i])), (i, -0.5 * grad, b[i])
+
+
+@pytest.mark.parametrize("lif", [False, True])
+def test_protocol_properties(oracle, lif):
+    f = synth.make_frame(seed=12, n_obs=250, last_is_frame=lif, outlier_frac=0.1)
+    r = oracle.pose_optimize(f)
+    assert r.status == 0 and all(1 <= k <= 10 for k in r.its_done)
+    planted = f.truth["is_outlier"]
+    assert (r.outlier.astype(bool) & planted).sum() >= 0.95 * planted.sum()
+    assert r.n_inliers == f.n_obs - int(r.outlier.sum())
+    # closer to the truth than the initial guess, in position and attitude
+    gt = f.truth["nav"]
+    assert np.abs(r.nav[:3] - gt[:3]).max() < np.abs(f.nav[:3] - gt[:3]).max()
+    assert np.abs(r.nav[:3] - gt[:3]).max() < 0.03
+    # bg, ba themselves never change; the last state is not written back
+    assert (r.nav[10:16] == f.nav[10:16]).all()
+    M = r.marg_cov_inv
+    np.testing.assert_allclose(M, M.T, rtol=1e-6, atol=1e-6 * np.abs(M).max())
+    assert np.linalg.eigvalsh(0.5 * (M + M.T)).min() > 0
+    if not lif:   # block diagonal: inverse of the diagonal blocks of H^-1 (src/Optimizer.cpp:2251-2253)
+        assert (M[:9, 9:] == 0).all() and (M[9:, :9] == 0).all()
+    else:
+        assert r.outlier_last.shape == (f.n_obs_last,) and (r.outlier_last.astype(bool) & f.truth["is_outlier_last"]).sum() >= 0.9 * f.truth["is_outlier_last"].sum()
+
+
+def test_fewer_than_three_correspondences_returns_zero_untouched(oracle):
+    f = synth.make_frame(seed=13, n_obs=60)
+    g = abi.FrameProblem(nav=f.nav, nav_last=f.nav_last, obs_pw=f.obs_pw[:2], obs_uv=f.obs_uv[:2], obs_w=f.obs_w[:2], K=f.K,
+                         T_cb=f.T_cb, g_w=f.g_w, imu_meas=f.imu_meas, imu_cov_pvphi=f.imu_cov_pvphi)
+    r = oracle.pose_optimize(g)
+    assert r.n_inliers == 0 and (r.nav == f.nav).all()
+
+
+def test_marginal_of_keyframe_variant_matches_numpy(oracle):
+    """margCovInv = blockdiag(inv(Hinv[PVR,PVR]), inv(Hinv[B,B])) for the Hessian of the last linearisation
+    (src/Optimizer.cpp:2244-2254).  On a noise-free frame the last iterations sit at the optimum, every residual is
+    far below the kernel widths and nothing is classified out, so the Hessian at the returned state is that one."""
+    f = synth.make_frame(seed=14, n_obs=80, noise=False)
+    r = oracle.pose_optimize(f)
+    assert r.outlier.sum() == 0
+    g = f.copy(); g.nav = r.nav
+    H, b, chi = oracle.frame_linearize(g)
+    Hi = np.linalg.inv(H)
+    np.testing.assert_allclose(r.marg_cov_inv[:9, :9], np.linalg.inv(Hi[:9, :9]), rtol=1e-4, atol=1e-6 * np.abs(r.marg_cov_inv).max())
+    np.testing.assert_allclose(r.marg_cov_inv[9:, 9:], np.linalg.inv(Hi[9:, 9:]), rtol=1e-4, atol=1e-6 * np.abs(r.marg_cov_inv).max())
