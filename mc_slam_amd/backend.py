@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VBA_LIB", os.path.join(_HERE, "csrc", "libvislam_ba.s
 _lib = None
 
 EXPORTS = ["vba_create", "vba_destroy", "vba_last_error", "vba_solve", "vba_batch_upload", "vba_batch_run",
-           "vba_batch_download", "vba_preintegrate", "vba_set_profile", "vba_get_profile"]
+           "vba_batch_download", "vba_preintegrate", "vba_pose_optimize", "vba_set_profile", "vba_get_profile"]
 
 
 def load_library():
@@ -37,6 +37,7 @@ def load_library():
     lib.vba_batch_download.argtypes = [C.c_void_p, C.c_int32, PP, PR]
     _pd, _pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     lib.vba_preintegrate.argtypes = [C.c_void_p, C.c_int32, _pi, _pd, _pd, _pd, C.c_double, C.c_double, _pd, _pd, _pd]
+    lib.vba_pose_optimize.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(abi.vba_frame_problem)), C.POINTER(C.POINTER(abi.vba_frame_result))]
     lib.vba_set_profile.argtypes = [C.c_void_p, C.c_int32]
     lib.vba_get_profile.argtypes = [C.c_void_p, C.POINTER(abi.vba_profile)]
     for n in EXPORTS:
@@ -124,6 +125,17 @@ class LocalBA:
         if rc != 0:
             raise self._err("vba_preintegrate")
         return meas, cov.reshape(E, 9, 9), (info.reshape(E, 9, 9) if want_info else None)
+
+    def pose_optimize(self, frames):
+        """vba_pose_optimize on copies of the FrameProblems: list of abi.FrameResult (with the optimised nav)"""
+        n = len(frames)
+        structs = [f.as_struct() for f in frames]
+        bufs = [abi.FrameResultBuf(f) for f in frames]
+        pp = (C.POINTER(abi.vba_frame_problem) * n)(*[C.pointer(s) for s in structs])
+        rr = (C.POINTER(abi.vba_frame_result) * n)(*[C.pointer(b.s) for b in bufs])
+        if self.lib.vba_pose_optimize(self.h, n, pp, rr) != 0:
+            raise self._err("vba_pose_optimize")
+        return [b.get(s) for b, s in zip(bufs, structs)]
 
     def set_profile(self, on=True):
         self.lib.vba_set_profile(self.h, 1 if on else 0)

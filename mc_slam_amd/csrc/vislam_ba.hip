@@ -8,6 +8,7 @@
 #include "../../include/vislam_ba.h"
 #include "vba_kernels_lm.h"
 #include "vba_preint.h"
+#include "vba_pose.h"
 
 #include <algorithm>
 #include <chrono>
@@ -61,6 +62,7 @@ struct Handle {
     std::string err;
     DevBuf buf[BUF_N];
     DevBuf preint;  // arena of vba_preintegrate
+    DevBuf pose_arena;  // arena of vba_pose_optimize
     Batch B;
     std::vector<WinDesc> desc;
     std::vector<WinCtrl> hctrl;
@@ -861,6 +863,7 @@ int vba_destroy(void* handle) {
     (void)hipStreamSynchronize(h->stream);
     for (auto& b : h->buf) b.release();
     h->preint.release();
+    h->pose_arena.release();
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
     for (auto st : h->xstreams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (h->stop_host) (void)hipHostFree((void*)h->stop_host);
@@ -967,6 +970,123 @@ int vba_preintegrate(void* handle, int32_t n_edges, const int32_t* sample_begin,
     HIPCHK(h, hipMemcpyAsync(cov_pvphi, d_c, b_c, hipMemcpyDeviceToHost, h->stream));
     if (imu_info_prv) HIPCHK(h, hipMemcpyAsync(imu_info_prv, d_i, b_c, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+namespace {
+// Matrix::inverse() of the small dense matrices of the set-up code (Gauss-Jordan, partial pivoting)
+void inverse_host(int n, const double* A, double* Ai) {
+    double M[15][30];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) { M[i][j] = A[i * n + j]; M[i][n + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++)
+            if (std::fabs(M[r][c]) > std::fabs(M[p][c])) p = r;
+        if (p != c)
+            for (int j = 0; j < 2 * n; j++) std::swap(M[c][j], M[p][j]);
+        const double inv = 1.0 / M[c][c];
+        for (int j = 0; j < 2 * n; j++) M[c][j] *= inv;
+        for (int r = 0; r < n; r++) {
+            if (r == c) continue;
+            const double f = M[r][c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 2 * n; j++) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Ai[i * n + j] = M[i][n + j];
+}
+}  // namespace
+
+int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* inout, vba_frame_result* const* out) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    if (n_frames <= 0 || !inout || !out) return fail(h, "vba_pose_optimize: bad arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<FrameDesc> desc(n_frames);
+    size_t n_tot = 0;
+    for (int f = 0; f < n_frames; f++) {
+        const vba_frame_problem* F = inout[f];
+        if (!F || !out[f] || F->n_obs < 0 || (F->n_obs > 0 && (!F->obs_pw || !F->obs_uv || !F->obs_w || !out[f]->outlier)))
+            return fail(h, "vba_pose_optimize: bad frame");
+        if (F->last_is_frame && F->n_obs_last > 0 && (!F->last_pw || !F->last_uv || !F->last_w)) return fail(h, "vba_pose_optimize: bad last frame");
+        n_tot += (size_t)F->n_obs + (F->last_is_frame ? (size_t)F->n_obs_last : 0);
+    }
+    std::vector<double> pw(3 * n_tot + 3), uv(2 * n_tot + 2), ww(n_tot + 1);
+    size_t o = 0;
+    for (int f = 0; f < n_frames; f++) {
+        const vba_frame_problem* F = inout[f];
+        FrameDesc& d = desc[f];
+        std::memset(&d, 0, sizeof d);
+        d.last_is_frame = F->last_is_frame ? 1 : 0;
+        d.compute_marg = F->compute_marg ? 1 : 0;
+        d.n_obs = F->n_obs;
+        d.n_last = d.last_is_frame ? F->n_obs_last : 0;
+        d.obs0 = (int)o;
+        std::memcpy(&pw[3 * o], F->obs_pw, 24 * (size_t)d.n_obs);
+        std::memcpy(&uv[2 * o], F->obs_uv, 16 * (size_t)d.n_obs);
+        std::memcpy(&ww[o], F->obs_w, 8 * (size_t)d.n_obs);
+        o += d.n_obs;
+        d.last0 = (int)o;
+        if (d.n_last) {
+            std::memcpy(&pw[3 * o], F->last_pw, 24 * (size_t)d.n_last);
+            std::memcpy(&uv[2 * o], F->last_uv, 16 * (size_t)d.n_last);
+            std::memcpy(&ww[o], F->last_w, 8 * (size_t)d.n_last);
+            o += d.n_last;
+        }
+        std::memcpy(d.nav, F->nav, sizeof d.nav);
+        std::memcpy(d.nav_last, F->nav_last, sizeof d.nav_last);
+        std::memcpy(d.prior_nav, F->prior_nav, sizeof d.prior_nav);
+        std::memcpy(d.prior_info, F->prior_info, sizeof d.prior_info);
+        std::memcpy(d.K, F->K, sizeof d.K);
+        quat_to_R_host(F->T_cb + 3, d.Rcb);
+        for (int i = 0; i < 3; i++) { d.tcb[i] = F->T_cb[i]; d.g[i] = F->g_w[i]; }
+        std::memcpy(d.meas, F->imu_meas, sizeof d.meas);
+        inverse_host(9, F->imu_cov_pvphi, d.info_pvr);   // Matrix9d InvCovPVR = imupreint.getCovPVPhi().inverse(), :2103
+        d.inv_bg = F->inv_bg_rw2; d.inv_ba = F->inv_ba_rw2;
+        d.hub_prior = (double)(float)std::sqrt(30.5779); d.hub_pvr = (double)(float)std::sqrt(21.666);
+        d.hub_bias = (double)(float)std::sqrt(16.812); d.hub_mono = (double)(float)std::sqrt(5.991);
+    }
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_desc = up(sizeof(FrameDesc) * n_frames), b_out = up(sizeof(FrameOut) * n_frames);
+    const size_t b_pw = up(pw.size() * 8), b_uv = up(uv.size() * 8), b_w = up(ww.size() * 8), b_err = up((2 * n_tot + 2) * 8), b_lvl = up(n_tot + 1);
+    HIPCHK(h, h->pose_arena.ensure(b_desc + b_out + b_pw + b_uv + b_w + b_err + b_lvl));
+    char* base = reinterpret_cast<char*>(h->pose_arena.p);
+    PoseBatch B;
+    B.desc = reinterpret_cast<const FrameDesc*>(base);
+    B.out = reinterpret_cast<FrameOut*>(base + b_desc);
+    double* d_pw = reinterpret_cast<double*>(base + b_desc + b_out);
+    double* d_uv = reinterpret_cast<double*>(base + b_desc + b_out + b_pw);
+    double* d_w = reinterpret_cast<double*>(base + b_desc + b_out + b_pw + b_uv);
+    B.pw = d_pw; B.uv = d_uv; B.w = d_w;
+    B.err = reinterpret_cast<double*>(base + b_desc + b_out + b_pw + b_uv + b_w);
+    B.lvl = reinterpret_cast<unsigned char*>(base + b_desc + b_out + b_pw + b_uv + b_w + b_err);
+    B.n_frames = n_frames;
+    HIPCHK(h, hipMemcpyAsync(base, desc.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_pw, pw.data(), pw.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_uv, uv.data(), uv.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_w, ww.data(), ww.size() * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(64), 0, h->stream, B);
+    HIPCHK(h, hipGetLastError());
+    std::vector<FrameOut> res(n_frames);
+    std::vector<unsigned char> lvl(n_tot + 1);
+    HIPCHK(h, hipMemcpyAsync(res.data(), B.out, sizeof(FrameOut) * n_frames, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(lvl.data(), B.lvl, n_tot + 1, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int f = 0; f < n_frames; f++) {
+        vba_frame_problem* F = inout[f];
+        vba_frame_result* R = out[f];
+        const FrameDesc& d = desc[f];
+        const FrameOut& r = res[f];
+        R->n_inliers = r.n_inliers; R->status = r.status;
+        for (int k = 0; k < 4; k++) { R->its_done[k] = r.its[k]; R->chi2_round[k] = r.chi2_round[k]; }
+        std::memcpy(R->marg_cov_inv, r.marg, sizeof r.marg);
+        std::memcpy(F->nav, r.nav, sizeof r.nav);
+        for (int i = 0; i < d.n_obs; i++) R->outlier[i] = lvl[d.obs0 + i];
+        if (R->outlier_last)
+            for (int i = 0; i < d.n_last; i++) R->outlier_last[i] = lvl[d.last0 + i];
+    }
     return 0;
 }
 

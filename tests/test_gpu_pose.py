@@ -1,0 +1,61 @@
+"""GPU parity of the IMU-aided per-frame PoseOptimization against the CPU oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+from mc_slam_amd import abi, synth, backend
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ba():
+    b = backend.LocalBA(0)
+    yield b
+    b.close()
+
+
+def _check(f, r, ro):
+    assert r.status == ro.status == 0
+    assert r.its_done == ro.its_done, (r.its_done, ro.its_done, r.chi2_round, ro.chi2_round)
+    assert (r.outlier == ro.outlier).all() and (r.outlier_last == ro.outlier_last).all()
+    assert r.n_inliers == ro.n_inliers
+    np.testing.assert_allclose(r.chi2_round, ro.chi2_round, rtol=1e-7)
+    assert np.abs(r.nav[:3] - ro.nav[:3]).max() <= 1e-6            # translations: the north-star bar
+    assert np.abs(r.nav[3:7] - ro.nav[3:7]).max() <= 1e-7
+    assert np.abs(r.nav[7:10] - ro.nav[7:10]).max() <= 1e-6
+    np.testing.assert_allclose(r.nav[16:22], ro.nav[16:22], atol=1e-8)
+    assert (r.nav[10:16] == f.nav[10:16]).all()                    # bg, ba are never touched
+    if f.compute_marg:
+        np.testing.assert_allclose(r.marg_cov_inv, ro.marg_cov_inv, rtol=1e-5, atol=1e-7 * np.abs(ro.marg_cov_inv).max())
+    else:
+        assert (r.marg_cov_inv == 0).all()
+
+
+@pytest.mark.parametrize("lif,seed,n_obs", [(False, 21, 300), (False, 22, 120), (True, 23, 300), (True, 24, 90)])
+def test_pose_optimization_matches_oracle(ba, oracle, lif, seed, n_obs):
+    f = synth.make_frame(seed=seed, n_obs=n_obs, last_is_frame=lif, outlier_frac=0.1)
+    r = ba.pose_optimize([f])[0]
+    ro = oracle.pose_optimize(f)
+    _check(f, r, ro)
+    assert r.outlier.sum() > 0
+
+
+def test_batch_of_frames_equals_single_calls(ba, oracle):
+    frames = [synth.make_frame(seed=30 + i, n_obs=60 + 37 * i, last_is_frame=bool(i % 2), compute_marg=bool(i % 3)) for i in range(7)]
+    tiny = synth.make_frame(seed=40, n_obs=60)
+    frames.append(abi.FrameProblem(nav=tiny.nav, nav_last=tiny.nav_last, obs_pw=tiny.obs_pw[:2], obs_uv=tiny.obs_uv[:2],
+                                   obs_w=tiny.obs_w[:2], K=tiny.K, T_cb=tiny.T_cb, g_w=tiny.g_w, imu_meas=tiny.imu_meas,
+                                   imu_cov_pvphi=tiny.imu_cov_pvphi))
+    rs = ba.pose_optimize(frames)
+    for f, r in zip(frames[:-1], rs[:-1]):
+        _check(f, r, oracle.pose_optimize(f))
+        r1 = ba.pose_optimize([f])[0]
+        assert (r1.nav == r.nav).all() and (r1.outlier == r.outlier).all() and (r1.marg_cov_inv == r.marg_cov_inv).all()
+    assert rs[-1].n_inliers == 0 and (rs[-1].nav == tiny.nav).all()     # fewer than 3 correspondences: untouched
+
+
+def test_noise_free_frame_recovers_the_truth(ba):
+    f = synth.make_frame(seed=41, n_obs=200, noise=False)
+    r = ba.pose_optimize([f])[0]
+    assert r.outlier.sum() == 0 and r.n_inliers == 200
+    assert np.abs(r.nav[:3] - f.truth["nav"][:3]).max() < 1e-3
