@@ -308,3 +308,54 @@ class FrameResultBuf:
         s = self.s
         return FrameResult(s.n_inliers, s.status, tuple(s.its_done), self.o[:self.n].copy(), self.ol[:self.nl].copy(),
                            np.array(s.chi2_round[:]), np.array(s.marg_cov_inv[:]).reshape(15, 15), np.array(st.nav[:]))
+
+
+# ---- on-disk problem format "VBAP" v1 (include/vislam_ba.h: vba_problem_save / vba_problem_load) ----
+_HDR = np.dtype([("magic", "S4"), ("version", "<u4"), ("i", "<i4", 12), ("K", "<f8", 4), ("T_cb", "<f8", 7), ("g_w", "<f8", 3),
+                 ("s", "<f8", 8)])
+
+
+def save_problem(path, p: "Problem"):
+    """numpy twin of vba_problem_save (same bytes)."""
+    s = p.as_struct()
+    hd = np.zeros(1, dtype=_HDR)
+    hd["magic"] = b"VBAP"; hd["version"] = 1
+    hd["i"] = [p.variant, p.n_kf, p.n_kf_free, p.n_pt, p.n_obs, p.n_imu, p.algo, p.its_stage1, p.its_stage2, p.protocol, p.robust,
+               1 if p.kf_fix is not None else 0]
+    hd["K"], hd["T_cb"], hd["g_w"] = p.K, p.T_cb, p.g_w
+    hd["s"] = [s.inv_bg_rw2, s.inv_ba_rw2, p.huber_vis, p.huber_prv, p.huber_bias, p.chi2_th, p.depth_min, p.rho_min]
+    with open(path, "wb") as f:
+        f.write(hd.tobytes())
+        for a in (p.kf_pose, p.kf_vel, p.kf_bias, p.pt, p.pt_ref_kf, p.pt_obs_begin, p.obs_kf, p.obs_uv, p.obs_w, p.imu_kf_i, p.imu_kf_j,
+                  p.imu_meas, p.imu_info_prv):
+            f.write(np.ascontiguousarray(a).tobytes())
+        if p.kf_fix is not None:
+            f.write(np.ascontiguousarray(p.kf_fix, dtype=np.uint8).tobytes())
+
+
+def load_problem(path) -> "Problem":
+    """numpy twin of vba_problem_load."""
+    raw = open(path, "rb").read()
+    hd = np.frombuffer(raw[:_HDR.itemsize], dtype=_HDR)[0]
+    if hd["magic"] != b"VBAP" or hd["version"] != 1:
+        raise ValueError("not a VBAP v1 file")
+    variant, n_kf, n_free, n_pt, n_obs, n_imu, algo, its1, its2, proto, robust, has_fix = [int(x) for x in hd["i"]]
+    off = [_HDR.itemsize]
+
+    def take(n, dt):
+        a = np.frombuffer(raw, dtype=dt, count=n, offset=off[0]).copy()
+        off[0] += a.nbytes
+        return a
+    pose, vel, bias, pt = take(7 * n_kf, "<f8"), take(3 * n_kf, "<f8"), take(12 * n_kf, "<f8"), take(3 * n_pt, "<f8")
+    ref, beg, okf = take(n_pt, "<i4"), take(n_pt + 1, "<i4"), take(n_obs, "<i4")
+    uv, w = take(2 * n_obs, "<f8"), take(n_obs, "<f8")
+    ii, ij, meas, info = take(n_imu, "<i4"), take(n_imu, "<i4"), take(61 * n_imu, "<f8"), take(81 * n_imu, "<f8")
+    fix = take(n_kf, "u1") if has_fix else None
+    if off[0] != len(raw):
+        raise ValueError("trailing bytes")
+    sc = hd["s"]
+    return Problem(variant=variant, n_kf_free=n_free, kf_pose=pose, pt=pt, pt_obs_begin=beg, obs_kf=okf, obs_uv=uv, obs_w=w, K=hd["K"].copy(),
+                   kf_vel=vel, kf_bias=bias, pt_ref_kf=ref, T_cb=hd["T_cb"].copy(), g_w=hd["g_w"].copy(), imu_kf_i=ii, imu_kf_j=ij,
+                   imu_meas=meas, imu_info_prv=info, algo=algo, its_stage1=its1, its_stage2=its2, chi2_th=float(sc[5]),
+                   depth_min=float(sc[6]), rho_min=float(sc[7]), huber_vis=float(sc[2]), huber_prv=float(sc[3]), huber_bias=float(sc[4]),
+                   protocol=proto, robust=robust, kf_fix=fix)

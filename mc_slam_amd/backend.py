@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VBA_LIB", os.path.join(_HERE, "csrc", "libvislam_ba.s
 _lib = None
 
 EXPORTS = ["vba_create", "vba_destroy", "vba_last_error", "vba_solve", "vba_batch_upload", "vba_batch_run",
-           "vba_batch_download", "vba_preintegrate", "vba_pose_optimize", "vba_set_profile", "vba_get_profile"]
+           "vba_batch_download", "vba_preintegrate", "vba_pose_optimize", "vba_problem_save", "vba_problem_load", "vba_problem_free", "vba_set_profile", "vba_get_profile"]
 
 
 def load_library():
@@ -126,16 +126,27 @@ class LocalBA:
             raise self._err("vba_preintegrate")
         return meas, cov.reshape(E, 9, 9), (info.reshape(E, 9, 9) if want_info else None)
 
-    def pose_optimize(self, frames):
-        """vba_pose_optimize on copies of the FrameProblems: list of abi.FrameResult (with the optimised nav)"""
+    def pose_pack(self, frames):
+        """ctypes views of a list of abi.FrameProblem for vba_pose_optimize (kept alive by the returned tuple)"""
         n = len(frames)
         structs = [f.as_struct() for f in frames]
         bufs = [abi.FrameResultBuf(f) for f in frames]
         pp = (C.POINTER(abi.vba_frame_problem) * n)(*[C.pointer(s) for s in structs])
         rr = (C.POINTER(abi.vba_frame_result) * n)(*[C.pointer(b.s) for b in bufs])
+        return n, structs, bufs, pp, rr, frames
+
+    def pose_run(self, packed):
+        n, structs, bufs, pp, rr, frames = packed
+        for s, f in zip(structs, frames):   # a run starts from the frame's initial state
+            s.nav[:] = f.nav.tolist()
         if self.lib.vba_pose_optimize(self.h, n, pp, rr) != 0:
             raise self._err("vba_pose_optimize")
-        return [b.get(s) for b, s in zip(bufs, structs)]
+
+    def pose_optimize(self, frames):
+        """vba_pose_optimize on copies of the FrameProblems: list of abi.FrameResult (with the optimised nav)"""
+        packed = self.pose_pack(frames)
+        self.pose_run(packed)
+        return [b.get(s) for b, s in zip(packed[2], packed[1])]
 
     def set_profile(self, on=True):
         self.lib.vba_set_profile(self.h, 1 if on else 0)

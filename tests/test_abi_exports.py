@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     txt = open(os.path.join(ROOT, "include", "vislam_ba.h")).read()
-    return sorted(set(re.findall(r"^\s*(?:int|const char \*)\s*\*?(vba_\w+)\s*\(", txt, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|void|const char \*)\s*\*?(vba_\w+)\s*\(", txt, flags=re.M)))
 
 
 def test_header_symbols_are_exported():
@@ -30,13 +30,14 @@ def test_struct_layout_matches_header():
     src = textwrap.dedent('''
         #include <stdio.h>
         #include "vislam_ba.h"
-        int main(){printf("%zu %zu %zu\\n", sizeof(vba_problem), sizeof(vba_result), sizeof(vba_profile));return 0;}''')
+        int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(vba_problem), sizeof(vba_result), sizeof(vba_profile), sizeof(vba_frame_problem), sizeof(vba_frame_result));return 0;}''')
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c"); exe = os.path.join(td, "s")
         open(c, "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        a, b, cc = map(int, subprocess.check_output([exe]).split())
-    assert (a, b, cc) == (C.sizeof(abi.vba_problem), C.sizeof(abi.vba_result), C.sizeof(abi.vba_profile))
+        sizes = tuple(map(int, subprocess.check_output([exe]).split()))
+    assert sizes == (C.sizeof(abi.vba_problem), C.sizeof(abi.vba_result), C.sizeof(abi.vba_profile),
+                     C.sizeof(abi.vba_frame_problem), C.sizeof(abi.vba_frame_result))
 
 
 def test_no_cpu_fallback_without_device():
