@@ -375,6 +375,16 @@ def config_c4(seed=4):
     return make_window(abi.VARIANT_PRV_IDP, n_kf=200, n_fixed=1, n_pt=50000, n_obs=500000, seed=seed)
 
 
+def config_gba(seed=6, n_kf=300, n_pt=30000, n_obs=180000, its=10, robust=1):
+    """GlobalBundleAdjustmentNavStatePRV at map scale: every keyframe free except PR/Bias of keyframe 0,
+    XYZ landmarks, one optimize(its) with Levenberg-Marquardt."""
+    p = make_window(abi.VARIANT_PRV_XYZ, algo=abi.ALGO_LM, n_kf=n_kf, n_fixed=0, n_pt=n_pt, n_obs=n_obs, seed=seed, outlier_frac=0.02)
+    p.protocol, p.robust, p.its_stage1, p.its_stage2 = abi.PROTO_SINGLE, robust, its, 0
+    p.huber_vis = float(np.float32(np.sqrt(5.99)))
+    p.kf_fix = np.zeros(p.n_kf, np.uint8); p.kf_fix[0] = 0b101
+    return p
+
+
 def make_frame(seed=5, n_obs=300, last_is_frame=False, compute_marg=True, noise=True, outlier_frac=0.1, pt_noise=0.01):
     """One tracked frame for the IMU-aided PoseOptimization (src/Optimizer.cpp:1671-2317): the last keyframe / frame,
     the preintegration up to the current frame, n_obs map points seen by both, a perturbed initial state."""
