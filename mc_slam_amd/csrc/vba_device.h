@@ -42,7 +42,10 @@ struct WinDesc {
     int lb0;        // offset into the k_lin2 landmark-run table
     int win;        // index of this window in the uploaded batch: the CSR-style tables (pt_obs_begin, item_begin,
                     // pimu_begin) carry one extra entry per window, so their rows start at offset + win
-    int pad1;
+    int tl_kb0;     // offset of this window's column-entry table of the left-looking factorisation (pan entries + nb + 1)
+    int tl_k0;      // offset into its k lists
+    int order;      // elimination order: 0 = V/Bias blocks first, 1 = keyframe by keyframe
+    int vp_pr0, vp_prs, vp_vb0, vp_vbs;  // position of dof r of free keyframe a: r < 6 ? pr0 + prs a + r : vb0 + vbs a + r - 6
     long long S0;   // offset (doubles) into S
     double K[4];
     double Rcb[9], tcb[3], g[3];
@@ -223,7 +226,7 @@ DEVI void so3inv(const double* a, double* o) {
 // blocks first (9 per keyframe, chain order) and all PR blocks last: the V/Bias part of the factor then
 // stays block-banded and whole 32x32 tiles of L are structurally zero (skipped by the tile lists).
 DEVI int vpos(const WinDesc& d, int a, int r) {
-    return d.pdim == 15 ? (r < 6 ? 9 * d.n_free + 6 * a + r : 9 * a + (r - 6)) : 6 * a + r;
+    return r < 6 ? d.vp_pr0 + d.vp_prs * a + r : d.vp_vb0 + d.vp_vbs * a + (r - 6);
 }
 DEVI double rl64(double v, int lane) {  // wave-uniform broadcast of one lane's double
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);

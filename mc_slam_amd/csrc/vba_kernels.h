@@ -41,6 +41,8 @@ struct Batch {
     const int* lin_blk;  // k_lin2: first landmark of every workgroup's run (n_part_lin + 1 entries per window)
     // tile structure of the factor (symbolic factorisation on 32x32 tiles, built at upload)
     const int *tl_step_begin, *tl_pairs, *tl_pan_begin, *tl_pan;
+    const int *tl_kl_begin, *tl_kl;  // left-looking factorisation: per column entry (J,J),(I,J).. the steps k < J that update it
+    double *dvec, *winv;             // D of the factor (nS per window); L_JJ^-T D_J^-1 of the current step (32x32 per window)
     double* part;
     const volatile int* stop_word;
     int* alive_cnt;  // pinned host words: [stage * 32 + it] = 1 if a window is still iterating after control call `it`
@@ -1223,6 +1225,244 @@ __global__ void __launch_bounds__(64) k_chol_update(Batch B, int k) {
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = acc[i];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Left-looking form of the tile factorisation for LARGE batches.  The right-looking kernels above re-read and
+// re-write every trailing tile once per step (~19 MB of HBM traffic per C3 factorisation); here a tile is read from S
+// once, accumulates ALL its updates C_IJ = S_IJ - sum_k L_Ik D_k L_Jk^T in MFMA registers (same k order, hence the same
+// rounding as the right-looking sweep), and is written once.  S itself is never modified.  Per block column J:
+//   diagonal tile : C_JJ, its L D L^T, the forward-substituted rhs y_J, and W_J = L_JJ^-T D_J^-1 (so that the panel
+//                   needs no serial triangular solve)
+//   panel tile    : C_IJ, then L_IJ = C_IJ W_J as one more MFMA product.
+// ------------------------------------------------------------------------------------------------
+DEVI void ll_accumulate(const Batch& B, const WinDesc& d, int I, int J, int kb, int ke, double* XI, double* XJ, double* ys,
+                        d4_t (&acc)[2][2], double* rhs_dot) {
+    __shared__ double dgs[32];
+    const int lane = threadIdx.x, n = d.nS;
+    const double* S = B.S + d.S0;
+    const double* Lf = B.Lf + d.S0;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int row = lane >> 1, c0 = (lane & 1) * 16;  // staging: 16 consecutive doubles of one tile row per lane
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            const double* C = S + ((size_t)I * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[ti][tj][i] = C[(size_t)(l4 + 4 * i) * n + l15];
+        }
+    const int* kl = B.tl_kl + d.tl_k0;
+    double sdot = 0.0;
+#ifndef LL_PREFETCH
+#define LL_PREFETCH 0
+#endif
+#if LL_PREFETCH
+    // register double buffer: the tiles of step e+1 are in flight while the MFMAs of step e run
+    double pi[16], pj[16], pd[16], py = 0.0;
+    if (kb < ke) {
+        const size_t dk = (size_t)kl[kb] * 32;
+        const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
+        const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
+        const double* sd = B.dvec + d.vec0 + dk + c0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { pi[q] = si[q]; pj[q] = sj[q]; pd[q] = sd[q]; }
+        if (rhs_dot && lane < 32) py = B.yv[d.vec0 + dk + lane];
+    }
+#endif
+    for (int e = kb; e < ke; e++) {
+        __syncthreads();  // the previous step's MFMAs are done with XI / XJ
+#if LL_PREFETCH
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            XI[row * 34 + c0 + q] = pi[q];
+            XJ[row * 34 + c0 + q] = pj[q] * pd[q];
+        }
+        if (rhs_dot && lane < 32) ys[lane] = py;
+        __syncthreads();
+        if (e + 1 < ke) {
+            const size_t dk = (size_t)kl[e + 1] * 32;
+            const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
+            const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
+            const double* sd = B.dvec + d.vec0 + dk + c0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { pi[q] = si[q]; pj[q] = sj[q]; pd[q] = sd[q]; }
+            if (rhs_dot && lane < 32) py = B.yv[d.vec0 + dk + lane];
+        }
+#else
+        {
+            const size_t dk = (size_t)kl[e] * 32;
+            if (lane < 32) {   // D_k (and y_k) once per wave through LDS, not 16 doubles per lane from memory
+                dgs[lane] = B.dvec[d.vec0 + dk + lane];
+                if (rhs_dot) ys[lane] = B.yv[d.vec0 + dk + lane];
+            }
+            __syncthreads();
+            const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
+            const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                XI[row * 34 + c0 + q] = si[q];
+                XJ[row * 34 + c0 + q] = sj[q] * dgs[c0 + q];
+            }
+        }
+        __syncthreads();
+#endif
+        if (rhs_dot && lane < 32) {
+#pragma unroll
+            for (int q = 0; q < 32; q++) sdot += XI[lane * 34 + q] * ys[q];
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+            for (int tj = 0; tj < 2; tj++) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ks++) {
+                    const double av = -XI[(16 * ti + l15) * 34 + 4 * ks + l4];
+                    const double bv = XJ[(16 * tj + l15) * 34 + 4 * ks + l4];
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[ti][tj], 0, 0, 0);
+                }
+            }
+    }
+    if (rhs_dot) *rhs_dot = sdot;
+    __syncthreads();
+}
+
+// diagonal tile of block column J: C_JJ, its L D L^T, y_J, D_J and W_J = L_JJ^-T D_J^-1
+DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, double* XI, double* XJ, double* ys, double* rd) {
+    const int* pb = B.tl_pan_begin + d.tl_step0;
+    const int* klb = B.tl_kl_begin + d.tl_kb0;
+    const int ent = pb[J] + J;  // column entry of (J,J)
+    const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5, n = d.nS;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    d4_t acc[2][2];
+    double sdot = 0.0;
+    ll_accumulate(B, d, J, J, klb[ent], klb[ent + 1], XI, XJ, ys, acc, &sdot);
+    // C_JJ through LDS into one row per lane
+    double* CT = XI;
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) CT[(16 * ti + l4 + 4 * i) * 34 + 16 * tj + l15] = acc[ti][tj][i];
+    __syncthreads();
+    double a[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) a[q] = (q <= r) ? CT[r * 34 + q] : 0.0;
+    double rdiag;
+    bool bad;
+    ldl32_regs(a, r, rdiag, bad);
+    double* Lf = B.Lf + d.S0;
+    const size_t dk = (size_t)J * 32;
+    double* Lk = XJ;  // 32 x 33
+    __syncthreads();
+    if (hi == 0) {
+#pragma unroll
+        for (int q = 0; q < 32; q++) Lk[r * 33 + q] = (q <= r) ? a[q] : 0.0;
+        rd[r] = rdiag;
+        double* lrow = Lf + (dk + r) * n + dk;
+#pragma unroll
+        for (int q = 0; q < 32; q++)
+            if (q <= r) lrow[q] = a[q];
+        double dr = 0.0;  // a[r] without a dynamic register index
+#pragma unroll
+        for (int q = 0; q < 32; q++) dr = (q == r) ? a[q] : dr;
+        B.dvec[d.vec0 + dk + r] = dr;
+    }
+    if (lane == 0 && bad) c.chol_fail = 1;
+    __syncthreads();
+    // y_J = L_JJ^-1 (b_J - sum_k L_Jk y_k)
+    double zr = (B.vec + d.vec0)[dk + r] - __shfl(sdot, r, 64);  // sdot lives in lanes 0..31; lanes 32..63 mirror them
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const double zq = rl64(zr, q);
+        zr = (r > q) ? zr - Lk[r * 33 + q] * zq : zr;
+    }
+    if (hi == 0) (B.yv + d.vec0)[dk + r] = zr;
+    // Z = L_JJ^-1 (unit lower) by columns: the two halves of the wave share a column, rows split even / odd is not
+    // possible (each row needs all earlier ones), so lanes 0..31 own one column each; W[j][k] = Z[j][k] / d_j, row-major
+    if (hi == 0) {
+        double z[32];
+#pragma unroll
+        for (int rr = 0; rr < 32; rr++) {
+            double sacc = (rr == r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < rr; q++) sacc -= Lk[rr * 33 + q] * z[q];
+            z[rr] = (rr >= r) ? sacc : 0.0;
+        }
+        double* W = B.winv + 1024 * (size_t)w;
+#pragma unroll
+        for (int j = 0; j < 32; j++) W[j * 32 + r] = z[j] * rd[j];
+    }
+}
+
+// (A fused variant -- the wave that owns tile (J+1,J) going on to factor diagonal tile J+1 -- and a register double buffer
+// for the tile loads were measured: no gain at 512 windows)
+__global__ void __launch_bounds__(64) k_chol_diag_ll(Batch B, int J) {
+    __shared__ double XI[32 * 34];
+    __shared__ double XJ[32 * 34];
+    __shared__ double ys[32], rd[32];
+    const int w = blockIdx.x;
+    if (w >= B.n_win) return;
+    const WinDesc& d = B.desc[w];
+    WinCtrl& c = B.ctrl[w];
+    if (!win_on(d, c)) return;
+    if (J >= d.nb) return;
+    ll_diag(B, d, c, w, J, XI, XJ, ys, rd);
+}
+
+__global__ void __launch_bounds__(64) k_chol_panel_ll(Batch B, int J) {
+    __shared__ double XI[32 * 34];
+    __shared__ double XJ[32 * 34];
+    __shared__ double ys[32];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    if (!win_on(d, B.ctrl[w])) return;
+    if (J >= d.nb) return;
+    const int* pb = B.tl_pan_begin + d.tl_step0;
+    const int* pan = B.tl_pan + d.tl_pan0;
+    const int npan = pb[J + 1] - pb[J];
+    const int bx = blockIdx.x;
+    if (bx >= npan) return;
+    const int I = pan[pb[J] + bx];
+    const int* klb = B.tl_kl_begin + d.tl_kb0;
+    const int ent = pb[J] + J + 1 + bx;
+    const int lane = threadIdx.x, n = d.nS;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    d4_t acc[2][2];
+    ll_accumulate(B, d, I, J, klb[ent], klb[ent + 1], XI, XJ, ys, acc, nullptr);
+    // L_IJ = C_IJ W_J
+    double* CT = XI;
+    double* WT = XJ;
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) CT[(16 * ti + l4 + 4 * i) * 34 + 16 * tj + l15] = acc[ti][tj][i];
+    {
+        const int row = lane >> 1, c0 = (lane & 1) * 16;
+        const double* sw = B.winv + 1024 * (size_t)w + row * 32 + c0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) WT[row * 34 + c0 + q] = sw[q];
+    }
+    __syncthreads();
+    double* Lf = B.Lf + d.S0;
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            d4_t o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                const double av = CT[(16 * ti + l15) * 34 + 4 * ks + l4];
+                const double bv = WT[(16 * tj + l15) * 34 + 4 * ks + l4];
+                o = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, o, 0, 0, 0);
+            }
+            double* C = Lf + ((size_t)I * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
+#pragma unroll
+            for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = o[i];
         }
 }
 

@@ -47,7 +47,7 @@ enum {
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
-    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_N
+    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_N
 };
 
 struct ProfEvt {
@@ -140,9 +140,14 @@ struct Structure {
     std::vector<int> step_begin, tpairs, pan_begin, pan;  // tile lists of the factorisation
     std::vector<int> step_npairs;
     std::vector<int> off_pair, pair_mask;
+    int order = 0;                     // elimination order of the reduced system (see build_structure)
+    std::vector<int> kl_begin, klist;  // left-looking factorisation: per column entry the steps k < J that update it
 };
 
-int vpos_host(int pdim, int nf, int a, int r) { return pdim == 15 ? (r < 6 ? 9 * nf + 6 * a + r : 9 * a + (r - 6)) : 6 * a + r; }
+int vpos_host(int order, int pdim, int nf, int a, int r) {
+    if (pdim != 15) return 6 * a + r;
+    return order ? 15 * a + r : (r < 6 ? 9 * nf + 6 * a + r : 9 * a + (r - 6));
+}
 
 int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2;
@@ -223,9 +228,16 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         for (auto& e : pl[i]) { st.pimu.push_back(e.first); st.pimu.push_back(e.second); }
     }
     // symbolic factorisation on 32x32 tiles (the tile-level analogue of SimplicialLDLT::analyzePattern,
-    // linear_solver_eigen.h:147-152): which tiles of L can be nonzero under the V/Bias-first ordering
+    // linear_solver_eigen.h:147-152): which tiles of L can be nonzero.  Two elimination orders are tried and the cheaper
+    // one (tile products of the factorisation) kept -- g2o lets AMD pick an order; the reduced system here is either
+    //   order 0: all V/Bias blocks first, PR blocks last -- the IMU chain stays a narrow band, the PR block fills in
+    //            completely: best when most keyframes share landmarks with most others (the usual local window)
+    //   order 1: keyframe by keyframe [PR_a V_a Bias_a] -- a block band whose width is the co-visibility span: best
+    //            for long, thin windows and for maps
     const int pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
     const int np = pdim * nf, nS = ((np + VBA_NB - 1) / VBA_NB) * VBA_NB, nb = nS / VBA_NB;
+    auto symbolic = [&](int order) -> long long {
+    st.tpairs.clear(); st.pan.clear();
     std::vector<unsigned char> T((size_t)nb * nb, 0);
     for (int i = 0; i < nb; i++) T[(size_t)i * nb + i] = 1;
     for (int pi = 0; pi < npairs; pi++) {
@@ -238,8 +250,8 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         for (int sr = 0; sr < nsub; sr++)
             for (int sc = 0; sc < nsub; sc++) {
                 const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
-                const int ti0 = vpos_host(pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(pdim, nf, a, r1) / VBA_NB;
-                const int tj0 = vpos_host(pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(pdim, nf, b, c1) / VBA_NB;
+                const int ti0 = vpos_host(order, pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(order, pdim, nf, a, r1) / VBA_NB;
+                const int tj0 = vpos_host(order, pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(order, pdim, nf, b, c1) / VBA_NB;
                 for (int ti = ti0; ti <= ti1; ti++)
                     for (int tj = tj0; tj <= tj1; tj++) T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)] = 1;
             }
@@ -263,6 +275,18 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         st.pan_begin[k + 1] = (int)st.pan.size();
         st.step_npairs[k] = st.step_begin[k + 1] - st.step_begin[k];
     }
+    // left-looking lists: column entries in the order (J,J), then (I,J) for I in the panel of J; K(I,J) = {k < J : L_Ik, L_Jk != 0}
+    st.kl_begin.clear();
+    st.klist.clear();
+    for (int J = 0; J < nb; J++) {
+        for (int e = -1; e < st.pan_begin[J + 1] - st.pan_begin[J]; e++) {
+            const int I = (e < 0) ? J : st.pan[st.pan_begin[J] + e];
+            st.kl_begin.push_back((int)st.klist.size());
+            for (int k = 0; k < J; k++)
+                if (T[(size_t)I * nb + k] && T[(size_t)J * nb + k]) st.klist.push_back(k);
+        }
+    }
+    st.kl_begin.push_back((int)st.klist.size());
     // which sub-blocks of a keyframe pair's block can land in a tile the factorisation reads (T now holds L's pattern)
     st.pair_mask.assign(npairs, 0);
     st.off_pair.clear();
@@ -274,8 +298,8 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         for (int sr = 0; sr < nsub; sr++)
             for (int sc = 0; sc < nsub; sc++) {
                 const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
-                const int ti0 = vpos_host(pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(pdim, nf, a, r1) / VBA_NB;
-                const int tj0 = vpos_host(pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(pdim, nf, b, c1) / VBA_NB;
+                const int ti0 = vpos_host(order, pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(order, pdim, nf, a, r1) / VBA_NB;
+                const int tj0 = vpos_host(order, pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(order, pdim, nf, b, c1) / VBA_NB;
                 bool any = false;
                 for (int ti = ti0; ti <= ti1; ti++)
                     for (int tj = tj0; tj <= tj1; tj++) any = any || T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)];
@@ -283,6 +307,20 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
             }
         st.pair_mask[pi] = mask;
     }
+    long long cost = (long long)st.klist.size();
+    return cost;
+    };
+    static const int env_order = getenv("VBA_ORDER") ? atoi(getenv("VBA_ORDER")) : -1;
+    st.order = 0;
+    if (pdim == 15) {
+        if (env_order >= 0) st.order = env_order ? 1 : 0;
+        else {
+            const long long c0 = symbolic(0), c1 = symbolic(1);
+            st.order = (10 * c1 < 7 * c0) ? 1 : 0;  // only a clear win: a batch that mixes both orders pays for both patterns
+            if (getenv("VBA_TIMING")) fprintf(stderr, "[vba] tile products of the factorisation: V/Bias-first %lld, keyframe order %lld (nb %d)\n", c0, c1, nb);
+        }
+    }
+    symbolic(st.order);
     st.off_pair.resize(npairs, 0);  // padded to the pair stride
     return 0;
 }
@@ -321,7 +359,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     std::vector<double> pose, vel, bias, pt, uv, ow, meas, info;
     std::vector<unsigned char> kffix;
     std::vector<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
-    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, offpair, pairmask;
+    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, offpair, pairmask, tlkb, tlk;
     h->step_grid.clear();
     h->pan_grid.clear();
     h->step_npair_max.clear();
@@ -395,6 +433,13 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         tlpanb.insert(tlpanb.end(), st.pan_begin.begin(), st.pan_begin.end());
         tlpair.insert(tlpair.end(), st.tpairs.begin(), st.tpairs.end());
         tlpan.insert(tlpan.end(), st.pan.begin(), st.pan.end());
+        d.order = st.order;
+        if (d.pdim != 15) { d.vp_pr0 = 0; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 0; }
+        else if (d.order) { d.vp_pr0 = 0; d.vp_prs = 15; d.vp_vb0 = 6; d.vp_vbs = 15; }
+        else { d.vp_pr0 = 9 * d.n_free; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 9; }
+        d.tl_kb0 = (int)tlkb.size(); d.tl_k0 = (int)tlk.size();
+        tlkb.insert(tlkb.end(), st.kl_begin.begin(), st.kl_begin.end());
+        tlk.insert(tlk.end(), st.klist.begin(), st.klist.end());
         if ((int)h->step_grid.size() < d.nb) { h->step_grid.resize(d.nb, 1); h->pan_grid.resize(d.nb, 0); h->step_npair_max.resize(d.nb, 0); }
         for (int k = 0; k < d.nb; k++) {
             h->step_grid[k] = std::max(h->step_grid[k], std::max(1, st.step_npairs[k]));
@@ -474,6 +519,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
     if (dalloc(h, BUF_LF, S_tot * 8) || dalloc(h, BUF_YV, (size_t)vec0 * 8)) return -1;
     if (h2d(h, BUF_TLSTEP, tlstep) || h2d(h, BUF_TLPAIR, tlpair) || h2d(h, BUF_TLPANB, tlpanb) || h2d(h, BUF_TLPAN, tlpan)) return -1;
+    if (h2d(h, BUF_TLKB, tlkb) || h2d(h, BUF_TLK, tlk)) return -1;
+    if (dalloc(h, BUF_DVEC, (size_t)vec0 * 8) || dalloc(h, BUF_WINV, (size_t)n * 1024 * 8)) return -1;
     if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
     if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b) || h2d(h, BUF_ITEMBEG, item_begin) || h2d(h, BUF_ITEMS, items)) return -1;
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d(h, BUF_LINBLK, linblk)) return -1;
@@ -515,6 +562,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.Lf = dp<double>(h, BUF_LF); B.yv = dp<double>(h, BUF_YV);
     B.tl_step_begin = dp<int>(h, BUF_TLSTEP); B.tl_pairs = dp<int>(h, BUF_TLPAIR);
     B.tl_pan_begin = dp<int>(h, BUF_TLPANB); B.tl_pan = dp<int>(h, BUF_TLPAN);
+    B.tl_kl_begin = dp<int>(h, BUF_TLKB); B.tl_kl = dp<int>(h, BUF_TLK);
+    B.dvec = dp<double>(h, BUF_DVEC); B.winv = dp<double>(h, BUF_WINV);
     B.var_act = dp<int>(h, BUF_VARACT);
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS);
@@ -559,7 +608,14 @@ void enqueue_solve_iteration(Handle* h) {
         ProfScope ps(h, VBA_PROF_FACTOR);
         static const int split_min = getenv("VBA_SPLIT_MIN") ? atoi(getenv("VBA_SPLIT_MIN")) : 64;
         if (n >= split_min) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
-            for (int k = 0; k < h->max_nb; k++) {
+            static const int left_looking = getenv("VBA_RIGHT_LOOKING") ? 0 : 1;
+            static const int ll_min = getenv("VBA_LL_MIN") ? atoi(getenv("VBA_LL_MIN")) : 384;
+            const bool ll = left_looking && n >= ll_min;  // measured: the right-looking pair is faster up to ~256 windows
+            for (int k = 0; k < h->max_nb && ll; k++) {  // every tile read once, updated in registers, written once
+                hipLaunchKernelGGL(k_chol_diag_ll, dim3(n), dim3(64), 0, h->stream, B, k);
+                if (h->pan_grid[k] > 0) hipLaunchKernelGGL(k_chol_panel_ll, dim3(h->pan_grid[k], n), dim3(64), 0, h->stream, B, k);
+            }
+            for (int k = 0; k < h->max_nb && !ll; k++) {
                 hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (h->pan_grid[k] + 1) / 2), n), dim3(64), 0, h->stream, B, k);
                 if (h->step_npair_max[k] > 0)
                     hipLaunchKernelGGL(k_chol_update, dim3(h->step_npair_max[k], n), dim3(64), 0, h->stream, B, k);
@@ -927,7 +983,7 @@ int vba_debug_buf_id(const char* name) {
     static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
-        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX"};
+        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;

@@ -290,3 +290,27 @@ def test_global_ba_map_scale_properties(ba, oracle):
     assert abs(out[0] - r.chi2_trace[-1]) <= 1e-9 * out[0]
     assert r.chi2_trace[-1] < 0.5 * r.chi2_trace[0]
     assert (q.kf_pose[0] == p.kf_pose[0]).all()
+
+
+@pytest.mark.parametrize("variant,nwin", [(abi.VARIANT_PRV_IDP, 66), (abi.VARIANT_PRV_IDP, 388), (abi.VARIANT_PRV_XYZ, 388),
+                                          (abi.VARIANT_SE3_XYZ, 66), (abi.VARIANT_SE3_XYZ, 388)])
+def test_large_batches_switch_factorisation_kernels(ba, oracle, variant, nwin):
+    """>= 64 windows: split right-looking kernels (k_chol_panel / k_chol_update); >= 384 windows: left-looking tile
+    kernels (k_chol_diag_ll / k_chol_panel_ll).  Same results as the single-window path (fused right-looking kernel)
+    up to rounding, and the oracle's bars."""
+    kw = [dict(n_kf=8, n_pt=200, n_obs=1000), dict(n_kf=13, n_pt=400, n_obs=2200), dict(n_kf=23, n_pt=900, n_obs=5200),
+          dict(n_kf=6, n_pt=60, n_obs=300)]
+    algo = abi.ALGO_GN if variant == abi.VARIANT_PRV_IDP else abi.ALGO_LM
+    ps = [synth.make_window(variant, algo=algo, n_fixed=2 if variant == abi.VARIANT_SE3_XYZ else 1, seed=80 + i, **k) for i, k in enumerate(kw)]
+    batch = [ps[i % 4] for i in range(nwin)]
+    ba.upload(batch); ba.run(); qs, rs = ba.download()
+    for i, p in enumerate(ps):
+        q1, r1 = ba.solve(p)
+        q, r = qs[i], rs[i]
+        assert r.status == 0 and r.its_done == r1.its_done and (r.obs_outlier == r1.obs_outlier).all()
+        np.testing.assert_allclose(r.chi2_trace, r1.chi2_trace, rtol=1e-9)
+        assert np.abs(q.kf_pose - q1.kf_pose).max() < 1e-9 and np.abs(q.pt - q1.pt).max() < 1e-8
+        qo, ro = oracle.solve(p)
+        _check(p, q, r, qo, ro)
+    for i in range(4, nwin):   # twins inside the batch agree bit for bit
+        assert (qs[i].kf_pose == qs[i % 4].kf_pose).all() and rs[i].chi2_vis == rs[i % 4].chi2_vis
