@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="windows per GPU per step")
+    ap.add_argument("--batch", type=int, default=2048, help="windows per GPU per step")
     ap.add_argument("--distinct", type=int, default=16, help="distinct seeded windows generated per rank (cycled to fill the batch)")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba"],
                     help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, for extra measurements")
