@@ -25,6 +25,8 @@ struct Batch {
     unsigned char* lvl;
     double *chi2_e, *depth_e, *chi2_f;  // chi2_f: chi2 recomputed at the final estimates (LM: chi2_e may be stale)
     double *erec, *prec, *slot, *n0rec;
+    const int* slot_perm;         // [n_obs] record position of every observation edge (keyframe-major for inverse-depth windows)
+    const int* pt_perm;           // [n_pt] record position of every landmark (grouped by reference keyframe)
     const unsigned char* kf_fix;  // [n_kf] per-vertex setFixed() of listed-free keyframes: bit0 PR, bit1 V, bit2 Bias
     // IMU factors
     const int *imu_i, *imu_j;
@@ -534,18 +536,19 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
                     G0[gi++] = v * rfm;
                 }
         }
-        double* sr = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + d.n_obs + p);
+        const int pp = B.pt_perm[gp];  // landmark records grouped by reference keyframe
+        double* sr = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + d.n_obs + pp);
 #pragma unroll
         for (int i = 0; i < 6; i++) sr[i] = W0[i] * sD;
         sr[6] = beta;
         sr[7] = sD;
-        double* pr = B.prec + VBA_PREC * gp;
+        double* pr = B.prec + VBA_PREC * (size_t)(d.pt0 + pp);
 #pragma unroll
         for (int i = 0; i < 21; i++) pr[i] = G0[i];
 #pragma unroll
         for (int i = 0; i < 6; i++) pr[21 + i] = g0[i];
         pr[27] = D;
-        double* nr = B.n0rec + VBA_N0REC * gp;
+        double* nr = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + pp);
 #pragma unroll
         for (int i = 0; i < 9; i++) nr[i] = N0[i];
     }
@@ -553,7 +556,7 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
     // D. one lane per edge: slot record; Bi and r into the LDS row for the transposed store
     if (t < ne) {
         const double sD = PT[pl * LIN2_PS + 17], beta = PT[pl * LIN2_PS + 18];
-        double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + e0 + t);
+        double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + B.slot_perm[d.obs0 + e0 + t]);
         double* er = ER + t * LIN2_ES;
 #pragma unroll
         for (int i = 0; i < 6; i++) sl[i] = on ? (Bi[i] * a[0] + Bi[6 + i] * a[1]) * sD : 0.0;
@@ -567,14 +570,15 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
     // E. edge records out (Bi and the weighted residual r; the reader rebuilds g = -Bi^T r and Br = [-A | A N0]),
     //    as contiguous 16-B chunks
     {
-        double* dst = B.erec + VBA_EREC1 * (size_t)(d.obs0 + e0);
+        double* dst = B.erec + VBA_EREC1 * (size_t)d.obs0;
+        const int* perm = B.slot_perm + d.obs0 + e0;
         const int nch = ne * (VBA_EREC1 / 2);
-        for (int ch = t; ch < nch; ch += 256) {
+        for (int ch = t; ch < nch; ch += 256) {  // eight lanes per 128-B record
             const int row = ch / (VBA_EREC1 / 2), col = (ch % (VBA_EREC1 / 2)) * 2;
             double2 v;
             v.x = (col < 14) ? ER[row * LIN2_ES + col] : 0.0;
             v.y = (col < 14) ? ER[row * LIN2_ES + col + 1] : 0.0;
-            *reinterpret_cast<double2*>(dst + (size_t)row * VBA_EREC1 + col) = v;
+            *reinterpret_cast<double2*>(dst + (size_t)perm[row] * VBA_EREC1 + col) = v;
         }
     }
     const double tot = block_sum256(chi, red);
@@ -1539,7 +1543,7 @@ __global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
         if (p >= d.n_pt) return;
         const size_t gp = d.pt0 + p;
         const double* slots = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0);
-        const double* sr = slots + VBA_SLOT * (size_t)(d.n_obs + p);
+        const double* sr = slots + VBA_SLOT * (size_t)(d.n_obs + B.pt_perm[gp]);
         const double sD = sr[7];
         if (!(sD > 0.0)) return;  // landmark outside the active set
         double cl = sr[6];        // beta - sum U . x_p
@@ -1551,7 +1555,7 @@ __global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
         for (int o = ob[p]; o < ob[p + 1]; o++) {
             const int kf = B.obs_kf[d.obs0 + o];
             if (kf >= d.n_free) continue;
-            const double* sl = slots + VBA_SLOT * (size_t)o;
+            const double* sl = slots + VBA_SLOT * (size_t)B.slot_perm[d.obs0 + o];
 #pragma unroll
             for (int i = 0; i < 6; i++) cl -= sl[i] * x[vpos(d, kf, i)];
         }

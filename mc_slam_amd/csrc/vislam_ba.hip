@@ -47,7 +47,7 @@ enum {
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
-    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_N
+    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM, BUF_N
 };
 
 struct ProfEvt {
@@ -140,6 +140,8 @@ struct Structure {
     std::vector<int> step_begin, tpairs, pan_begin, pan;  // tile lists of the factorisation
     std::vector<int> step_npairs;
     std::vector<int> off_pair, pair_mask;
+    std::vector<int> slot_perm;        // record position of every observation edge (see build_structure)
+    std::vector<int> pt_perm;          // record position of every landmark (reference slot, point record, N0)
     int order = 0;                     // elimination order of the reduced system (see build_structure)
     std::vector<int> kl_begin, klist;  // left-looking factorisation: per column entry the steps k < J that update it
 };
@@ -160,6 +162,35 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
             st.pair_b[pidx(a, b)] = b;
         }
     st.obs_pt.resize(P->n_obs);
+    // Where the slot / edge records of observation o live.  Inverse-depth windows keep them KEYFRAME-major (all records of
+    // one observing keyframe contiguous, landmark order inside): the Schur gather of a keyframe pair (a,b) then stays
+    // inside two ~45-KB segments instead of wandering over the whole 2-MB array, and the diagonal pair streams its
+    // segment.  (The observation arrays themselves stay landmark-major, as the caller hands them over.)
+    st.slot_perm.resize(P->n_obs);
+    st.pt_perm.resize(P->n_pt);
+    static const bool no_perm = getenv("VBA_NO_SLOT_PERM") != nullptr;
+    if (P->variant == VBA_VARIANT_PRV_IDP && !no_perm) {
+        // counting sort by observing / reference keyframe (stable: landmark order inside a keyframe)
+        std::vector<int> start(P->n_kf + 1, 0);
+        for (int o = 0; o < P->n_obs; o++) {
+            const int kf = P->obs_kf[o];
+            if (kf < 0 || kf >= P->n_kf) return fail(h, "obs_kf out of range");
+            start[kf + 1]++;
+        }
+        for (int k = 0; k < P->n_kf; k++) start[k + 1] += start[k];
+        for (int o = 0; o < P->n_obs; o++) st.slot_perm[o] = start[P->obs_kf[o]]++;
+        start.assign(P->n_kf + 1, 0);
+        for (int p = 0; p < P->n_pt; p++) {
+            const int rf = P->pt_ref_kf[p];
+            if (rf < 0 || rf >= P->n_kf) return fail(h, "pt_ref_kf out of range");
+            start[rf + 1]++;
+        }
+        for (int k = 0; k < P->n_kf; k++) start[k + 1] += start[k];
+        for (int p = 0; p < P->n_pt; p++) st.pt_perm[p] = start[P->pt_ref_kf[p]]++;
+    } else {
+        for (int o = 0; o < P->n_obs; o++) st.slot_perm[o] = o;
+        for (int p = 0; p < P->n_pt; p++) st.pt_perm[p] = p;
+    }
     std::vector<int> cnt(npairs + 1, 0);
     std::vector<std::pair<int, int>> sl;  // (kf, slot) of one landmark, free keyframes only
     const bool idp = P->variant == VBA_VARIANT_PRV_IDP;
@@ -203,8 +234,8 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
                     else {
                         int* it = &st.items[2 * (size_t)(refpair ? fill2[pi]++ : fill[pi]++)];
                         // slot ids: observation o -> o ; reference keyframe of landmark p -> n_obs + p
-                        it[0] = sl[i1].second >= 0 ? sl[i1].second : P->n_obs + p;
-                        it[1] = sl[i2].second >= 0 ? sl[i2].second : P->n_obs + p;
+                        it[0] = sl[i1].second >= 0 ? st.slot_perm[sl[i1].second] : P->n_obs + st.pt_perm[p];
+                        it[1] = sl[i2].second >= 0 ? st.slot_perm[sl[i2].second] : P->n_obs + st.pt_perm[p];
                     }
                 }
         }
@@ -359,7 +390,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     std::vector<double> pose, vel, bias, pt, uv, ow, meas, info;
     std::vector<unsigned char> kffix;
     std::vector<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
-    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, offpair, pairmask, tlkb, tlk;
+    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, offpair, pairmask, tlkb, tlk, slotperm, ptperm;
     h->step_grid.clear();
     h->pan_grid.clear();
     h->step_npair_max.clear();
@@ -459,6 +490,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         ptobs.insert(ptobs.end(), P->pt_obs_begin, P->pt_obs_begin + d.n_pt + 1);
         obskf.insert(obskf.end(), P->obs_kf, P->obs_kf + d.n_obs);
         obspt.insert(obspt.end(), st.obs_pt.begin(), st.obs_pt.end());
+        slotperm.insert(slotperm.end(), st.slot_perm.begin(), st.slot_perm.end());
+        ptperm.insert(ptperm.end(), st.pt_perm.begin(), st.pt_perm.end());
         uv.insert(uv.end(), P->obs_uv, P->obs_uv + 2 * (size_t)d.n_obs);
         ow.insert(ow.end(), P->obs_w, P->obs_w + d.n_obs);
         if (d.n_imu) {
@@ -519,7 +552,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
     if (dalloc(h, BUF_LF, S_tot * 8) || dalloc(h, BUF_YV, (size_t)vec0 * 8)) return -1;
     if (h2d(h, BUF_TLSTEP, tlstep) || h2d(h, BUF_TLPAIR, tlpair) || h2d(h, BUF_TLPANB, tlpanb) || h2d(h, BUF_TLPAN, tlpan)) return -1;
-    if (h2d(h, BUF_TLKB, tlkb) || h2d(h, BUF_TLK, tlk)) return -1;
+    if (h2d(h, BUF_TLKB, tlkb) || h2d(h, BUF_TLK, tlk) || h2d(h, BUF_SLOTPERM, slotperm) || h2d(h, BUF_PTPERM, ptperm)) return -1;
     if (dalloc(h, BUF_DVEC, (size_t)vec0 * 8) || dalloc(h, BUF_WINV, (size_t)n * 1024 * 8)) return -1;
     if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
     if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b) || h2d(h, BUF_ITEMBEG, item_begin) || h2d(h, BUF_ITEMS, items)) return -1;
@@ -564,6 +597,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.tl_pan_begin = dp<int>(h, BUF_TLPANB); B.tl_pan = dp<int>(h, BUF_TLPAN);
     B.tl_kl_begin = dp<int>(h, BUF_TLKB); B.tl_kl = dp<int>(h, BUF_TLK);
     B.dvec = dp<double>(h, BUF_DVEC); B.winv = dp<double>(h, BUF_WINV);
+    B.slot_perm = dp<int>(h, BUF_SLOTPERM); B.pt_perm = dp<int>(h, BUF_PTPERM);
     B.var_act = dp<int>(h, BUF_VARACT);
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS);
@@ -983,7 +1017,7 @@ int vba_debug_buf_id(const char* name) {
     static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
-        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV"};
+        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
