@@ -139,7 +139,7 @@ def main():
             tr = json.load(open(tj))
             if tr["batch"] == args.batch:
                 kmap = {"schur": ["k_schur_diag", "k_schur_off"], "linearize": ["k_lin2"],
-                        "factor": ["k_chol_step", "k_chol_panel", "k_chol_update"], "trsv": ["k_trsv"], "update": ["k_update"]}
+                        "factor": ["k_chol_step", "k_chol_panel", "k_chol_update", "k_chol_diag_ll", "k_chol_panel_ll"], "trsv": ["k_trsv"], "update": ["k_update"]}
                 ks = [tr["kernels"][k] for k in kmap.get(dom, []) if k in tr["kernels"]]
                 n_it = tr["kernels"]["k_schur_diag"]["active_launches"]
                 n_cls = tr["kernels"]["k_lin2"]["active_launches"] if dom == "linearize" else n_it
