@@ -150,12 +150,18 @@ int vba_preintegrate(void *handle, int32_t n_edges, const int32_t *sample_begin,
 /* ---- IMU-aided per-frame pose optimisation ----
  * Optimizer::PoseOptimization(Frame*, KeyFrame* pLastKF, IMUPreintegrator, gw, bComputeMarg)   src/Optimizer.cpp:2046-2317
  * Optimizer::PoseOptimization(Frame*, Frame*   pLastFrame, IMUPreintegrator, gw, bComputeMarg) src/Optimizer.cpp:1671-2044
+ * Optimizer::PoseOptimization(Frame*)  (vision only, BASELINE configs[0])                        src/Optimizer.cpp:3610-3835
  * Everything between the vertex set-up and the write-back: the four optimize(10) rounds of Levenberg-Marquardt on the
- * 15- or 30-dimensional system, the chi2 > 5.991 reclassification after every round, the kernel removal after the third,
+ * 6-, 15- or 30-dimensional system, the chi2 > 5.991 reclassification after every round, the kernel removal after the third,
  * and computeMarginals.  One call solves a batch of independent frames (one workgroup per frame). */
+#define VBA_FRAME_KF 0
+#define VBA_FRAME_FRAME 1
+#define VBA_FRAME_VISION 2
 #define VBA_NAV_STRIDE 22 /* NavState: P(3) q(4, xyzw) V(3) bg(3) ba(3) dbg(3) dba(3)   src/IMU/NavState.h:124-138 */
 typedef struct vba_frame_problem {
-    int32_t last_is_frame;  /* 0: last keyframe, fixed (:2082-2097).  1: last frame, free, tied to its marginal prior (:1710-1747) */
+    int32_t last_is_frame;  /* VBA_FRAME_*: 0 last keyframe, fixed (:2082-2097); 1 last frame, free, tied to its marginal prior
+                             * (:1710-1747); 2 vision only: nav[0..6] is T_cw as SE3Quat (t, q xyzw), one VertexSE3Expmap +
+                             * EdgeSE3ProjectXYZOnlyPose edges (:3623-3672), no IMU fields are read */
     int32_t compute_marg;   /* bComputeMarg */
     int32_t n_obs;          /* monocular correspondences of the frame (mvpMapPoints[i] != NULL, mvuRight[i] < 0) */
     int32_t n_obs_last;     /* those of the last frame (last_is_frame only) */

@@ -96,6 +96,21 @@ DEVI void po_mono(const FrameDesc& d, const double* nav, const double* Rwb, cons
     }
 }
 
+// EdgeSE3ProjectXYZOnlyPose (types_six_dof_expmap.cpp): error and the 2x6 Jacobian, rotation columns first
+DEVI void po_mono_se3(const FrameDesc& d, const double* T, const double* Pw, const double* uv, double* e, double* J0, double* J1) {
+    double Pc[3];
+    qrot(T + 3, Pw, Pc);  // SE3Quat::map, se3quat.h:217-220
+    Pc[0] += T[0]; Pc[1] += T[1]; Pc[2] += T[2];
+    const double fx = d.K[0], fy = d.K[1], cx = d.K[2], cy = d.K[3];
+    e[0] = uv[0] - (Pc[0] / Pc[2] * fx + cx);
+    e[1] = uv[1] - (Pc[1] / Pc[2] * fy + cy);
+    if (J0) {
+        const double x = Pc[0], y = Pc[1], z = Pc[2], z_2 = z * z;
+        J0[0] = x * y / z_2 * fx; J0[1] = -(1 + (x * x / z_2)) * fx; J0[2] = y / z * fx; J0[3] = -1. / z * fx; J0[4] = 0; J0[5] = x / z_2 * fx;
+        J1[0] = (1 + y * y / z_2) * fy; J1[1] = -x * y / z_2 * fy; J1[2] = -x / z * fy; J1[3] = 0; J1[4] = -1. / z * fy; J1[5] = y / z_2 * fy;
+    }
+}
+
 // EdgeNavStatePVR::computeError (g2otypes.cpp:529-585): rows rP, rV, rPhi
 DEVI void po_pvr_error(const FrameDesc& d, const double* ni, const double* nj, double* e) {
     const double* meas = d.meas;
@@ -255,6 +270,19 @@ DEVI double po_errors(const PoseBatch& B, const FrameDesc& d, double* sm, int vi
     const int t = threadIdx.x;
     const double *cur = sm + PO_CUR, *last = sm + PO_LAST;
     double chi = 0.0;
+    if (d.last_is_frame == 2) {  // vision only: one VertexSE3Expmap, no IMU edges
+        for (int i = t; i < d.n_obs; i += 64) {
+            const size_t g = (size_t)d.obs0 + i;
+            if (B.lvl[g]) continue;
+            double e[2], w;
+            po_mono_se3(d, cur, B.pw + 3 * g, B.uv + 2 * g, e, nullptr, nullptr);
+            B.err[2 * g] = e[0]; B.err[2 * g + 1] = e[1];
+            const double wt = B.w[g];
+            const double s = e[0] * (wt * e[0]) + e[1] * (wt * e[1]);
+            chi += vis_robust ? huber(s, d.hub_mono, &w) : s;
+        }
+        return po_wave_sum(chi);
+    }
     if (t == 0) {
         double e[15], w;
         if (d.last_is_frame) {
@@ -294,11 +322,47 @@ DEVI double po_errors(const PoseBatch& B, const FrameDesc& d, double* sm, int vi
 
 // buildSystem at the state whose errors were just computed
 DEVI void po_build(const PoseBatch& B, const FrameDesc& d, double* sm, int vis_robust) {
-    const int t = threadIdx.x, n = d.last_is_frame ? 30 : 15;
+    const int t = threadIdx.x, n = (d.last_is_frame == 2) ? 6 : (d.last_is_frame ? 30 : 15);
     double *cur = sm + PO_CUR, *last = sm + PO_LAST;
     for (int q = t; q < 900; q += 64) sm[PO_H + q] = 0.0;
     if (t < 30) sm[PO_B + t] = 0.0;
     __syncthreads();
+    if (d.last_is_frame == 2) {
+        double acc[21], bb[6];
+#pragma unroll
+        for (int i = 0; i < 21; i++) acc[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) bb[i] = 0;
+        for (int i = t; i < d.n_obs; i += 64) {
+            const size_t g = (size_t)d.obs0 + i;
+            if (B.lvl[g]) continue;
+            double e[2], J0[6], J1[6], rw = 1.0;
+            po_mono_se3(d, cur, B.pw + 3 * g, B.uv + 2 * g, e, J0, J1);
+            const double wt = B.w[g];
+            if (vis_robust) huber(e[0] * (wt * e[0]) + e[1] * (wt * e[1]), d.hub_mono, &rw);
+            const double Wt = rw * wt;
+            int gi = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                bb[a] -= J0[a] * Wt * e[0] + J1[a] * Wt * e[1];
+#pragma unroll
+                for (int c = a; c < 6; c++) acc[gi++] += J0[a] * Wt * J0[c] + J1[a] * Wt * J1[c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 21; i++) acc[i] = po_wave_sum(acc[i]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) bb[i] = po_wave_sum(bb[i]);
+        if (t == 0) {
+            int gi = 0;
+            for (int a = 0; a < 6; a++) {
+                sm[PO_B + a] = bb[a];
+                for (int c = a; c < 6; c++) { sm[PO_H + a * 6 + c] = acc[gi]; sm[PO_H + c * 6 + a] = acc[gi]; gi++; }
+            }
+        }
+        __syncthreads();
+        return;
+    }
     // vision edges: 21 + 6 sums per frame, lane-strided then reduced in a fixed order
     const double dm = d.hub_mono;
     for (int pass = 0; pass < (d.last_is_frame ? 2 : 1); pass++) {
@@ -486,9 +550,10 @@ __global__ void __launch_bounds__(64) k_pose_opt(PoseBatch B) {
     if (f >= B.n_frames) return;
     const FrameDesc& d = B.desc[f];
     FrameOut& out = B.out[f];
-    const int n = d.last_is_frame ? 30 : 15;
+    const bool vision = d.last_is_frame == 2, lif = d.last_is_frame == 1;
+    const int n = vision ? 6 : (lif ? 30 : 15);
     for (int i = t; i < d.n_obs; i += 64) B.lvl[(size_t)d.obs0 + i] = 0;  // pFrame->mvbOutlier[i] = false, :2147
-    if (d.last_is_frame)
+    if (lif)
         for (int i = t; i < d.n_last; i += 64) B.lvl[(size_t)d.last0 + i] = 0;
     if (t == 0) {
         out.n_inliers = 0; out.status = 0;
@@ -498,7 +563,7 @@ __global__ void __launch_bounds__(64) k_pose_opt(PoseBatch B) {
     for (int q = t; q < 225; q += 64) out.marg[q] = 0.0;
     if (d.n_obs < 3) return;  // nInitialCorrespondences < 3, :2178
     int vis_robust = 1, nBad = 0;
-    const int n_edges = d.n_obs + 2 + (d.last_is_frame ? d.n_last + 1 : 0);
+    const int n_edges = d.n_obs + (vision ? 0 : 2) + (lif ? d.n_last + 1 : 0);
     for (int round = 0; round < 4; round++) {
         if (t < 22) { sm[PO_CUR + t] = d.nav[t]; sm[PO_LAST + t] = d.nav_last[t]; }  // setEstimate(...) before every round
         __syncthreads();
@@ -524,8 +589,11 @@ __global__ void __launch_bounds__(64) k_pose_opt(PoseBatch B) {
                 __syncthreads();
                 const bool ok2 = po_solve(sm, n, lambda);
                 if (ok2 && t == 0) {
-                    po_oplus(sm + PO_CUR, sm + PO_X, sm + PO_X + 9);
-                    if (n == 30) po_oplus(sm + PO_LAST, sm + PO_X + 15, sm + PO_X + 24);
+                    if (vision) se3_oplus(sm + PO_CUR, sm + PO_X);  // VertexSE3Expmap::oplusImpl
+                    else {
+                        po_oplus(sm + PO_CUR, sm + PO_X, sm + PO_X + 9);
+                        if (n == 30) po_oplus(sm + PO_LAST, sm + PO_X + 15, sm + PO_X + 24);
+                    }
                 }
                 __syncthreads();
                 double tempChi = po_errors(B, d, sm, vis_robust);
@@ -558,7 +626,7 @@ __global__ void __launch_bounds__(64) k_pose_opt(PoseBatch B) {
         }
         if (t == 0) { out.its[round] = cj; out.chi2_round[round] = cur; }
         // ---- reclassification (:2193-2219): chi2 from the stored error, recomputed for the edges that sat out ----
-        for (int pass = 0; pass < (d.last_is_frame ? 2 : 1); pass++) {
+        for (int pass = 0; pass < (lif ? 2 : 1); pass++) {
             const int N = pass ? d.n_last : d.n_obs, o0 = pass ? d.last0 : d.obs0;
             const double* nav = sm + (pass ? PO_LAST : PO_CUR);
             double Rwb[9];
@@ -568,7 +636,8 @@ __global__ void __launch_bounds__(64) k_pose_opt(PoseBatch B) {
                 const size_t g = (size_t)o0 + i;
                 double e[2] = {B.err[2 * g], B.err[2 * g + 1]};
                 if (B.lvl[g]) {
-                    po_mono(d, nav, Rwb, B.pw + 3 * g, B.uv + 2 * g, e, nullptr, nullptr);
+                    if (vision) po_mono_se3(d, nav, B.pw + 3 * g, B.uv + 2 * g, e, nullptr, nullptr);
+                    else po_mono(d, nav, Rwb, B.pw + 3 * g, B.uv + 2 * g, e, nullptr, nullptr);
                     B.err[2 * g] = e[0]; B.err[2 * g + 1] = e[1];
                 }
                 const double wt = B.w[g];
@@ -585,16 +654,17 @@ __global__ void __launch_bounds__(64) k_pose_opt(PoseBatch B) {
         if (n_edges < 10) break;         // optimizer.edges().size() < 10
     }
     if (t == 0) {
-        for (int k = 0; k < 10; k++) out.nav[k] = sm[PO_CUR + k];
-        for (int k = 16; k < 22; k++) out.nav[k] = sm[PO_CUR + k];
+        for (int k = 0; k < (vision ? 7 : 10); k++) out.nav[k] = sm[PO_CUR + k];
+        if (!vision)
+            for (int k = 16; k < 22; k++) out.nav[k] = sm[PO_CUR + k];
         out.n_inliers = d.n_obs - nBad;
     }
-    if (d.compute_marg) {
+    if (d.compute_marg && !vision) {
         // computeMarginals on the Hessian of the last linearisation (:2244-2254 / :2005-2019)
         __syncthreads();
         double* Hi = sm + PO_H;  // H itself is no longer needed
         po_inverse(sm, sm + PO_HL, n, n, Hi, n);
-        if (!d.last_is_frame) {
+        if (!lif) {
             double* tmp = sm + PO_HL;
             po_inverse(sm, Hi, n, 9, tmp, 9);
             for (int q = t; q < 81; q += 64) out.marg[15 * (q / 9) + q % 9] = tmp[q];

@@ -1100,8 +1100,8 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
         const vba_frame_problem* F = inout[f];
         if (!F || !out[f] || F->n_obs < 0 || (F->n_obs > 0 && (!F->obs_pw || !F->obs_uv || !F->obs_w || !out[f]->outlier)))
             return fail(h, "vba_pose_optimize: bad frame");
-        if (F->last_is_frame && F->n_obs_last > 0 && (!F->last_pw || !F->last_uv || !F->last_w)) return fail(h, "vba_pose_optimize: bad last frame");
-        n_tot += (size_t)F->n_obs + (F->last_is_frame ? (size_t)F->n_obs_last : 0);
+        if (F->last_is_frame == VBA_FRAME_FRAME && F->n_obs_last > 0 && (!F->last_pw || !F->last_uv || !F->last_w)) return fail(h, "vba_pose_optimize: bad last frame");
+        n_tot += (size_t)F->n_obs + (F->last_is_frame == VBA_FRAME_FRAME ? (size_t)F->n_obs_last : 0);
     }
     std::vector<double> pw(3 * n_tot + 3), uv(2 * n_tot + 2), ww(n_tot + 1);
     size_t o = 0;
@@ -1109,10 +1109,11 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
         const vba_frame_problem* F = inout[f];
         FrameDesc& d = desc[f];
         std::memset(&d, 0, sizeof d);
-        d.last_is_frame = F->last_is_frame ? 1 : 0;
+        if (F->last_is_frame < 0 || F->last_is_frame > 2) return fail(h, "vba_pose_optimize: unknown frame kind");
+        d.last_is_frame = F->last_is_frame;
         d.compute_marg = F->compute_marg ? 1 : 0;
         d.n_obs = F->n_obs;
-        d.n_last = d.last_is_frame ? F->n_obs_last : 0;
+        d.n_last = (d.last_is_frame == VBA_FRAME_FRAME) ? F->n_obs_last : 0;
         d.obs0 = (int)o;
         std::memcpy(&pw[3 * o], F->obs_pw, 24 * (size_t)d.n_obs);
         std::memcpy(&uv[2 * o], F->obs_uv, 16 * (size_t)d.n_obs);
@@ -1133,7 +1134,7 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
         quat_to_R_host(F->T_cb + 3, d.Rcb);
         for (int i = 0; i < 3; i++) { d.tcb[i] = F->T_cb[i]; d.g[i] = F->g_w[i]; }
         std::memcpy(d.meas, F->imu_meas, sizeof d.meas);
-        inverse_host(9, F->imu_cov_pvphi, d.info_pvr);   // Matrix9d InvCovPVR = imupreint.getCovPVPhi().inverse(), :2103
+        if (F->last_is_frame != VBA_FRAME_VISION) inverse_host(9, F->imu_cov_pvphi, d.info_pvr);   // Matrix9d InvCovPVR = imupreint.getCovPVPhi().inverse(), :2103
         d.inv_bg = F->inv_bg_rw2; d.inv_ba = F->inv_ba_rw2;
         d.hub_prior = (double)(float)std::sqrt(30.5779); d.hub_pvr = (double)(float)std::sqrt(21.666);
         d.hub_bias = (double)(float)std::sqrt(16.812); d.hub_mono = (double)(float)std::sqrt(5.991);

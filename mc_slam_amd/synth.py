@@ -416,3 +416,24 @@ def make_frame(seed=5, n_obs=300, last_is_frame=False, compute_marg=True, noise=
     f.truth = dict(nav=np.concatenate([gt["pose"][CUR], gt["vel"][CUR]]), is_outlier=gt["is_outlier"][sel_c],
                    is_outlier_last=gt["is_outlier"][sel_l])
     return f
+
+
+def make_frame_vision(seed=1, n_obs=200, noise=True, outlier_frac=0.1, pt_noise=0.01):
+    """BASELINE configs[0] (C1): one frame, ~200 monocular correspondences, vision-only Optimizer::PoseOptimization(Frame*)
+    (src/Optimizer.cpp:3610-3835).  nav[0..6] = T_cw as SE3Quat, float32-narrowed like pFrame->mTcw; points float32."""
+    f = make_frame(seed=seed, n_obs=n_obs, noise=noise, outlier_frac=outlier_frac, pt_noise=pt_noise)
+    R_bc, p_bc, _ = extrinsics()
+
+    def tcw(nav):
+        Rwb = quat_to_rot(nav[3:7])
+        Rcw = (Rwb @ R_bc).T
+        t = -Rcw @ (Rwb @ p_bc + nav[:3])
+        T = np.float32(np.concatenate([Rcw.reshape(-1), t])).astype(np.float64)
+        return np.concatenate([T[9:], rot_to_quat(_orthonormalise(T[:9].reshape(3, 3)))])
+    nav = np.zeros(abi.NAV_STRIDE); nav[:7] = tcw(f.nav)
+    g = abi.FrameProblem(nav=nav, nav_last=np.zeros(abi.NAV_STRIDE), obs_pw=np.float32(f.obs_pw).astype(np.float64), obs_uv=f.obs_uv,
+                         obs_w=f.obs_w, K=f.K, T_cb=f.T_cb, g_w=f.g_w, imu_meas=f.imu_meas, imu_cov_pvphi=f.imu_cov_pvphi,
+                         last_is_frame=2, compute_marg=0)
+    gt = np.concatenate([f.truth["nav"][:7], np.zeros(3)])
+    g.truth = dict(T_cw=tcw(gt), is_outlier=f.truth["is_outlier"])
+    return g

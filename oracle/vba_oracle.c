@@ -1558,6 +1558,16 @@ static void frame_prior_error(const vba_frame_problem *F, const double *nl, doub
 static double frame_errors(fctx *c) {
     const vba_frame_problem *F = c->F;
     double chi = 0, rho[3];
+    if (F->last_is_frame == VBA_FRAME_VISION) { /* EdgeSE3ProjectXYZOnlyPose only (src/Optimizer.cpp:3640-3672) */
+        const double dm = (double)(float)sqrt(5.991);
+        for (int i = 0; i < F->n_obs; i++) {
+            if (c->lvl[i]) continue;
+            vbo_edge_se3xyz(F->obs_pw + 3 * i, c->cur, F->K, F->obs_uv + 2 * i, c->err + 2 * i, NULL, NULL, NULL);
+            const double s = chi2_2(c->err + 2 * i, F->obs_w[i]);
+            if (c->vis_robust) { vbo_huber(s, dm, rho); chi += rho[0]; } else chi += s;
+        }
+        return chi;
+    }
     if (F->last_is_frame) {
         frame_prior_error(F, c->last, c->e_prior);
         vbo_huber(quadform(c->e_prior, F->prior_info, 15), (double)(float)sqrt(30.5779), rho);
@@ -1624,6 +1634,22 @@ static void frame_build(fctx *c) {
     memset(c->H, 0, sizeof c->H);
     memset(c->b, 0, sizeof c->b);
     double rho[3];
+    if (lf == VBA_FRAME_VISION) {
+        const double dm = (double)(float)sqrt(5.991);
+        for (int i = 0; i < F->n_obs; i++) {
+            if (c->lvl[i]) continue;
+            double e[2], Jp[6], J[12];
+            vbo_edge_se3xyz(F->obs_pw + 3 * i, c->cur, F->K, F->obs_uv + 2 * i, e, NULL, Jp, J);
+            double rw = 1.0;
+            if (c->vis_robust) { vbo_huber(chi2_2(e, F->obs_w[i]), dm, rho); rw = rho[1]; }
+            const double Wt = rw * F->obs_w[i];
+            for (int a = 0; a < 6; a++) {
+                c->b[a] -= J[a] * Wt * e[0] + J[6 + a] * Wt * e[1];
+                for (int bb = 0; bb < 6; bb++) c->H[a * n + bb] += J[a] * Wt * J[bb] + J[6 + a] * Wt * J[6 + bb];
+            }
+        }
+        return;
+    }
     if (lf) {
         double J0[135], J1[90], JrI[9];
         memset(J0, 0, sizeof J0);
@@ -1735,8 +1761,14 @@ static int frame_lm(fctx *c, int iterations, double *chi_out) {
             for (int i = 0; i < n; i++) A[i * n + i] += lambda;
             const int ok2 = chol_solve_dense(n, A, c->b, c->x);
             if (ok2) {
-                nav_oplus(c->cur, c->x, c->x + 9);
-                if (n == 30) nav_oplus(c->last, c->x + 15, c->x + 24);
+                if (n == 6) { /* VertexSE3Expmap::oplusImpl: SE3Quat::exp(update) * estimate */
+                    double E[7];
+                    vbo_se3_exp(c->x, E);
+                    se3_mul(E, c->cur, c->cur);
+                } else {
+                    nav_oplus(c->cur, c->x, c->x + 9);
+                    if (n == 30) nav_oplus(c->last, c->x + 15, c->x + 24);
+                }
             }
             tempChi = frame_errors(c);
             if (!ok2) tempChi = DBL_MAX;
@@ -1803,13 +1835,14 @@ int vba_oracle_pose_optimize(vba_frame_problem *F, vba_frame_result *out) {
     fctx C, *c = &C;
     memset(c, 0, sizeof C);
     c->F = F;
-    c->n = F->last_is_frame ? 30 : 15;
+    const int vision = F->last_is_frame == VBA_FRAME_VISION, lif = F->last_is_frame == VBA_FRAME_FRAME;
+    c->n = vision ? 6 : (lif ? 30 : 15);
     c->lvl = calloc(F->n_obs + 1, 1);
     c->err = calloc(2 * F->n_obs + 2, 8);
     c->lvl_last = calloc(F->n_obs_last + 1, 1);
     c->err_last = calloc(2 * F->n_obs_last + 2, 8);
-    dense_inverse(9, F->imu_cov_pvphi, c->info_pvr);       /* Matrix9d InvCovPVR = imupreint.getCovPVPhi().inverse() */
-    if (F->last_is_frame && out->outlier_last)
+    if (!vision) dense_inverse(9, F->imu_cov_pvphi, c->info_pvr);       /* Matrix9d InvCovPVR = imupreint.getCovPVPhi().inverse() */
+    if (lif && out->outlier_last)
         for (int i = 0; i < F->n_obs_last; i++) out->outlier_last[i] = 0;
     c->vis_robust = 1;
     int nBad = 0;
@@ -1818,13 +1851,15 @@ int vba_oracle_pose_optimize(vba_frame_problem *F, vba_frame_result *out) {
         memcpy(c->last, F->nav_last, sizeof c->last);
         out->its_done[it] = frame_lm(c, 10, &out->chi2_round[it]);
         const double dm2 = 5.991;
-        for (int pass = 0; pass < (F->last_is_frame ? 2 : 1); pass++) {
+        for (int pass = 0; pass < (lif ? 2 : 1); pass++) {
             const int N = pass ? F->n_obs_last : F->n_obs;
             unsigned char *lvl = pass ? c->lvl_last : c->lvl;
             double *err = pass ? c->err_last : c->err;
             int bad = 0;
             for (int i = 0; i < N; i++) {
-                if (lvl[i]) /* outliers are outside the active set: their error is recomputed at the final estimate */
+                if (lvl[i] && vision)
+                    vbo_edge_se3xyz(F->obs_pw + 3 * i, c->cur, F->K, F->obs_uv + 2 * i, err + 2 * i, NULL, NULL, NULL);
+                else if (lvl[i]) /* outliers are outside the active set: their error is recomputed at the final estimate */
                     frame_mono(F, pass ? c->last : c->cur, (pass ? F->last_pw : F->obs_pw) + 3 * i, (pass ? F->last_uv : F->obs_uv) + 2 * i, err + 2 * i, NULL);
                 const float chi2 = (float)chi2_2(err + 2 * i, (pass ? F->last_w : F->obs_w)[i]); /* const float chi2 = e->chi2() */
                 if (chi2 > (float)dm2) { lvl[i] = 1; bad++; } else lvl[i] = 0;
@@ -1832,19 +1867,22 @@ int vba_oracle_pose_optimize(vba_frame_problem *F, vba_frame_result *out) {
             if (!pass) nBad = bad;
         }
         if (it == 2) c->vis_robust = 0;                    /* e->setRobustKernel(0) */
-        if (F->n_obs + F->n_obs_last * (F->last_is_frame ? 1 : 0) + 2 + (F->last_is_frame ? 1 : 0) < 10) break; /* optimizer.edges().size() < 10 */
+        if (F->n_obs + (lif ? F->n_obs_last + 1 : 0) + (vision ? 0 : 2) < 10) break; /* optimizer.edges().size() < 10 */
     }
-    memcpy(F->nav, c->cur, 10 * sizeof(double));            /* P, R, V of the PVR vertex */
-    memcpy(F->nav + 16, c->cur + 16, 6 * sizeof(double));   /* dbg, dba of the bias vertex */
+    if (vision) memcpy(F->nav, c->cur, 7 * sizeof(double)); /* pFrame->SetPose(Converter::toCvMat(SE3quat_recov)) */
+    else {
+        memcpy(F->nav, c->cur, 10 * sizeof(double));            /* P, R, V of the PVR vertex */
+        memcpy(F->nav + 16, c->cur + 16, 6 * sizeof(double));   /* dbg, dba of the bias vertex */
+    }
     for (int i = 0; i < F->n_obs; i++) out->outlier[i] = c->lvl[i];
-    if (F->last_is_frame && out->outlier_last)
+    if (lif && out->outlier_last)
         for (int i = 0; i < F->n_obs_last; i++) out->outlier_last[i] = c->lvl_last[i];
     out->n_inliers = F->n_obs - nBad;
-    if (F->compute_marg) {
+    if (F->compute_marg && !vision) {
         /* computeMarginals on the Hessian of the last linearisation (lambda already restored) */
         double Hi[900];
         dense_inverse(c->n, c->Hlast, Hi);
-        if (!F->last_is_frame) {
+        if (!lif) {
             /* margCovInv = blockdiag(spinv(0,0)^-1, spinv(1,1)^-1), :2251-2253 */
             double A[81], Ai[81], B[36], Bi[36];
             for (int i = 0; i < 9; i++)
@@ -1875,12 +1913,12 @@ int vba_oracle_frame_linearize(vba_frame_problem *F, double *H, double *b, doubl
     fctx C, *c = &C;
     memset(c, 0, sizeof C);
     c->F = F;
-    c->n = F->last_is_frame ? 30 : 15;
+    c->n = F->last_is_frame == VBA_FRAME_VISION ? 6 : (F->last_is_frame ? 30 : 15);
     c->lvl = calloc(F->n_obs + 1, 1);
     c->err = calloc(2 * F->n_obs + 2, 8);
     c->lvl_last = calloc(F->n_obs_last + 1, 1);
     c->err_last = calloc(2 * F->n_obs_last + 2, 8);
-    dense_inverse(9, F->imu_cov_pvphi, c->info_pvr);
+    if (F->last_is_frame != VBA_FRAME_VISION) dense_inverse(9, F->imu_cov_pvphi, c->info_pvr);
     c->vis_robust = 1;
     memcpy(c->cur, F->nav, sizeof c->cur);
     memcpy(c->last, F->nav_last, sizeof c->last);

@@ -212,7 +212,7 @@ def pose_optimize(f: abi.FrameProblem):
 
 
 def frame_linearize(f: abi.FrameProblem, want_H=True):
-    n = 30 if f.last_is_frame else 15
+    n = {0: 15, 1: 30, 2: 6}[int(f.last_is_frame)]
     H = np.zeros((n, n)); b = np.zeros(n); chi = C.c_double(0)
     s = f.as_struct()
     fn = lib().vba_oracle_frame_linearize

@@ -59,3 +59,22 @@ def test_noise_free_frame_recovers_the_truth(ba):
     r = ba.pose_optimize([f])[0]
     assert r.outlier.sum() == 0 and r.n_inliers == 200
     assert np.abs(r.nav[:3] - f.truth["nav"][:3]).max() < 1e-3
+
+
+def test_c1_vision_only_pose_optimization_matches_oracle(ba, oracle):
+    """BASELINE configs[0]: Optimizer::PoseOptimization(Frame*) on one frame with ~200 monocular correspondences
+    (src/Optimizer.cpp:3610-3835), seed 1 -- and a batch that mixes all three frame kinds."""
+    f = synth.make_frame_vision(seed=1, n_obs=200)
+    r = ba.pose_optimize([f])[0]
+    ro = oracle.pose_optimize(f)
+    assert r.its_done == ro.its_done and (r.outlier == ro.outlier).all() and r.n_inliers == ro.n_inliers
+    np.testing.assert_allclose(r.chi2_round, ro.chi2_round, rtol=1e-7)
+    assert np.abs(r.nav[:3] - ro.nav[:3]).max() <= 1e-6 and np.abs(r.nav[3:7] - ro.nav[3:7]).max() <= 1e-7
+    assert (r.nav[7:] == 0).all() and r.outlier.sum() > 0
+    mix = [synth.make_frame_vision(seed=2, n_obs=150), synth.make_frame(seed=3, n_obs=100), synth.make_frame(seed=4, n_obs=100, last_is_frame=True), f]
+    rs = ba.pose_optimize(mix)
+    for g, rr in zip(mix, rs):
+        rq = oracle.pose_optimize(g)
+        assert rr.its_done == rq.its_done and (rr.outlier == rq.outlier).all()
+        assert np.abs(rr.nav[:7] - rq.nav[:7]).max() <= 1e-6
+    assert (rs[-1].nav == r.nav).all()

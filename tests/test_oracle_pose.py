@@ -71,3 +71,28 @@ def test_marginal_of_keyframe_variant_matches_numpy(oracle):
     Hi = np.linalg.inv(H)
     np.testing.assert_allclose(r.marg_cov_inv[:9, :9], np.linalg.inv(Hi[:9, :9]), rtol=1e-4, atol=1e-6 * np.abs(r.marg_cov_inv).max())
     np.testing.assert_allclose(r.marg_cov_inv[9:, 9:], np.linalg.inv(Hi[9:, 9:]), rtol=1e-4, atol=1e-6 * np.abs(r.marg_cov_inv).max())
+
+
+# ---- vision-only PoseOptimization(Frame*): BASELINE configs[0] (C1: one frame, ~200 observations, seed 1) ----
+def test_c1_vision_only_pose_optimization(oracle):
+    f = synth.make_frame_vision(seed=1, n_obs=200)
+    H, b, chi0 = oracle.frame_linearize(f)
+    assert H.shape == (6, 6) and np.linalg.eigvalsh(H).min() > 0
+    h = 1e-6
+    for i in range(6):   # b = -1/2 d chi2 / d xi through SE3Quat::exp(xi) * T (left-multiplicative, rotation first)
+        vals = []
+        for sgn in (+1, -1):
+            d = np.zeros(6); d[i] = sgn * h
+            g = f.copy(); g.nav = f.nav.copy()
+            T = g.nav[:7].copy(); oracle.call("vbo_oplus_se3", T, d); g.nav[:7] = T
+            vals.append(oracle.frame_linearize(g, want_H=False)[2])
+        grad = (vals[0] - vals[1]) / (2 * h)
+        assert abs(-0.5 * grad - b[i]) <= 2e-4 * max(1.0, abs(b[i])), (i, -0.5 * grad, b[i])
+    r = oracle.pose_optimize(f)
+    assert r.status == 0 and all(1 <= k <= 10 for k in r.its_done)
+    planted = f.truth["is_outlier"]
+    assert (r.outlier.astype(bool) & planted).sum() >= 0.95 * planted.sum()
+    assert r.n_inliers == f.n_obs - int(r.outlier.sum())
+    assert np.abs(r.nav[:3] - f.truth["T_cw"][:3]).max() < 0.03 < 1.0
+    assert np.abs(r.nav[:3] - f.truth["T_cw"][:3]).max() < np.abs(f.nav[:3] - f.truth["T_cw"][:3]).max()
+    assert (r.nav[7:] == 0).all() and (r.marg_cov_inv == 0).all()
