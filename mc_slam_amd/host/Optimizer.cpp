@@ -283,15 +283,22 @@ void Optimizer::LocalBAPRVIDP(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLoc
 }
 
 // ------------------------------------------------------------------------------------------------
-bool Optimizer::PackLocalBundleAdjustment(KeyFrame* pKF, PackedWindow& W) {
+bool Optimizer::PackLocalBundleAdjustment(KeyFrame* pKF, PackedWindow& W) { return PackLocalBundleAdjustment(pKF, nullptr, W); }
+
+bool Optimizer::PackLocalBundleAdjustment(KeyFrame* pKF, const std::list<KeyFrame*>* pList, PackedWindow& W) {
     W = PackedWindow();
     std::memset(&W.P, 0, sizeof W.P);
-    std::list<KeyFrame*> lLocalKeyFrames;                                                                         // :3861-3875
-    lLocalKeyFrames.push_back(pKF);
-    pKF->mnBALocalForKF = pKF->mnId;
-    for (KeyFrame* pKFi : pKF->GetVectorCovisibleKeyFrames()) {
-        pKFi->mnBALocalForKF = pKF->mnId;
-        if (!pKFi->isBad()) lLocalKeyFrames.push_back(pKFi);
+    std::list<KeyFrame*> lLocalKeyFrames;
+    if (pList) {                                                                                                  // :2981-2986
+        lLocalKeyFrames = *pList;
+        for (KeyFrame* pKFi : lLocalKeyFrames) pKFi->mnBALocalForKF = pKF->mnId;
+    } else {                                                                                                      // :3861-3875
+        lLocalKeyFrames.push_back(pKF);
+        pKF->mnBALocalForKF = pKF->mnId;
+        for (KeyFrame* pKFi : pKF->GetVectorCovisibleKeyFrames()) {
+            pKFi->mnBALocalForKF = pKF->mnId;
+            if (!pKFi->isBad()) lLocalKeyFrames.push_back(pKFi);
+        }
     }
     std::list<MapPoint*> lLocalMapPoints;                                                                         // :3878-3895
     for (KeyFrame* pKFi : lLocalKeyFrames)
@@ -301,6 +308,13 @@ bool Optimizer::PackLocalBundleAdjustment(KeyFrame* pKF, PackedWindow& W) {
                 pMP->mnBALocalForKF = pKF->mnId;
             }
     std::list<KeyFrame*> lFixedCameras;                                                                           // :3898-3915
+    if (pList) {   // the keyframe before the window is fixed first (:3005-3023)
+        KeyFrame* pKFPrevLocal = lLocalKeyFrames.front()->GetPrevKeyFrame();
+        if (pKFPrevLocal) {
+            pKFPrevLocal->mnBAFixedForKF = pKF->mnId;
+            if (!pKFPrevLocal->isBad()) lFixedCameras.push_back(pKFPrevLocal);
+        }
+    }
     for (MapPoint* pMP : lLocalMapPoints)
         for (auto& mit : pMP->GetObservations()) {
             KeyFrame* pKFi = mit.first;
@@ -358,9 +372,19 @@ bool Optimizer::PackLocalBundleAdjustment(KeyFrame* pKF, PackedWindow& W) {
     return true;
 }
 
+void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, bool* pbStopFlag, Map* pMap,
+                                      LocalMapping* pLM) {
+    if (pKF != lLocalKeyFrames.back()) std::cerr << "pKF != lLocalKeyFrames.back. check" << std::endl;                // :2978-2979
+    LocalBundleAdjustmentImpl(pKF, &lLocalKeyFrames, pbStopFlag, pMap, pLM);
+}
+
 void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, LocalMapping* pLM) {
+    LocalBundleAdjustmentImpl(pKF, nullptr, pbStopFlag, pMap, pLM);
+}
+
+void Optimizer::LocalBundleAdjustmentImpl(KeyFrame* pKF, const std::list<KeyFrame*>* pList, bool* pbStopFlag, Map* pMap, LocalMapping* pLM) {
     PackedWindow& W = t_last;
-    if (!PackLocalBundleAdjustment(pKF, W)) return;
+    if (!PackLocalBundleAdjustment(pKF, pList, W)) return;
     if (pbStopFlag && *pbStopFlag) return;                                                                        // :4088-4090
     void* h = handle();
     if (!h) { std::cerr << "LocalBundleAdjustment: no HIP device, local BA skipped (the backend has no CPU path)" << std::endl; return; }
@@ -595,6 +619,177 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std:
     }
     // the fixed keyframe is written back too in the reference (its estimate did not move): a float32 round trip
     WriteBackMapPoints(W, nLoopKF);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-frame pose optimisation (src/Optimizer.cpp:3610-3835, 2046-2317, 1671-2044): set-up and write-back here, the four
+// optimize(10) rounds + reclassification + marginals behind vba_pose_optimize.
+// ------------------------------------------------------------------------------------------------
+namespace {
+void NavToArray(const NavState& ns, double* v) {
+    const Vector3d P = ns.Get_P(), V = ns.Get_V(), bg = ns.Get_BiasGyr(), ba = ns.Get_BiasAcc(), dbg = ns.Get_dBias_Gyr(), dba = ns.Get_dBias_Acc();
+    const Quaterniond q = ns.Get_R();
+    const double a[22] = {P[0], P[1], P[2], q[0], q[1], q[2], q[3], V[0], V[1], V[2], bg[0], bg[1], bg[2], ba[0], ba[1], ba[2],
+                          dbg[0], dbg[1], dbg[2], dba[0], dba[1], dba[2]};
+    std::memcpy(v, a, sizeof a);
+}
+struct FrameObs {
+    std::vector<double> pw, uv, w;
+    std::vector<size_t> idx;
+    std::vector<uint8_t> outl;
+};
+// monocular correspondences of a frame (:2137-2172); resets mvbOutlier like the reference does
+void GatherFrame(Frame* f, FrameObs& o) {
+    for (int i = 0; i < f->N; i++) {
+        MapPoint* pMP = f->mvpMapPoints[i];
+        if (!pMP || f->mvuRight[i] >= 0) continue;   // stereo: "stereo shouldn't in poseoptimization"
+        f->mvbOutlier[i] = false;
+        double P[3];
+        pMP->GetWorldPos(P);
+        const KeyPoint& kp = f->mvKeysUn[i];
+        o.pw.insert(o.pw.end(), {P[0], P[1], P[2]});
+        o.uv.push_back(kp.pt.x); o.uv.push_back(kp.pt.y);
+        o.w.push_back(f->mvInvLevelSigma2[kp.octave]);
+        o.idx.push_back((size_t)i);
+    }
+    o.outl.assign(o.idx.size() + 1, 0);
+}
+void FillCommon(vba_frame_problem& F, Frame* f, const FrameObs& o) {
+    F.n_obs = (int32_t)o.idx.size();
+    F.obs_pw = o.pw.data(); F.obs_uv = o.uv.data(); F.obs_w = o.w.data();
+    F.K[0] = f->fx; F.K[1] = f->fy; F.K[2] = f->cx; F.K[3] = f->cy;
+}
+void FillImu(vba_frame_problem& F, const IMUPreintegrator& pre, const Vector3d& gw) {
+    Matrix3d Rcb; Vector3d tcb;
+    ConfigParam::GetEigT_cb(Rcb, tcb);
+    const Quaterniond qcb = MatrixToQuat(Rcb.data());
+    for (int i = 0; i < 3; i++) { F.T_cb[i] = tcb[i]; F.g_w[i] = gw[i]; }
+    for (int i = 0; i < 4; i++) F.T_cb[3 + i] = qcb[i];
+    double* m = F.imu_meas;
+    m[0] = pre.getDeltaTime();
+    std::memcpy(m + 1, pre.getDeltaP().data(), 24); std::memcpy(m + 4, pre.getDeltaV().data(), 24);
+    std::memcpy(m + 7, pre.getDeltaR().data(), 72);
+    std::memcpy(m + 16, pre.getJPBiasg().data(), 72); std::memcpy(m + 25, pre.getJPBiasa().data(), 72);
+    std::memcpy(m + 34, pre.getJVBiasg().data(), 72); std::memcpy(m + 43, pre.getJVBiasa().data(), 72);
+    std::memcpy(m + 52, pre.getJRBiasg().data(), 72);
+    std::memcpy(F.imu_cov_pvphi, pre.getCovPVPhi().data(), sizeof F.imu_cov_pvphi);
+    F.inv_bg_rw2 = 1.0 / IMUData::getGyrBiasRW2();
+    F.inv_ba_rw2 = 1.0 / IMUData::getAccBiasRW2();
+}
+int RunFrame(vba_frame_problem& F, vba_frame_result& R, const char* who) {
+    void* h = handle();
+    if (!h) { std::cerr << who << ": no HIP device, pose optimisation skipped (the backend has no CPU path)" << std::endl; return -1; }
+    vba_frame_problem* pf = &F;
+    vba_frame_result* pr = &R;
+    if (vba_pose_optimize(h, 1, &pf, &pr) != 0) { std::cerr << who << ": " << vba_last_error(h) << std::endl; return -1; }
+    return 0;
+}
+NavState ArrayToNav(const NavState& base, const double* v) {   // ns_recov: PVR from the PVR vertex, delta biases from the bias vertex
+    NavState ns = base;
+    ns.Set_Pos({{v[0], v[1], v[2]}});
+    ns.Set_Rot({{v[3], v[4], v[5], v[6]}});
+    ns.Set_Vel({{v[7], v[8], v[9]}});
+    ns.Set_DeltaBiasGyr({{v[16], v[17], v[18]}});
+    ns.Set_DeltaBiasAcc({{v[19], v[20], v[21]}});
+    return ns;
+}
+}  // namespace
+
+int Optimizer::PoseOptimization(Frame* pFrame) {                                                                   // :3610-3835
+    FrameObs o;
+    GatherFrame(pFrame, o);
+    if (o.idx.size() < 3) return 0;                                                                               // :3726-3727
+    vba_frame_problem F;
+    std::memset(&F, 0, sizeof F);
+    vba_frame_result R;
+    std::memset(&R, 0, sizeof R);
+    F.last_is_frame = VBA_FRAME_VISION;
+    FillCommon(F, pFrame, o);
+    {   // Converter::toSE3Quat(pFrame->mTcw)
+        double Rm[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Rm[3 * i + j] = pFrame->mTcw[4 * i + j];
+        Quaterniond q = MatrixToQuat(Rm);
+        if (q[3] < 0) for (auto& v : q) v = -v;
+        for (int i = 0; i < 3; i++) F.nav[i] = pFrame->mTcw[4 * i + 3];
+        for (int i = 0; i < 4; i++) F.nav[3 + i] = q[i];
+    }
+    F.T_cb[6] = 1.0;
+    R.outlier = o.outl.data();
+    if (RunFrame(F, R, "PoseOptimization") != 0) return 0;
+    for (size_t k = 0; k < o.idx.size(); k++) pFrame->mvbOutlier[o.idx[k]] = o.outl[k] != 0;
+    const Matrix3d Rr = QuatToMatrix({{F.nav[3], F.nav[4], F.nav[5], F.nav[6]}});                                  // Converter::toCvMat(SE3quat_recov)
+    Mat4f T{};
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T[4 * r + c] = (float)Rr[3 * r + c];
+        T[4 * r + 3] = (float)F.nav[r];
+    }
+    T[15] = 1.0f;
+    pFrame->SetPose(T);
+    return R.n_inliers;
+}
+
+int Optimizer::PoseOptimization(Frame* pFrame, KeyFrame* pLastKF, const IMUPreintegrator& imupreint, const Vector3d& gw,
+                                const bool& bComputeMarg) {                                                       // :2046-2317
+    FrameObs o;
+    GatherFrame(pFrame, o);
+    if (o.idx.size() < 3) return 0;
+    vba_frame_problem F;
+    std::memset(&F, 0, sizeof F);
+    vba_frame_result R;
+    std::memset(&R, 0, sizeof R);
+    F.last_is_frame = VBA_FRAME_KF;
+    F.compute_marg = bComputeMarg ? 1 : 0;
+    FillCommon(F, pFrame, o);
+    FillImu(F, imupreint, gw);
+    NavToArray(pFrame->GetNavState(), F.nav);
+    NavToArray(pLastKF->GetNavState(), F.nav_last);
+    R.outlier = o.outl.data();
+    if (RunFrame(F, R, "PoseOptimization") != 0) return 0;
+    for (size_t k = 0; k < o.idx.size(); k++) pFrame->mvbOutlier[o.idx[k]] = o.outl[k] != 0;
+    const NavState ns = ArrayToNav(pFrame->GetNavState(), F.nav);
+    pFrame->SetNavState(ns);
+    pFrame->UpdatePoseFromNS();
+    if (bComputeMarg) {
+        std::memcpy(pFrame->mMargCovInv.data(), R.marg_cov_inv, sizeof R.marg_cov_inv);
+        pFrame->mNavStatePrior = ns;
+    }
+    return R.n_inliers;
+}
+
+int Optimizer::PoseOptimization(Frame* pFrame, Frame* pLastFrame, const IMUPreintegrator& imupreint, const Vector3d& gw,
+                                const bool& bComputeMarg) {                                                       // :1671-2044
+    FrameObs o, ol;
+    GatherFrame(pFrame, o);
+    GatherFrame(pLastFrame, ol);
+    if (o.idx.size() < 3) return 0;
+    vba_frame_problem F;
+    std::memset(&F, 0, sizeof F);
+    vba_frame_result R;
+    std::memset(&R, 0, sizeof R);
+    F.last_is_frame = VBA_FRAME_FRAME;
+    F.compute_marg = bComputeMarg ? 1 : 0;
+    FillCommon(F, pFrame, o);
+    F.n_obs_last = (int32_t)ol.idx.size();
+    F.last_pw = ol.pw.data(); F.last_uv = ol.uv.data(); F.last_w = ol.w.data();
+    FillImu(F, imupreint, gw);
+    NavToArray(pFrame->GetNavState(), F.nav);
+    NavToArray(pLastFrame->GetNavState(), F.nav_last);
+    NavToArray(pLastFrame->mNavStatePrior, F.prior_nav);
+    std::memcpy(F.prior_info, pLastFrame->mMargCovInv.data(), sizeof F.prior_info);
+    R.outlier = o.outl.data();
+    R.outlier_last = ol.outl.data();
+    if (RunFrame(F, R, "PoseOptimization") != 0) return 0;
+    for (size_t k = 0; k < o.idx.size(); k++) pFrame->mvbOutlier[o.idx[k]] = o.outl[k] != 0;
+    for (size_t k = 0; k < ol.idx.size(); k++) pLastFrame->mvbOutlier[ol.idx[k]] = ol.outl[k] != 0;
+    const NavState ns = ArrayToNav(pFrame->GetNavState(), F.nav);
+    pFrame->SetNavState(ns);
+    pFrame->UpdatePoseFromNS();
+    if (bComputeMarg) {
+        std::memcpy(pFrame->mMargCovInv.data(), R.marg_cov_inv, sizeof R.marg_cov_inv);
+        pFrame->mNavStatePrior = ns;
+    }
+    return R.n_inliers;
 }
 
 void Optimizer::GlobalBundleAdjustment(Map* pMap, int nIterations, bool* pbStopFlag, const unsigned long nLoopKF, const bool bRobust) {

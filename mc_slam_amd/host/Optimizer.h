@@ -48,6 +48,18 @@ public:
     static bool PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations,
                                      bool bRobust, PackedWindow& W);
 
+    // include/Optimizer.h:57-59: local BA over an explicit keyframe list (the VI sliding window), vision edges only
+    static void LocalBundleAdjustment(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, bool* pbStopFlag, Map* pMap,
+                                      LocalMapping* pLM = NULL);
+    // include/Optimizer.h:77, :26-31: per-frame pose optimisation, vision only and IMU-aided (last keyframe / last frame)
+    static int PoseOptimization(Frame* pFrame);
+    static int PoseOptimization(Frame* pFrame, KeyFrame* pLastKF, const IMUPreintegrator& imupreint, const Vector3d& gw,
+                                const bool& bComputeMarg = false);
+    static int PoseOptimization(Frame* pFrame, Frame* pLastFrame, const IMUPreintegrator& imupreint, const Vector3d& gw,
+                                const bool& bComputeMarg = false);
+    static bool PackLocalBundleAdjustment(KeyFrame* pKF, const std::list<KeyFrame*>* pList, PackedWindow& W);
+    static void LocalBundleAdjustmentImpl(KeyFrame* pKF, const std::list<KeyFrame*>* pList, bool* pbStopFlag, Map* pMap, LocalMapping* pLM);
+
     // graph extraction only (what the two entry points hand to vba_solve); exposed for tests
     static bool PackLocalBAPRVIDP(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw, PackedWindow& W);
     static bool PackLocalBundleAdjustment(KeyFrame* pKF, PackedWindow& W);

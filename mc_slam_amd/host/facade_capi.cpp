@@ -14,6 +14,7 @@ struct FcMap {
     LocalMapping lm;
     std::map<long, std::unique_ptr<KeyFrame>> kfs;
     std::map<long, std::unique_ptr<MapPoint>> mps;
+    std::map<long, std::unique_ptr<Frame>> frames;
 };
 
 extern "C" {
@@ -109,6 +110,15 @@ int fc_local_ba_prvidp(void* m, const long* ids, int n, const double* gw, int st
     Optimizer::LocalBAPRVIDP(l.back(), l, &bstop, &M->map, g, &M->lm);
     return 0;
 }
+// LocalBundleAdjustment over an explicit keyframe list (include/Optimizer.h:57-59); mode 1: extraction only
+int fc_local_ba_vision_list(void* m, const long* ids, int n, int stop, int mode) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    std::list<KeyFrame*> l = window(M, ids, n);
+    bool bstop = stop != 0;
+    if (mode == 1) return Optimizer::PackLocalBundleAdjustment(l.back(), &l, Optimizer::LastWindowMutable()) ? 0 : -1;
+    Optimizer::LocalBundleAdjustment(l.back(), l, &bstop, &M->map, &M->lm);
+    return 0;
+}
 int fc_local_ba_vision(void* m, long cur, int stop) {
     FcMap* M = reinterpret_cast<FcMap*>(m);
     bool bstop = stop != 0;
@@ -157,6 +167,86 @@ int fc_get_mappoint_gba(void* m, long id, float* Pw, long* nLoop) {
     std::memcpy(Pw, p->mPosGBA, 12);
     *nLoop = (long)p->mnBAGlobalForKF;
     return 0;
+}
+// ---- frames (per-frame pose optimisation) ----
+static void set_nav(NavState& ns, const double* nav) {
+    ns.Set_Pos({{nav[0], nav[1], nav[2]}});
+    ns.Set_Rot({{nav[3], nav[4], nav[5], nav[6]}});
+    ns.Set_Vel({{nav[7], nav[8], nav[9]}});
+    ns.Set_BiasGyr({{nav[10], nav[11], nav[12]}});
+    ns.Set_BiasAcc({{nav[13], nav[14], nav[15]}});
+    ns.Set_DeltaBiasGyr({{nav[16], nav[17], nav[18]}});
+    ns.Set_DeltaBiasAcc({{nav[19], nav[20], nav[21]}});
+}
+static void get_nav(const NavState& ns, double* nav22) {
+    const Vector3d P = ns.Get_P(), V = ns.Get_V(), bg = ns.Get_BiasGyr(), ba = ns.Get_BiasAcc(), dbg = ns.Get_dBias_Gyr(), dba = ns.Get_dBias_Acc();
+    const Quaterniond q = ns.Get_R();
+    const double v[22] = {P[0], P[1], P[2], q[0], q[1], q[2], q[3], V[0], V[1], V[2], bg[0], bg[1], bg[2], ba[0], ba[1], ba[2],
+                          dbg[0], dbg[1], dbg[2], dba[0], dba[1], dba[2]};
+    std::memcpy(nav22, v, sizeof v);
+}
+int fc_add_frame(void* m, long id, const double* nav22, const double* K) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    std::unique_ptr<Frame> f(new Frame());
+    f->fx = (float)K[0]; f->fy = (float)K[1]; f->cx = (float)K[2]; f->cy = (float)K[3];
+    f->mvInvLevelSigma2.resize(8);
+    for (int l = 0; l < 8; l++) f->mvInvLevelSigma2[l] = 1.0f / (float)std::pow(1.2, 2 * l);
+    set_nav(f->mNavState, nav22);
+    f->UpdatePoseFromNS();
+    M->frames[id] = std::move(f);
+    return 0;
+}
+int fc_frame_set_tcw(void* m, long id, const float* T16) {
+    Mat4f T; std::memcpy(T.data(), T16, 64);
+    reinterpret_cast<FcMap*>(m)->frames.at(id)->SetPose(T);
+    return 0;
+}
+int fc_frame_add_obs(void* m, long frame, long mp, float u, float v, int octave) {   // mp < 0: an unmatched keypoint
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    Frame* f = M->frames.at(frame).get();
+    KeyPoint kp; kp.pt.x = u; kp.pt.y = v; kp.octave = octave;
+    f->mvKeysUn.push_back(kp);
+    f->mvuRight.push_back(-1.0f);
+    f->mvpMapPoints.push_back(mp >= 0 ? M->mps.at(mp).get() : nullptr);
+    f->mvbOutlier.push_back(true);   // whatever the tracker left there: the optimiser resets matched ones
+    f->N = (int)f->mvKeysUn.size();
+    return 0;
+}
+int fc_frame_set_prior(void* m, long id, const double* prior_nav22, const double* info225) {
+    Frame* f = reinterpret_cast<FcMap*>(m)->frames.at(id).get();
+    set_nav(f->mNavStatePrior, prior_nav22);
+    std::memcpy(f->mMargCovInv.data(), info225, 225 * 8);
+    return 0;
+}
+static IMUPreintegrator make_preint(const double* meas61, const double* cov81) {
+    IMUPreintegrator P;
+    P._delta_time = meas61[0];
+    std::memcpy(P._delta_P.data(), meas61 + 1, 24); std::memcpy(P._delta_V.data(), meas61 + 4, 24);
+    std::memcpy(P._delta_R.data(), meas61 + 7, 72);
+    std::memcpy(P._J_P_Biasg.data(), meas61 + 16, 72); std::memcpy(P._J_P_Biasa.data(), meas61 + 25, 72);
+    std::memcpy(P._J_V_Biasg.data(), meas61 + 34, 72); std::memcpy(P._J_V_Biasa.data(), meas61 + 43, 72);
+    std::memcpy(P._J_R_Biasg.data(), meas61 + 52, 72);
+    std::memcpy(P._cov_P_V_Phi.data(), cov81, 648);
+    return P;
+}
+// kind 2: PoseOptimization(Frame*); 0: (Frame*, KeyFrame* last, ...); 1: (Frame*, Frame* last, ...).  Returns the inlier count.
+int fc_pose_optimization(void* m, int kind, long frame, long last, const double* meas61, const double* cov81, const double* gw, int marg) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    Frame* f = M->frames.at(frame).get();
+    if (kind == 2) return Optimizer::PoseOptimization(f);
+    const IMUPreintegrator pre = make_preint(meas61, cov81);
+    const Vector3d g{{gw[0], gw[1], gw[2]}};
+    if (kind == 0) return Optimizer::PoseOptimization(f, M->kfs.at(last).get(), pre, g, marg != 0);
+    return Optimizer::PoseOptimization(f, M->frames.at(last).get(), pre, g, marg != 0);
+}
+int fc_frame_get(void* m, long id, double* nav22, float* T16, double* marg225, double* prior22, unsigned char* outlier, int cap) {
+    Frame* f = reinterpret_cast<FcMap*>(m)->frames.at(id).get();
+    get_nav(f->GetNavState(), nav22);
+    std::memcpy(T16, f->mTcw.data(), 64);
+    std::memcpy(marg225, f->mMargCovInv.data(), 225 * 8);
+    get_nav(f->mNavStatePrior, prior22);
+    for (int i = 0; i < f->N && i < cap; i++) outlier[i] = f->mvbOutlier[i] ? 1 : 0;
+    return f->N;
 }
 int fc_get_nav(void* m, long id, double* nav22, float* T16) {
     FcMap* M = reinterpret_cast<FcMap*>(m);

@@ -223,6 +223,31 @@ public:
     long unsigned int mnBAGlobalForKF = 0;
 };
 
+// include/Frame.h: the slice PoseOptimization reads and writes (:48-67, :104, :214, :230)
+class Frame {
+public:
+    int N = 0;
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+    std::vector<KeyPoint> mvKeysUn;
+    std::vector<float> mvuRight;
+    std::vector<float> mvInvLevelSigma2;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    Mat4f mTcw{};
+    std::array<double, 225> mMargCovInv{};   // Matrix<double,15,15>, row-major here
+    NavState mNavStatePrior;
+    const NavState& GetNavState() const { return mNavState; }
+    void SetNavState(const NavState& ns) { mNavState = ns; }
+    void SetPose(const Mat4f& T) { mTcw = T; }
+    void UpdatePoseFromNS() {  // Frame::UpdatePoseFromNS(ConfigParam::GetMatTbc()): the same float32 chain as KeyFrame's
+        KeyFrame k;
+        k.SetNavState(mNavState);
+        k.UpdatePoseFromNS();
+        mTcw = k.GetPose();
+    }
+    NavState mNavState;
+};
+
 inline bool cmpKeyFrameId::operator()(const KeyFrame* a, const KeyFrame* b) const { return a->mnId < b->mnId; }
 
 }  // namespace ORB_SLAM2

@@ -30,6 +30,7 @@ def lib():
         l.fc_add_observation.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_float, C.c_float, C.c_int]
         l.fc_local_ba_prvidp.argtypes = [C.c_void_p, _pl, C.c_int, _pd, C.c_int, C.c_int]
         l.fc_local_ba_vision.argtypes = [C.c_void_p, C.c_long, C.c_int]
+        l.fc_local_ba_vision_list.argtypes = [C.c_void_p, _pl, C.c_int, C.c_int, C.c_int]
         l.fc_global_ba_prv.argtypes = [C.c_void_p, _pd, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int]
         l.fc_global_ba_vision.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int]
         l.fc_get_gba.argtypes = [C.c_void_p, C.c_long, _pd, _pf, _pl]
@@ -138,6 +139,10 @@ class FacadeMap:
         self.L.fc_get_mappoint_gba(self.m, q, Pw.ctypes.data_as(_pf), C.byref(n))
         return Pw, n.value
 
+    def local_ba_vision_list(self, ids, stop=0, extract_only=False):
+        ids = np.asarray(ids, dtype=np.int64)
+        return self.L.fc_local_ba_vision_list(self.m, ids.ctypes.data_as(_pl), len(ids), stop, 1 if extract_only else 0)
+
     def local_ba_vision(self, stop=0):
         p = self.p
         free = sorted(self.tidx[i] for i in range(p.n_kf_free))
@@ -174,3 +179,63 @@ def last_problem() -> abi.Problem:
         huber_vis=s.huber_vis, huber_prv=s.huber_prv, huber_bias=s.huber_bias, protocol=s.protocol, robust=s.robust,
         kf_fix=(np.ctypeslib.as_array(s.kf_fix, shape=(s.n_kf,)).copy() if s.kf_fix else None))
     return pr
+
+
+class FrameScene:
+    """The map points, the last keyframe / frame and the current frame of one synthetic FrameProblem, held the way the
+    tracker holds them (float32 map points and keypoints); unmatched keypoints are interleaved so that the keypoint
+    index <-> correspondence index maps of the facade are exercised."""
+    CUR, LAST = 1, 2
+
+    def __init__(self, f: abi.FrameProblem, R_bc, p_bc):
+        L = lib()
+        L.fc_add_frame.argtypes = [C.c_void_p, C.c_long, _pd, _pd]
+        L.fc_frame_set_tcw.argtypes = [C.c_void_p, C.c_long, _pf]
+        L.fc_frame_add_obs.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_float, C.c_float, C.c_int]
+        L.fc_frame_set_prior.argtypes = [C.c_void_p, C.c_long, _pd, _pd]
+        L.fc_pose_optimization.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_long, _pd, _pd, _pd, C.c_int]
+        L.fc_frame_get.argtypes = [C.c_void_p, C.c_long, _pd, _pf, _pd, _pd, C.POINTER(C.c_uint8), C.c_int]
+        self.L, self.f = L, f
+        self.kind = int(f.last_is_frame)
+        self.m = L.fc_create()
+        L.fc_set_tbc(_d(R_bc.reshape(-1)), _d(p_bc))
+        ident = np.zeros(22); ident[6] = 1.0
+        L.fc_add_keyframe(self.m, 0, _d(f.nav_last if self.kind == 0 else ident), _d(f.K), -1, 0)   # last keyframe / map-point owner
+        pts = np.vstack([f.obs_pw, f.last_pw]) if f.n_obs_last else f.obs_pw
+        for i, P in enumerate(pts):
+            L.fc_add_mappoint(self.m, i, _f(P), 0)
+        if self.kind == 2:
+            L.fc_add_frame(self.m, self.CUR, _d(ident), _d(f.K))
+            T = np.eye(4, dtype=np.float32); T[:3, :3] = synth.quat_to_rot(f.nav[3:7]); T[:3, 3] = f.nav[:3]
+            L.fc_frame_set_tcw(self.m, self.CUR, _f(T.reshape(-1)))
+        else:
+            L.fc_add_frame(self.m, self.CUR, _d(f.nav), _d(f.K))
+        self.cur_index = self._fill(self.CUR, range(f.n_obs), f.obs_uv, f.obs_w)
+        self.last_index = []
+        if self.kind == 1:
+            L.fc_add_frame(self.m, self.LAST, _d(f.nav_last), _d(f.K))
+            L.fc_frame_set_prior(self.m, self.LAST, _d(f.prior_nav), _d(f.prior_info.reshape(-1)))
+            self.last_index = self._fill(self.LAST, range(f.n_obs, f.n_obs + f.n_obs_last), f.last_uv, f.last_w)
+
+    def _fill(self, fid, mp_ids, uv, w):
+        index, n = [], 0
+        for i, mp in enumerate(mp_ids):
+            if i % 5 == 0:   # a keypoint without a map point
+                self.L.fc_frame_add_obs(self.m, fid, -1, 10.0, 10.0, 0); n += 1
+            index.append(n)
+            self.L.fc_frame_add_obs(self.m, fid, mp, np.float32(uv[i, 0]), np.float32(uv[i, 1]), octave_of(w[i])); n += 1
+        return np.array(index, dtype=np.int64)
+
+    def run(self):
+        f = self.f
+        return self.L.fc_pose_optimization(self.m, self.kind, self.CUR, 0 if self.kind == 0 else self.LAST, _d(f.imu_meas),
+                                           _d(f.imu_cov_pvphi.reshape(-1)), _d(f.g_w), int(f.compute_marg))
+
+    def get(self, fid):
+        nav = np.zeros(22); T = np.zeros(16, dtype=np.float32); marg = np.zeros(225); prior = np.zeros(22); o = np.zeros(8192, dtype=np.uint8)
+        n = self.L.fc_frame_get(self.m, fid, nav.ctypes.data_as(_pd), T.ctypes.data_as(_pf), marg.ctypes.data_as(_pd), prior.ctypes.data_as(_pd),
+                                o.ctypes.data_as(C.POINTER(C.c_uint8)), len(o))
+        return nav, T.reshape(4, 4), marg.reshape(15, 15), prior, o[:n].astype(bool)
+
+    def close(self):
+        self.L.fc_destroy(self.m)

@@ -244,3 +244,81 @@ def test_facade_global_ba_vision_equals_direct_solve():
         T = fm.pose_tcw(int(kf_ids[row]))
         np.testing.assert_array_equal(T[:3, 3], q.kf_pose[row, :3].astype(np.float32))
     fm.close()
+
+
+# ---- per-frame pose optimisation through the facade (BASELINE configs[0]) ----
+def _narrowed(f):
+    """the FrameProblem the facade ends up handing to vba_pose_optimize: float32 map points (cv::Mat CV_32F)"""
+    g = f.copy()
+    g.obs_pw = np.float32(f.obs_pw).astype(np.float64)
+    g.last_pw = np.float32(f.last_pw).astype(np.float64)
+    return g
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [2, 0, 1])
+def test_facade_pose_optimization_equals_direct_call(kind):
+    from mc_slam_amd import backend
+    R_bc, p_bc, _ = synth.extrinsics()
+    f = synth.make_frame_vision(seed=1, n_obs=200) if kind == 2 else synth.make_frame(seed=90 + kind, n_obs=180, last_is_frame=bool(kind))
+    ba = backend.LocalBA(0)
+    r = ba.pose_optimize([_narrowed(f)])[0]
+    ba.close()
+    sc = facade.FrameScene(f, R_bc, p_bc)
+    n_in = sc.run()
+    nav, T, marg, prior, outl = sc.get(sc.CUR)
+    assert n_in == r.n_inliers > 100
+    assert (outl[sc.cur_index] == r.outlier.astype(bool)).all()
+    assert outl[[i for i in range(len(outl)) if i not in set(sc.cur_index)]].all()      # unmatched keypoints are not touched
+    if kind == 2:     # SetPose(Converter::toCvMat(SE3quat)): float32; the facade re-derives the quaternion from the float32 mTcw
+        np.testing.assert_allclose(T[:3, 3], r.nav[:3], atol=5e-7)
+        np.testing.assert_allclose(T[:3, :3], synth.quat_to_rot(r.nav[3:7]), atol=1e-6)
+    else:
+        # (the facade's float32 pyramid table differs from the generator's weights in the last float32 bit)
+        np.testing.assert_allclose(nav[:10], r.nav[:10], atol=2e-6)
+        np.testing.assert_allclose(nav[16:22], r.nav[16:22], atol=1e-7)
+        assert (nav[10:16] == f.nav[10:16]).all()
+        np.testing.assert_allclose(marg, r.marg_cov_inv, rtol=1e-4, atol=1e-6 * np.abs(r.marg_cov_inv).max())
+        assert (prior == nav).all()                                                     # pFrame->mNavStatePrior = ns_recov
+        Rwb = synth.quat_to_rot(nav[3:7]); Rcw = (Rwb @ R_bc).T
+        np.testing.assert_allclose(T[:3, 3], -Rcw @ (Rwb @ p_bc + nav[:3]), atol=2e-5)
+        if kind == 1:
+            _n, _T, _m, _p, ol = sc.get(sc.LAST)
+            assert (ol[sc.last_index] == r.outlier_last.astype(bool)).all()
+            nl, *_ = sc.get(sc.LAST)
+            assert (nl == f.nav_last).all()                                             # the last frame's state is not written back
+    sc.close()
+
+
+def test_list_overload_of_local_bundle_adjustment_extraction():
+    """LocalBundleAdjustment(pKF, lLocalKeyFrames, ...) (src/Optimizer.cpp:2975-3336): the window is the given list, the
+    keyframe before it is fixed first, then every other observer of the window's map points."""
+    p = synth.make_window(abi.VARIANT_SE3_XYZ, n_kf=9, n_fixed=1, n_pt=250, n_obs=1400, seed=64)
+    fm = facade.FacadeMap(p)
+    ids = sorted(fm.tidx[i] for i in range(p.n_kf))
+    win = ids[3:]                                   # keyframes 3..8 are the window; 2 precedes it; 0, 1 are older observers
+    assert fm.local_ba_vision_list(win, extract_only=True) == 0
+    e = facade.last_problem()
+    _mp, kf_ids = facade.last_ids()
+    assert (e.variant, e.algo, e.n_kf_free) == (0, abi.ALGO_LM, len(win))
+    assert list(kf_ids[:len(win)]) == win and kf_ids[len(win)] == win[0] - 1      # the predecessor is the first fixed camera
+    assert set(kf_ids[len(win):]) <= set(ids[:3])
+    assert (e.its_stage1, e.its_stage2) == (5, 10)
+    fm.close()
+
+
+@pytest.mark.gpu
+def test_list_overload_of_local_bundle_adjustment_runs():
+    from mc_slam_amd import backend
+    p = synth.make_window(abi.VARIANT_SE3_XYZ, n_kf=9, n_fixed=1, n_pt=250, n_obs=1400, seed=64)
+    fm = facade.FacadeMap(p)
+    win = sorted(fm.tidx[i] for i in range(p.n_kf))[3:]
+    fm.local_ba_vision_list(win, extract_only=True)
+    e = facade.last_problem()
+    ba = backend.LocalBA(0); q, r = ba.solve(e); ba.close()
+    fm.local_ba_vision_list(win)
+    res = facade.lib().fc_last_result().contents
+    assert tuple(res.its_done) == r.its_done and res.n_outliers == r.n_outliers and fm.L.fc_map_updated(fm.m) == 1
+    for row, t in enumerate(win):
+        np.testing.assert_array_equal(fm.pose_tcw(t)[:3, 3], q.kf_pose[row, :3].astype(np.float32))
+    fm.close()
