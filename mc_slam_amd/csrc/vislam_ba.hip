@@ -412,6 +412,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         if (P->variant != VBA_VARIANT_PRV_IDP && P->algo != VBA_ALGO_LM)
             return fail(h, "XYZ landmarks are solved with Levenberg-Marquardt only (as the reference does, src/Optimizer.cpp:1028,3928)");
         if (P->n_kf_free <= 0 || P->n_kf_free > P->n_kf || P->n_pt < 0 || P->n_obs < 0) return fail(h, "bad sizes");
+        if (P->n_pt == 0 || P->n_obs == 0) return fail(h, "a window without landmarks or observations has nothing to optimise");
         if (w > 0 && (P->variant != probs[0]->variant || P->algo != probs[0]->algo)) return fail(h, "mixed batch");
         if (P->its_stage1 > 30 || P->its_stage2 > 30 || P->its_stage1 < 0 || P->its_stage2 < 0) return fail(h, "its out of range");
         if (P->protocol != VBA_PROTO_LOCAL && P->protocol != VBA_PROTO_SINGLE) return fail(h, "unknown protocol");

@@ -227,6 +227,7 @@ bool Optimizer::PackLocalBAPRVIDP(KeyFrame* pCurKF, const std::list<KeyFrame*>& 
     for (int i = 0; i < 3; i++) { W.P.T_cb[i] = tcb[i]; W.P.g_w[i] = gw[i]; }
     for (int i = 0; i < 4; i++) W.P.T_cb[3 + i] = qcb[i];
     W.P.depth_min = 0.01; W.P.rho_min = 2e-6;                                                                     // g2otypes.h:122-127, :484
+    if (W.vMP.empty() || W.obsKF.empty()) return false;   // an empty graph: the reference's optimize() changes nothing
     FinishProblem(W);
     return true;
 }
@@ -364,10 +365,12 @@ bool Optimizer::PackLocalBundleAdjustment(KeyFrame* pKF, const std::list<KeyFram
         W.vMP.push_back(pMP);
         W.begin.push_back((int32_t)W.obsKF.size());
     }
+    if (W.vMP.empty() || W.obsKF.empty()) return false;   // nothing to optimise: g2o would run on an empty graph and change nothing
     W.P.variant = VBA_VARIANT_SE3_XYZ;
     W.P.algo = VBA_ALGO_LM;                                                                                       // :3928
     W.P.T_cb[6] = 1.0;
     W.P.depth_min = 0.0;
+    if (W.vMP.empty() || W.obsKF.empty()) return false;   // an empty graph: the reference's optimize() changes nothing
     FinishProblem(W);
     return true;
 }
@@ -526,6 +529,7 @@ bool Optimizer::PackGlobalBundleAdjustmentNavStatePRV(Map* pMap, const Vector3d&
     for (int i = 0; i < 3; i++) { W.P.T_cb[i] = tcb[i]; W.P.g_w[i] = gw[i]; }
     for (int i = 0; i < 4; i++) W.P.T_cb[3 + i] = qcb[i];
     W.P.depth_min = 0.0;
+    if (W.vMP.empty() || W.obsKF.empty()) return false;   // an empty graph: the reference's optimize() changes nothing
     FinishProblem(W);
     W.P.protocol = VBA_PROTO_SINGLE;
     W.P.robust = bRobust ? 1 : 0;
@@ -593,6 +597,7 @@ bool Optimizer::PackBundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const 
     W.P.algo = VBA_ALGO_LM;                                                                                       // :3393
     W.P.T_cb[6] = 1.0;
     W.P.depth_min = 0.0;
+    if (W.vMP.empty() || W.obsKF.empty()) return false;   // an empty graph: the reference's optimize() changes nothing
     FinishProblem(W);
     W.P.protocol = VBA_PROTO_SINGLE;
     W.P.robust = bRobust ? 1 : 0;

@@ -316,6 +316,8 @@ def test_list_overload_of_local_bundle_adjustment_runs():
     fm.local_ba_vision_list(win, extract_only=True)
     e = facade.last_problem()
     ba = backend.LocalBA(0); q, r = ba.solve(e); ba.close()
+    fm.close()
+    fm = facade.FacadeMap(p)      # a fresh map: the mnBALocalForKF / mnBAFixedForKF marks of the first extraction persist, as upstream
     fm.local_ba_vision_list(win)
     res = facade.lib().fc_last_result().contents
     assert tuple(res.its_done) == r.its_done and res.n_outliers == r.n_outliers and fm.L.fc_map_updated(fm.m) == 1

@@ -69,6 +69,15 @@ def test_xyz_variants_match_oracle(ba, oracle, variant, algo, kw):
         assert abs(r.lambda_final - ro.lambda_final) <= 1e-6 * ro.lambda_final
 
 
+def test_empty_window_is_refused_with_a_message(ba):
+    p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31)
+    q = abi.Problem(variant=p.variant, n_kf_free=p.n_kf_free, kf_pose=p.kf_pose, pt=np.zeros((0, 3)), pt_obs_begin=[0], obs_kf=[],
+                    obs_uv=np.zeros((0, 2)), obs_w=[], K=p.K, kf_vel=p.kf_vel, kf_bias=p.kf_bias, T_cb=p.T_cb, g_w=p.g_w,
+                    imu_kf_i=p.imu_kf_i, imu_kf_j=p.imu_kf_j, imu_meas=p.imu_meas, imu_info_prv=p.imu_info_prv, algo=p.algo)
+    with pytest.raises(RuntimeError, match="nothing to optimise"):
+        ba.solve(q)
+
+
 def test_unsupported_combinations_fail_loudly(ba):
     # the reference never runs GN on XYZ landmarks nor LM on inverse-depth ones; the backend says so instead of guessing
     p = synth.make_window(abi.VARIANT_SE3_XYZ, algo=abi.ALGO_GN, n_kf=6, n_fixed=2, n_pt=60, n_obs=300, seed=33)
