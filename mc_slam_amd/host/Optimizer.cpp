@@ -128,6 +128,17 @@ PackedWindow& Optimizer::LastWindowMutable() { return t_last; }
 // ------------------------------------------------------------------------------------------------
 bool Optimizer::PackLocalBAPRVIDP(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw,
                                   PackedWindow& W) {
+    return PackLocalVI(pCurKF, lLocalKeyFrames, gw, true, W);
+}
+bool Optimizer::PackLocalBundleAdjustmentNavStatePRV(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw,
+                                                     PackedWindow& W) {
+    return PackLocalVI(pCurKF, lLocalKeyFrames, gw, false, W);
+}
+
+// the two visual-inertial local windows share everything but the landmark model: inverse depth in the reference keyframe
+// (LocalBAPRVIDP, :32-625) or world XYZ (LocalBundleAdjustmentNavStatePRV, :937-1388)
+bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw, bool idp,
+                            PackedWindow& W) {
     W = PackedWindow();
     std::memset(&W.P, 0, sizeof W.P);
     if (pCurKF != lLocalKeyFrames.back()) std::cerr << "pCurKF != lLocalKeyFrames.back. check" << std::endl;  // :37-38
@@ -183,9 +194,32 @@ bool Optimizer::PackLocalBAPRVIDP(KeyFrame* pCurKF, const std::list<KeyFrame*>& 
         if (!PRVInformation(M.getCovPVPhi(), info)) { std::cerr << "singular preintegration covariance" << std::endl; return false; }
         W.info.insert(W.info.end(), info, info + 81);
     }
-    // landmarks and EdgePRIDP edges                                                                   (:337-451)
     W.begin.push_back(0);
+    if (!idp) {   // VertexSBAPointXYZ + one EdgeNavStatePRPointXYZ per observation (:1151-1193)
+        for (MapPoint* pMP : lLocalMapPoints) {
+            double Pw[3];
+            pMP->GetWorldPos(Pw);
+            for (auto& mit : pMP->GetObservations()) {
+                KeyFrame* pKFi = mit.first;
+                if (pKFi->isBad()) continue;
+                if (pKFi->mvuRight[mit.second] >= 0) { std::cerr << "Stereo not supported yet" << std::endl; continue; }
+                const KeyPoint& kpUn = pKFi->mvKeysUn[mit.second];
+                W.obsKF.push_back(kfIdx[pKFi]);
+                W.uv.push_back(kpUn.pt.x); W.uv.push_back(kpUn.pt.y);
+                W.w.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);
+                W.vEdgeKF.push_back(pKFi);
+                W.vEdgeMP.push_back(pMP);
+                W.P.K[0] = pKFi->fx; W.P.K[1] = pKFi->fy; W.P.K[2] = pKFi->cx; W.P.K[3] = pKFi->cy;
+            }
+            W.pt.insert(W.pt.end(), {Pw[0], Pw[1], Pw[2]});
+            W.ref.push_back(0);
+            W.vMP.push_back(pMP);
+            W.begin.push_back((int32_t)W.obsKF.size());
+        }
+    }
+    // landmarks and EdgePRIDP edges                                                                   (:337-451)
     for (MapPoint* pMP : lLocalMapPoints) {
+        if (!idp) break;
         double Pw[3];
         pMP->GetWorldPos(Pw);
         KeyFrame* pRefKF = pMP->GetReferenceKeyFrame();
@@ -219,14 +253,14 @@ bool Optimizer::PackLocalBAPRVIDP(KeyFrame* pCurKF, const std::list<KeyFrame*>& 
         W.begin.push_back((int32_t)W.obsKF.size());
         W.P.K[0] = pRefKF->fx; W.P.K[1] = pRefKF->fy; W.P.K[2] = pRefKF->cx; W.P.K[3] = pRefKF->cy;              // :422
     }
-    W.P.variant = VBA_VARIANT_PRV_IDP;
-    W.P.algo = VBA_ALGO_GN;                                                                                       // :136
+    W.P.variant = idp ? VBA_VARIANT_PRV_IDP : VBA_VARIANT_PRV_XYZ;
+    W.P.algo = idp ? VBA_ALGO_GN : VBA_ALGO_LM;                                                                   // :136 / :1028
     Matrix3d Rcb; Vector3d tcb;
     ConfigParam::GetEigT_cb(Rcb, tcb);                                                                            // :41-43
     const Quaterniond qcb = MatrixToQuat(Rcb.data());
     for (int i = 0; i < 3; i++) { W.P.T_cb[i] = tcb[i]; W.P.g_w[i] = gw[i]; }
     for (int i = 0; i < 4; i++) W.P.T_cb[3 + i] = qcb[i];
-    W.P.depth_min = 0.01; W.P.rho_min = 2e-6;                                                                     // g2otypes.h:122-127, :484
+    W.P.depth_min = idp ? 0.01 : 0.0; W.P.rho_min = 2e-6;                                                         // g2otypes.h:122-127 / :300-303, :484
     if (W.vMP.empty() || W.obsKF.empty()) return false;   // an empty graph: the reference's optimize() changes nothing
     FinishProblem(W);
     return true;
@@ -281,6 +315,45 @@ void Optimizer::LocalBAPRVIDP(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLoc
         pMP->UpdateNormalAndDepth();
     }
     if (pLM) pLM->SetMapUpdateFlagInTracking(true);                                                               // :620-623
+}
+
+void Optimizer::LocalBundleAdjustmentNavStatePRV(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocalKeyFrames, bool* pbStopFlag,
+                                                 Map* pMap, const Vector3d& gw, LocalMapping* pLM) {             // :937-1388
+    PackedWindow& W = t_last;
+    if (!PackLocalBundleAdjustmentNavStatePRV(pCurKF, lLocalKeyFrames, gw, W)) return;
+    if (pbStopFlag && *pbStopFlag) return;                                                                        // :1196-1198
+    void* h = handle();
+    if (!h) { std::cerr << "LocalBundleAdjustmentNavStatePRV: no HIP device, local BA skipped (the backend has no CPU path)" << std::endl; return; }
+    {
+        StopMirror stop(pbStopFlag);
+        if (vba_solve(h, &W.P, &W.R, pbStopFlag ? stop.ptr() : nullptr) != 0) {
+            std::cerr << "LocalBundleAdjustmentNavStatePRV: " << vba_last_error(h) << std::endl;
+            return;
+        }
+    }
+    if (W.R.status == VBA_ABORTED_BEFORE) return;
+    std::vector<std::pair<KeyFrame*, MapPoint*>> vToErase;                                                        // :1222-1238
+    for (size_t i = 0; i < W.vEdgeKF.size(); i++) {
+        if (W.vEdgeMP[i]->isBad()) continue;
+        if (W.outlier[i]) vToErase.push_back(std::make_pair(W.vEdgeKF[i], W.vEdgeMP[i]));
+    }
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+    for (auto& e : vToErase) { e.first->EraseMapPointMatch(e.second); e.second->EraseObservation(e.first); }
+    for (int i = 0; i < W.P.n_kf_free; i++) {                                                                     // :1250-1270
+        KeyFrame* pKFi = W.vKF[i];
+        pKFi->SetNavStatePos({{W.pose[7 * i], W.pose[7 * i + 1], W.pose[7 * i + 2]}});
+        pKFi->SetNavStateRot({{W.pose[7 * i + 3], W.pose[7 * i + 4], W.pose[7 * i + 5], W.pose[7 * i + 6]}});
+        pKFi->SetNavStateVel({{W.vel[3 * i], W.vel[3 * i + 1], W.vel[3 * i + 2]}});
+        pKFi->SetNavStateDeltaBg({{W.bias[12 * i + 6], W.bias[12 * i + 7], W.bias[12 * i + 8]}});
+        pKFi->SetNavStateDeltaBa({{W.bias[12 * i + 9], W.bias[12 * i + 10], W.bias[12 * i + 11]}});
+        pKFi->UpdatePoseFromNS();
+    }
+    for (size_t p = 0; p < W.vMP.size(); p++) {                                                                   // :1275-1283
+        const float Pw[3] = {(float)W.pt[3 * p], (float)W.pt[3 * p + 1], (float)W.pt[3 * p + 2]};
+        W.vMP[p]->SetWorldPos(Pw);
+        W.vMP[p]->UpdateNormalAndDepth();
+    }
+    if (pLM) pLM->SetMapUpdateFlagInTracking(true);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -33,6 +33,11 @@ public:
     // include/Optimizer.h:22-24 (gw is a cv::Mat 3x1 there)
     static void LocalBAPRVIDP(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, bool* pbStopFlag, Map* pMap,
                               const Vector3d& gw, LocalMapping* pLM = NULL);
+    // include/Optimizer.h:36-38: the same window with world-XYZ landmarks and Levenberg-Marquardt
+    static void LocalBundleAdjustmentNavStatePRV(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, bool* pbStopFlag, Map* pMap,
+                                                 const Vector3d& gw, LocalMapping* pLM = NULL);
+    static bool PackLocalBundleAdjustmentNavStatePRV(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw, PackedWindow& W);
+    static bool PackLocalVI(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw, bool idp, PackedWindow& W);
     // include/Optimizer.h:74
     static void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, LocalMapping* pLM = NULL);
 

@@ -110,6 +110,16 @@ int fc_local_ba_prvidp(void* m, const long* ids, int n, const double* gw, int st
     Optimizer::LocalBAPRVIDP(l.back(), l, &bstop, &M->map, g, &M->lm);
     return 0;
 }
+// LocalBundleAdjustmentNavStatePRV (VI window, XYZ landmarks, LM); mode 1: extraction only
+int fc_local_ba_prv_xyz(void* m, const long* ids, int n, const double* gw, int stop, int mode) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    std::list<KeyFrame*> l = window(M, ids, n);
+    bool bstop = stop != 0;
+    const Vector3d g{{gw[0], gw[1], gw[2]}};
+    if (mode == 1) return Optimizer::PackLocalBundleAdjustmentNavStatePRV(l.back(), l, g, Optimizer::LastWindowMutable()) ? 0 : -1;
+    Optimizer::LocalBundleAdjustmentNavStatePRV(l.back(), l, &bstop, &M->map, g, &M->lm);
+    return 0;
+}
 // LocalBundleAdjustment over an explicit keyframe list (include/Optimizer.h:57-59); mode 1: extraction only
 int fc_local_ba_vision_list(void* m, const long* ids, int n, int stop, int mode) {
     FcMap* M = reinterpret_cast<FcMap*>(m);

@@ -30,6 +30,7 @@ def lib():
         l.fc_add_observation.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_float, C.c_float, C.c_int]
         l.fc_local_ba_prvidp.argtypes = [C.c_void_p, _pl, C.c_int, _pd, C.c_int, C.c_int]
         l.fc_local_ba_vision.argtypes = [C.c_void_p, C.c_long, C.c_int]
+        l.fc_local_ba_prv_xyz.argtypes = [C.c_void_p, _pl, C.c_int, _pd, C.c_int, C.c_int]
         l.fc_local_ba_vision_list.argtypes = [C.c_void_p, _pl, C.c_int, C.c_int, C.c_int]
         l.fc_global_ba_prv.argtypes = [C.c_void_p, _pd, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int]
         l.fc_global_ba_vision.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int]
@@ -138,6 +139,10 @@ class FacadeMap:
         Pw = np.zeros(3, dtype=np.float32); n = C.c_long(0)
         self.L.fc_get_mappoint_gba(self.m, q, Pw.ctypes.data_as(_pf), C.byref(n))
         return Pw, n.value
+
+    def local_ba_prv_xyz(self, stop=0, extract_only=False):
+        ids = self.window_ids()
+        return self.L.fc_local_ba_prv_xyz(self.m, ids.ctypes.data_as(_pl), len(ids), _d(self.p.g_w), stop, 1 if extract_only else 0)
 
     def local_ba_vision_list(self, ids, stop=0, extract_only=False):
         ids = np.asarray(ids, dtype=np.int64)

@@ -324,3 +324,28 @@ def test_list_overload_of_local_bundle_adjustment_runs():
     for row, t in enumerate(win):
         np.testing.assert_array_equal(fm.pose_tcw(t)[:3, 3], q.kf_pose[row, :3].astype(np.float32))
     fm.close()
+
+
+@pytest.mark.gpu
+def test_facade_prv_xyz_window_equals_direct_solve():
+    """LocalBundleAdjustmentNavStatePRV (src/Optimizer.cpp:937-1388): the VI window with world-XYZ landmarks and LM."""
+    from mc_slam_amd import backend
+    p = synth.make_window(abi.VARIANT_PRV_XYZ, n_kf=9, n_fixed=1, n_pt=250, n_obs=1400, seed=65)
+    fm = facade.FacadeMap(p)
+    assert fm.local_ba_prv_xyz(extract_only=True) == 0
+    e = facade.last_problem()
+    assert (e.variant, e.algo, e.n_kf_free, e.n_imu, e.its_stage1, e.its_stage2, e.depth_min) == (1, abi.ALGO_LM, p.n_kf_free, p.n_imu, 5, 10, 0.0)
+    assert e.n_pt == p.n_pt and e.n_obs == p.n_obs
+    ba = backend.LocalBA(0); q, r = ba.solve(e); ba.close()
+    fm.close()
+    fm = facade.FacadeMap(p)
+    fm.local_ba_prv_xyz()
+    assert fm.L.fc_map_updated(fm.m) == 1
+    for i, t in enumerate(fm.window_ids()):
+        nav, T = fm.nav(int(t))
+        assert (nav[:7] == q.kf_pose[i]).all() and (nav[7:10] == q.kf_vel[i]).all() and (nav[16:22] == q.kf_bias[i, 6:]).all()
+    mp_ids, _ = facade.last_ids()
+    for j in range(0, len(mp_ids), 11):
+        Pw, _n, upd = fm.mappoint(int(mp_ids[j]))
+        assert upd == 1 and (Pw == q.pt[j].astype(np.float32)).all()
+    fm.close()
