@@ -709,10 +709,10 @@ DEVI void schur_write_block(const Batch& B, const WinDesc& d, const WinCtrl& c, 
 // LD = landmark dimension (1: inverse depth, slot record 8 doubles; 3: XYZ, slot record 24 doubles)
 // LP = lanes per pair: 64 (one pair per wave: small batches, latency) or 16 (four pairs per wave: throughput)
 template <int LD, int LP>
-DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4) {
+DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in = -1, int quad_in = 0) {
     constexpr int SS = (LD == 1) ? VBA_SLOT : VBA_SLOT3;
-    int w, quad;
-    if (!schur_map(B, max_quads, w, quad)) return;
+    int w = w_in, quad = quad_in;
+    if (w_in < 0 && !schur_map(B, max_quads, w, quad)) return;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
     if (!win_on(d, c)) return;
@@ -820,10 +820,11 @@ __global__ void __launch_bounds__(64) k_schur_off3_w(Batch B, int max_quads) {
 // diagonal pairs (a,a): every slot of keyframe a; also the reduced rhs (block_solver.hpp:436-439), the
 // unreduced b_p and the H_pp diagonal (LM's lambda init)
 template <int LD>
-DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk, double* sh_r, double* sh_b, double* sh_h) {
+DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk, double* sh_r, double* sh_b, double* sh_h,
+                          int w_in = -1, int a_in = 0) {
     constexpr int SS = (LD == 1) ? VBA_SLOT : VBA_SLOT3;
-    int w, a;
-    if (!schur_map(B, max_free, w, a)) return;
+    int w = w_in, a = a_in;
+    if (w_in < 0 && !schur_map(B, max_free, w, a)) return;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
     if (hd_pass ? !c.active : !win_on(d, c)) return;  // hd_pass: LM's pre-trial pass for computeLambdaInit
@@ -924,6 +925,24 @@ __global__ void __launch_bounds__(64) k_schur_diag(Batch B, int max_free) {
     __shared__ double blk[15 * 15 + 16];
     __shared__ double sh_r[6], sh_b[6], sh_h[6];
     schur_diag_body<1>(B, max_free, 0, blk, sh_r, sh_b, sh_h);
+}
+// Both Schur kernels of the inverse-depth variant in ONE launch, a window's diagonal pairs right before its off-diagonal
+// ones: they read the same slot and edge records, which are then still in the XCD's L2 for the second reader.
+__global__ void __launch_bounds__(64, 3) k_schur_all(Batch B, int max_free, int max_quads) {
+    __shared__ double blk[15 * 15 + 16];
+    __shared__ double sh_r[6], sh_b[6], sh_h[6];
+    int w, idx;
+    if (!schur_map(B, max_free + max_quads, w, idx)) return;
+    if (idx < max_free) schur_diag_body<1>(B, max_free, 0, blk, sh_r, sh_b, sh_h, w, idx);
+    else schur_off_body<1, 16>(B, max_quads, blk, w, idx - max_free);
+}
+__global__ void __launch_bounds__(64, 3) k_schur_all3(Batch B, int max_free, int max_quads) {  // XYZ landmarks
+    __shared__ double blk[15 * 15 + 16];
+    __shared__ double sh_r[6], sh_b[6], sh_h[6];
+    int w, idx;
+    if (!schur_map(B, max_free + max_quads, w, idx)) return;
+    if (idx < max_free) schur_diag_body<3>(B, max_free, 0, blk, sh_r, sh_b, sh_h, w, idx);
+    else schur_off_body<3, 16>(B, max_quads, blk, w, idx - max_free);
 }
 __global__ void __launch_bounds__(64) k_schur_diag3(Batch B, int max_free, int hd_pass) {
     __shared__ double blk[15 * 15 + 16];

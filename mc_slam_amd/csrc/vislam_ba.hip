@@ -680,14 +680,24 @@ void enqueue_solve_iteration(Handle* h) {
         ProfScope ps(h, VBA_PROF_SCHUR);
         const int ngrp = (n >= 8) ? 8 * ((n + 7) / 8) : n;
         if (idp) {
+            static const int fused_schur = getenv("VBA_SCHUR_SPLIT") ? 0 : 1;
+            if (n >= 8 && fused_schur) {
+                hipLaunchKernelGGL(k_schur_all, dim3((h->max_free + h->max_quads) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_quads);
+            } else {
             hipLaunchKernelGGL(k_schur_diag, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free);
             if (n >= 8) hipLaunchKernelGGL(k_schur_off, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
             else hipLaunchKernelGGL(k_schur_off_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
+            }
         } else {
             hipLaunchKernelGGL(k_dinv, dim3(h->max_pt_blk, n), dim3(64), 0, h->stream, B);
-            hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 0);
-            if (n >= 8) hipLaunchKernelGGL(k_schur_off3, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
-            else hipLaunchKernelGGL(k_schur_off3_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
+            static const int fused_schur3 = getenv("VBA_SCHUR_FUSE3") ? 1 : 0;  // measured on C2: no gain for the 192-B XYZ records
+            if (n >= 8 && fused_schur3) {
+                hipLaunchKernelGGL(k_schur_all3, dim3((h->max_free + h->max_quads) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_quads);
+            } else {
+                hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 0);
+                if (n >= 8) hipLaunchKernelGGL(k_schur_off3, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
+                else hipLaunchKernelGGL(k_schur_off3_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
+            }
         }
     }
     {
