@@ -382,6 +382,14 @@ void quat_to_R_host(const double* q, double* R) {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// >= this many windows: left-looking factorisation kernels, which never modify S (measured: the right-looking pair is faster
+// up to ~256 windows)
+bool use_left_looking(int n) {
+    static const int left_looking = getenv("VBA_RIGHT_LOOKING") ? 0 : 1;
+    static const int ll_min = getenv("VBA_LL_MIN") ? atoi(getenv("VBA_LL_MIN")) : 384;
+    return left_looking && n >= ll_min;
+}
+
 int do_upload(Handle* h, int n, vba_problem* const* probs) {
     static const bool timing = getenv("VBA_TIMING") != nullptr;
     const double t_begin = now_ms();
@@ -555,6 +563,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         pair_a.insert(pair_a.end(), st.pair_a.begin(), st.pair_a.end());
         pair_b.insert(pair_b.end(), st.pair_b.begin(), st.pair_b.end());
         offpair.insert(offpair.end(), st.off_pair.begin(), st.off_pair.end());
+        if (use_left_looking(n))   // S stays pristine: a sub-block nothing is ever added to keeps the zero of the upload
+            for (int pi = 0; pi < d.n_pairs; pi++)
+                if (st.pair_a[pi] != st.pair_b[pi] && st.pimu_begin[pi + 1] == st.pimu_begin[pi]) st.pair_mask[pi] &= 1;
         pairmask.insert(pairmask.end(), st.pair_mask.begin(), st.pair_mask.end());
         item_begin.insert(item_begin.end(), st.item_begin.begin(), st.item_begin.end());
         items.insert(items.end(), st.items.begin(), st.items.end());
@@ -612,7 +623,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (h2d(h, BUF_OFFPAIR, offpair) || h2d(h, BUF_PAIRMASK, pairmask)) return -1;
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
     // S: zero everything once, identity on the pads
-    for (int w = 0; w < n; w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
+    if (use_left_looking(n)) HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->stream));
+    for (int w = 0; w < n && !use_left_looking(n); w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
         const WinDesc& d = h->desc[w];
         if (d.nS > d.np)
             HIPCHK(h, hipMemsetAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)d.np * d.nS, 0, (size_t)(d.nS - d.np) * d.nS * 8, h->stream));
@@ -704,9 +716,7 @@ void enqueue_solve_iteration(Handle* h) {
         ProfScope ps(h, VBA_PROF_FACTOR);
         static const int split_min = getenv("VBA_SPLIT_MIN") ? atoi(getenv("VBA_SPLIT_MIN")) : 64;
         if (n >= split_min) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
-            static const int left_looking = getenv("VBA_RIGHT_LOOKING") ? 0 : 1;
-            static const int ll_min = getenv("VBA_LL_MIN") ? atoi(getenv("VBA_LL_MIN")) : 384;
-            const bool ll = left_looking && n >= ll_min;  // measured: the right-looking pair is faster up to ~256 windows
+            const bool ll = use_left_looking(n);
             for (int k = 0; k < h->max_nb && ll; k++) {  // every tile read once, updated in registers, written once
                 hipLaunchKernelGGL(k_chol_diag_ll, dim3(n), dim3(64), 0, h->stream, B, k);
                 if (h->pan_grid[k] > 0) hipLaunchKernelGGL(k_chol_panel_ll, dim3(h->pan_grid[k], n), dim3(64), 0, h->stream, B, k);
