@@ -386,7 +386,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 // up to ~256 windows)
 bool use_left_looking(int n) {
     static const int left_looking = getenv("VBA_RIGHT_LOOKING") ? 0 : 1;
-    static const int ll_min = getenv("VBA_LL_MIN") ? atoi(getenv("VBA_LL_MIN")) : 384;
+    static const int ll_min = getenv("VBA_LL_MIN") ? atoi(getenv("VBA_LL_MIN")) : 256;
     return left_looking && n >= ll_min;
 }
 

@@ -304,7 +304,7 @@ def test_global_ba_map_scale_properties(ba, oracle):
 @pytest.mark.parametrize("variant,nwin", [(abi.VARIANT_PRV_IDP, 66), (abi.VARIANT_PRV_IDP, 388), (abi.VARIANT_PRV_XYZ, 388),
                                           (abi.VARIANT_SE3_XYZ, 66), (abi.VARIANT_SE3_XYZ, 388)])
 def test_large_batches_switch_factorisation_kernels(ba, oracle, variant, nwin):
-    """>= 64 windows: split right-looking kernels (k_chol_panel / k_chol_update); >= 384 windows: left-looking tile
+    """>= 64 windows: split right-looking kernels (k_chol_panel / k_chol_update); >= 256 windows: left-looking tile
     kernels (k_chol_diag_ll / k_chol_panel_ll).  Same results as the single-window path (fused right-looking kernel)
     up to rounding, and the oracle's bars."""
     kw = [dict(n_kf=8, n_pt=200, n_obs=1000), dict(n_kf=13, n_pt=400, n_obs=2200), dict(n_kf=23, n_pt=900, n_obs=5200),
