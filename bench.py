@@ -138,10 +138,10 @@ def main():
             tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))[-1]
             tr = json.load(open(tj))
             if tr["batch"] == args.batch:
-                kmap = {"schur": ["k_schur_diag", "k_schur_off"], "linearize": ["k_lin2"],
+                kmap = {"schur": ["k_schur_all", "k_schur_diag", "k_schur_off"], "linearize": ["k_lin2"],
                         "factor": ["k_chol_step", "k_chol_panel", "k_chol_update", "k_chol_diag_ll", "k_chol_panel_ll"], "trsv": ["k_trsv"], "update": ["k_update"]}
                 ks = [tr["kernels"][k] for k in kmap.get(dom, []) if k in tr["kernels"]]
-                n_it = tr["kernels"]["k_schur_diag"]["active_launches"]
+                n_it = tr["kernels"]["k_schur_all" if "k_schur_all" in tr["kernels"] else "k_schur_diag"]["active_launches"]
                 n_cls = tr["kernels"]["k_lin2"]["active_launches"] if dom == "linearize" else n_it
                 roofline["traffic"] = sum((k["fetch_corrected"] + k["write"]) * k["active_launches"] for k in ks) / n_cls
                 roofline["traffic_source"] = os.path.basename(tj)
