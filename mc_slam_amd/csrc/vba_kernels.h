@@ -484,13 +484,15 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
         return;
     }
     __syncthreads();
-    // C. one lane per landmark: sums over its edges (fixed order): D, b_l and, for the reference keyframe,
-    //    sum Br^T Br = Q^T (sum A^T A) Q, sum Br^T a = Q^T sum A^T a, sum Br^T r = Q^T sum A^T r with Q = [-I | N0]
-    if (t < npb) {
-        const int p = p0 + t;
+    // C. FOUR lanes per landmark: each sums every fourth edge (fixed order), the quad adds up (fixed order again), then
+    //    all four hold D, b_l and, for the reference keyframe, sum Br^T Br = Q^T (sum A^T A) Q, sum Br^T a = Q^T sum A^T a,
+    //    sum Br^T r = Q^T sum A^T r with Q = [-I | N0]; the three records of the landmark leave from different lanes
+    if (t < 4 * npb) {
+        const int jl = t >> 2, sub = t & 3;
+        const int p = p0 + jl;
         const size_t gp = d.pt0 + p;
         double D = 0, bl = 0, M[6] = {0, 0, 0, 0, 0, 0}, wa[3] = {0, 0, 0}, wr[3] = {0, 0, 0};
-        for (int o = ob[p] - e0; o < ob[p + 1] - e0; o++) {
+        for (int o = ob[p] - e0 + sub; o < ob[p + 1] - e0; o += 4) {
             const double* er = ER + o * LIN2_ES;
             const double a0 = er[6], a1 = er[7], q0 = er[8], q1 = er[9];
             D += a0 * a0 + a1 * a1;
@@ -505,25 +507,45 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
                 for (int j = i; j < 3; j++) M[gi++] += b0 * er[j] + b1 * er[3 + j];
             }
         }
+#define QUADSUM(v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); }
+        QUADSUM(D) QUADSUM(bl)
+#pragma unroll
+        for (int i = 0; i < 6; i++) QUADSUM(M[i])
+#pragma unroll
+        for (int i = 0; i < 3; i++) { QUADSUM(wa[i]) QUADSUM(wr[i]) }
+#undef QUADSUM
         const double sD = (D > 0.0) ? sqrt(1.0 / D) : 0.0;
         const double beta = sD * bl;
-        double* q = PT + t * LIN2_PS;
-        q[17] = sD;
-        q[18] = beta;
+        double* q = PT + jl * LIN2_PS;
         const double rfm = q[16];  // 1: reference keyframe is free, 0: fixed (no Hessian block)
-        double N0[9], Ms[9], MN[9], W0[6], g0[6], G0[21];
+        double N0[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) N0[i] = q[7 + i];
-        Ms[0] = M[0]; Ms[1] = M[1]; Ms[2] = M[2]; Ms[3] = M[1]; Ms[4] = M[3]; Ms[5] = M[4]; Ms[6] = M[2]; Ms[7] = M[4]; Ms[8] = M[5];
-        mm3(Ms, N0, MN);
+        const int pp = B.pt_perm[gp];  // landmark records grouped by reference keyframe
+        if (sub == 0) {
+            q[17] = sD;
+            q[18] = beta;
+            double* sr = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + d.n_obs + pp);
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            W0[k] = -wa[k] * rfm;
-            g0[k] = wr[k] * rfm;
-            W0[3 + k] = (N0[k] * wa[0] + N0[3 + k] * wa[1] + N0[6 + k] * wa[2]) * rfm;
-            g0[3 + k] = -(N0[k] * wr[0] + N0[3 + k] * wr[1] + N0[6 + k] * wr[2]) * rfm;
-        }
-        {
+            for (int k = 0; k < 3; k++) {
+                sr[k] = -wa[k] * rfm * sD;
+                sr[3 + k] = (N0[k] * wa[0] + N0[3 + k] * wa[1] + N0[6 + k] * wa[2]) * rfm * sD;
+            }
+            sr[6] = beta;
+            sr[7] = sD;
+        } else if (sub == 3) {
+            double* nr = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + pp);
+#pragma unroll
+            for (int i = 0; i < 9; i++) nr[i] = N0[i];
+        } else {
+            double Ms[9], MN[9], G0[21], g0[6];
+            Ms[0] = M[0]; Ms[1] = M[1]; Ms[2] = M[2]; Ms[3] = M[1]; Ms[4] = M[3]; Ms[5] = M[4]; Ms[6] = M[2]; Ms[7] = M[4]; Ms[8] = M[5];
+            mm3(Ms, N0, MN);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                g0[k] = wr[k] * rfm;
+                g0[3 + k] = -(N0[k] * wr[0] + N0[3 + k] * wr[1] + N0[6 + k] * wr[2]) * rfm;
+            }
             int gi = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++)
@@ -535,22 +557,18 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
                     else v = N0[i - 3] * MN[j - 3] + N0[3 + i - 3] * MN[3 + j - 3] + N0[6 + i - 3] * MN[6 + j - 3];
                     G0[gi++] = v * rfm;
                 }
+            double* pr = B.prec + VBA_PREC * (size_t)(d.pt0 + pp);
+            if (sub == 1) {
+#pragma unroll
+                for (int i = 0; i < 14; i++) pr[i] = G0[i];
+            } else {
+#pragma unroll
+                for (int i = 14; i < 21; i++) pr[i] = G0[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) pr[21 + i] = g0[i];
+                pr[27] = D;
+            }
         }
-        const int pp = B.pt_perm[gp];  // landmark records grouped by reference keyframe
-        double* sr = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + d.n_obs + pp);
-#pragma unroll
-        for (int i = 0; i < 6; i++) sr[i] = W0[i] * sD;
-        sr[6] = beta;
-        sr[7] = sD;
-        double* pr = B.prec + VBA_PREC * (size_t)(d.pt0 + pp);
-#pragma unroll
-        for (int i = 0; i < 21; i++) pr[i] = G0[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) pr[21 + i] = g0[i];
-        pr[27] = D;
-        double* nr = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + pp);
-#pragma unroll
-        for (int i = 0; i < 9; i++) nr[i] = N0[i];
     }
     __syncthreads();
     // D. one lane per edge: slot record; Bi and r into the LDS row for the transposed store
