@@ -571,33 +571,21 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
         }
     }
     __syncthreads();
-    // D. one lane per edge: slot record; Bi and r into the LDS row for the transposed store
+    // D. one lane per edge: its slot record and its edge record (Bi and the weighted residual r; the reader rebuilds
+    //    g = -Bi^T r and Br = [-A | A N0]).  The records live keyframe-major (slot_perm), so neighbouring lanes write
+    //    to unrelated 128-B lines anyway: each lane stores its own record with seven 16-B stores, no LDS transpose
     if (t < ne) {
         const double sD = PT[pl * LIN2_PS + 17], beta = PT[pl * LIN2_PS + 18];
-        double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + B.slot_perm[d.obs0 + e0 + t]);
-        double* er = ER + t * LIN2_ES;
+        const int pe = B.slot_perm[d.obs0 + e0 + t];
+        double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + pe);
 #pragma unroll
         for (int i = 0; i < 6; i++) sl[i] = on ? (Bi[i] * a[0] + Bi[6 + i] * a[1]) * sD : 0.0;
         sl[6] = beta;
         sl[7] = sD;
+        double2* dst = reinterpret_cast<double2*>(B.erec + VBA_EREC1 * (size_t)(d.obs0 + pe));
 #pragma unroll
-        for (int i = 0; i < 12; i++) er[i] = Bi[i];
-        er[12] = r2[0]; er[13] = r2[1];
-    }
-    __syncthreads();
-    // E. edge records out (Bi and the weighted residual r; the reader rebuilds g = -Bi^T r and Br = [-A | A N0]),
-    //    as contiguous 16-B chunks
-    {
-        double* dst = B.erec + VBA_EREC1 * (size_t)d.obs0;
-        const int* perm = B.slot_perm + d.obs0 + e0;
-        const int nch = ne * (VBA_EREC1 / 2);
-        for (int ch = t; ch < nch; ch += 256) {  // eight lanes per 128-B record
-            const int row = ch / (VBA_EREC1 / 2), col = (ch % (VBA_EREC1 / 2)) * 2;
-            double2 v;
-            v.x = (col < 14) ? ER[row * LIN2_ES + col] : 0.0;
-            v.y = (col < 14) ? ER[row * LIN2_ES + col + 1] : 0.0;
-            *reinterpret_cast<double2*>(dst + (size_t)perm[row] * VBA_EREC1 + col) = v;
-        }
+        for (int i = 0; i < 6; i++) dst[i] = make_double2(Bi[2 * i], Bi[2 * i + 1]);
+        dst[6] = make_double2(r2[0], r2[1]);
     }
     const double tot = block_sum256(chi, red);
     if (t == 0) B.part[d.part0 + lb] = tot;
