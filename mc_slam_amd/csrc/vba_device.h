@@ -8,7 +8,8 @@
 
 #define VBA_NB 32          // block size of the dense reduced-system factorisation
 #define VBA_EREC 32        // doubles per edge record, XYZ variants (256 B)
-#define VBA_EREC1 16       // doubles per edge record, inverse-depth variant (128 B = one cache line): Bi(12), r(2)
+#define VBA_EREC1 8        // doubles per edge record, inverse-depth variant (64 B): P_c (3), sqrt(rho' w) (1), r (2); the
+                           // readers rebuild Bi = [A | B_rot] from it and the observer's rotation (rebuild_edge)
 #define VBA_N0REC 16       // doubles per landmark: N0 = R0 hat(b0) (9), so that Br = [-A | A N0] is rebuilt by the reader
 #define VBA_PREC 32        // doubles per point record  (256 B)
 #define VBA_SLOT 8         // doubles per slot record   (64 B = one line), inverse-depth landmarks

@@ -413,10 +413,9 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
     // B. one lane per edge.  With A = sqrt(rho' w) J_pi R_cb R_i^T (2x3) the two pose Jacobians of the edge are
     //    Bi = [A | -sqrt(.) (J_pi R_cb) x ta] (observer) and Br = A [-I | N0] (reference keyframe, N0 per landmark).
     double chi = 0.0;
-    double Bi[12], a[2] = {0, 0}, r2[2] = {0, 0};
-#pragma unroll
-    for (int i = 0; i < 12; i++) Bi[i] = 0.0;
-    bool on = false;
+    double ub[6] = {0, 0, 0, 0, 0, 0};      // Bi^T a: numerator of the edge's slot record
+    double rpc[3] = {0, 0, 1}, rsc = 0.0;   // edge record: P_c and the Jacobian scale (0: no Jacobian for the readers)
+    double a[2] = {0, 0}, r2[2] = {0, 0};
     int pl = 0;
     if (t < ne) {
         const size_t go = d.obs0 + e0 + t;
@@ -433,6 +432,7 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
         mv3(d.Rcb, ta, Pc);
         Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
         B.depth_e[go] = Pc[2];
+        rpc[0] = Pc[0]; rpc[1] = Pc[1]; rpc[2] = Pc[2];
         double A[6] = {0, 0, 0, 0, 0, 0};
         if (!B.lvl[go]) {
             const double iz = 1.0 / Pc[2];
@@ -445,7 +445,6 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
             if (c.robust_vis) chi = huber(s, d.hub_vis, &rw);
             else chi = s;
             if (mode == LIN_FULL) {
-                on = true;
                 const double sc = sqrt(rw * wgt);
                 const double Jp[6] = {fx * iz, 0.0, -Pc[0] * iz * fx * iz, 0.0, fy * iz, -Pc[1] * iz * fy * iz};
                 double Jc[6];
@@ -455,6 +454,8 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
                     for (int k = 0; k < 3; k++)
                         Jc[3 * rr + k] = Jp[3 * rr] * d.Rcb[k] + Jp[3 * rr + 1] * d.Rcb[3 + k] + Jp[3 * rr + 2] * d.Rcb[6 + k];
                 const bool of = kf_free(B, d, kf) & 1;
+                rsc = of ? sc : 0.0;
+                double Bi[12];
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
 #pragma unroll
@@ -468,6 +469,8 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
                     Bi[6 * rr + 4] = of ? -sc * (j2 * ta[0] - j0 * ta[2]) : 0.0;
                     Bi[6 * rr + 5] = of ? -sc * (j0 * ta[1] - j1 * ta[0]) : 0.0;
                 }
+#pragma unroll
+                for (int i = 0; i < 6; i++) ub[i] = Bi[i] * a[0] + Bi[6 + i] * a[1];
                 r2[0] = sc * ex; r2[1] = sc * ey;
             }
         }
@@ -571,21 +574,20 @@ __global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
         }
     }
     __syncthreads();
-    // D. one lane per edge: its slot record and its edge record (Bi and the weighted residual r; the reader rebuilds
-    //    g = -Bi^T r and Br = [-A | A N0]).  The records live keyframe-major (slot_perm), so neighbouring lanes write
-    //    to unrelated 128-B lines anyway: each lane stores its own record with seven 16-B stores, no LDS transpose
+    // D. one lane per edge: its slot record U = Bi^T a / sqrt(D) and its 64-B edge record (P_c, scale, weighted residual),
+    //    from which the Schur kernels rebuild Bi, g = -Bi^T r and Br = [-A | A N0].  Records live keyframe-major (slot_perm).
     if (t < ne) {
         const double sD = PT[pl * LIN2_PS + 17], beta = PT[pl * LIN2_PS + 18];
         const int pe = B.slot_perm[d.obs0 + e0 + t];
         double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + pe);
 #pragma unroll
-        for (int i = 0; i < 6; i++) sl[i] = on ? (Bi[i] * a[0] + Bi[6 + i] * a[1]) * sD : 0.0;
+        for (int i = 0; i < 6; i++) sl[i] = ub[i] * sD;
         sl[6] = beta;
         sl[7] = sD;
         double2* dst = reinterpret_cast<double2*>(B.erec + VBA_EREC1 * (size_t)(d.obs0 + pe));
-#pragma unroll
-        for (int i = 0; i < 6; i++) dst[i] = make_double2(Bi[2 * i], Bi[2 * i + 1]);
-        dst[6] = make_double2(r2[0], r2[1]);
+        dst[0] = make_double2(rpc[0], rpc[1]);
+        dst[1] = make_double2(rpc[2], rsc);
+        dst[2] = make_double2(r2[0], r2[1]);
     }
     const double tot = block_sum256(chi, red);
     if (t == 0) B.part[d.part0 + lb] = tot;
@@ -714,6 +716,36 @@ DEVI void schur_write_block(const Batch& B, const WinDesc& d, const WinCtrl& c, 
 // instead of 6 per pair, and every lane sees ~6 items instead of ~1.4).
 // LD = landmark dimension (1: inverse depth, slot record 8 doubles; 3: XYZ, slot record 24 doubles)
 // LP = lanes per pair: 64 (one pair per wave: small batches, latency) or 16 (four pairs per wave: throughput)
+// Bi = [A | B_rot] of an EdgePRIDP from its 64-B record (P_c, s = sqrt(rho' w), r) and the observer's rotation R_a:
+// J_c = J_pi(P_c) R_cb, A = s J_c R_a^T, B_rot = -s J_c x t_a with t_a = R_cb^T (P_c - t_cb)   (k_lin2 phase B, g2otypes.cpp:139-145)
+DEVI void rebuild_edge(const WinDesc& d, const double* Ra, const double* rec, double* b0, double* b1, double& r0, double& r1) {
+    const double Pc[3] = {rec[0], rec[1], rec[2]}, sc = rec[3];
+    r0 = rec[4]; r1 = rec[5];
+    const double fx = d.K[0], fy = d.K[1];
+    const double iz = 1.0 / Pc[2];
+    const double Jp[6] = {fx * iz, 0.0, -Pc[0] * iz * fx * iz, 0.0, fy * iz, -Pc[1] * iz * fy * iz};
+    double Jc[6];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            Jc[3 * rr + k] = Jp[3 * rr] * d.Rcb[k] + Jp[3 * rr + 1] * d.Rcb[3 + k] + Jp[3 * rr + 2] * d.Rcb[6 + k];
+    const double pm[3] = {Pc[0] - d.tcb[0], Pc[1] - d.tcb[1], Pc[2] - d.tcb[2]};
+    double ta[3];
+    mtv3(d.Rcb, pm, ta);
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        double* bb = rr ? b1 : b0;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            bb[k] = sc * (Jc[3 * rr] * Ra[3 * k] + Jc[3 * rr + 1] * Ra[3 * k + 1] + Jc[3 * rr + 2] * Ra[3 * k + 2]);
+        const double j0 = Jc[3 * rr], j1 = Jc[3 * rr + 1], j2 = Jc[3 * rr + 2];
+        bb[3] = -sc * (j1 * ta[2] - j2 * ta[1]);
+        bb[4] = -sc * (j2 * ta[0] - j0 * ta[2]);
+        bb[5] = -sc * (j0 * ta[1] - j1 * ta[0]);
+    }
+}
+
 template <int LD, int LP>
 DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in = -1, int quad_in = 0) {
     constexpr int SS = (LD == 1) ? VBA_SLOT : VBA_SLOT3;
@@ -767,14 +799,18 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
                 const bool a_ref = sa >= d.n_obs;
                 const double* re = B.erec + VBA_EREC1 * (size_t)(d.obs0 + (a_ref ? sb : sa));
                 const double* n0 = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + (a_ref ? sa : sb) - d.n_obs);
-                double N0[9];
+                const double* Ro = B.kfR + 12 * (size_t)(d.kf0 + (a_ref ? b : a));  // the observer's rotation
+                double N0[9], Rm[9], rec[6], bi0[6], bi1[6], rr0, rr1;
 #pragma unroll
-                for (int i = 0; i < 9; i++) N0[i] = n0[i];
+                for (int i = 0; i < 9; i++) { N0[i] = n0[i]; Rm[i] = Ro[i]; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) rec[i] = re[i];
+                rec[4] = rec[5] = 0.0;
+                rebuild_edge(d, Rm, rec, bi0, bi1, rr0, rr1);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    double bi[6], br[6];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) bi[j] = re[6 * h + j];
+                    const double* bi = h ? bi1 : bi0;
+                    double br[6];
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         br[k] = -bi[k];
@@ -845,6 +881,12 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
     const int ib = B.item_begin[d.pair0 + d.win + pr], ie = B.item_begin[d.pair0 + d.win + pr + 1];
     const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
+    double Ra[9];  // rotation of keyframe a (the observer of every non-reference item of its diagonal pair)
+    {
+        const double* Ca = B.kfR + 12 * (size_t)(d.kf0 + a);
+#pragma unroll
+        for (int i = 0; i < 9; i++) Ra[i] = Ca[i];
+    }
     int nxt = 0;
     if (ib + t < ie) nxt = items[ib + t].x;
     for (int it = ib + t; it < ie; it += 64) {
@@ -865,10 +907,17 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
             for (int i = 0; i < 6; i++) bp[i] += pr_[21 + i];
         } else {
             const double* ra = B.erec + ((LD == 1) ? VBA_EREC1 : VBA_EREC) * (size_t)(d.obs0 + sa);
-            const double r0 = (LD == 1) ? ra[12] : 0.0, r1 = (LD == 1) ? ra[13] : 0.0;
+            double r0 = 0.0, r1 = 0.0;
             double b0[6], b1[6];
+            if (LD == 1) {
+                double rec[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) { b0[i] = ra[i]; b1[i] = ra[6 + i]; }
+                for (int i = 0; i < 6; i++) rec[i] = ra[i];
+                rebuild_edge(d, Ra, rec, b0, b1, r0, r1);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; i++) { b0[i] = ra[i]; b1[i] = ra[6 + i]; }
+            }
             int gi = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
