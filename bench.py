@@ -23,6 +23,57 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def bench_pose(args, rank, local_rank, world, dist, torch):
+    """Extra measurement: frames/s of vba_pose_optimize on a batch of tracked frames (300 correspondences, last
+    keyframe and last-frame variants alternating), end to end per call (host gather + H2D + the one kernel + D2H); the CPU
+    oracle's PoseOptimization restatement on the same frames beside it."""
+    import numpy as np
+    from mc_slam_amd import synth, backend, shard
+    nb = args.batch if args.batch != 2048 else 4096
+    distinct = [synth.make_frame(seed=shard.window_seed(g), n_obs=300, last_is_frame=bool(i % 2))
+                for i, g in enumerate(shard.window_ids(16 * world, rank, world))]
+    frames = [distinct[i % len(distinct)] for i in range(nb)]
+    ba = backend.LocalBA(local_rank)
+    packed = ba.pose_pack(frames)
+    meter = shard.ThroughputMeter(dist, torch.cuda.synchronize)
+    for _ in range(args.warmup):
+        ba.pose_run(packed)
+    meter.start()
+    for _ in range(args.steps):
+        ba.pose_run(packed)
+    total, dt = meter.stop(nb * args.steps, device="cuda")
+    res = [b.get(s_) for b, s_ in zip(packed[2], packed[1])]
+    out = None
+    if rank == 0:
+        cpu, verified = None, "batch self-consistent"
+        for i, r in enumerate(res):
+            j = i % len(distinct)
+            if r.its_done != res[j].its_done or (r.nav != res[j].nav).any():
+                raise SystemExit("bench: frame %d did not solve like its twin %d" % (i, j))
+        if not args.no_cpu_baseline:
+            import oracle_lib
+            t0 = time.perf_counter()
+            ros = [oracle_lib.pose_optimize(f) for f in distinct]
+            tc = time.perf_counter() - t0
+            for r, ro in zip(res, ros):
+                if r.its_done != ro.its_done or (r.outlier != ro.outlier).any() or np.abs(r.nav[:3] - ro.nav[:3]).max() > 1e-6:
+                    raise SystemExit("bench: a frame does not match the CPU oracle")
+            verified += "; %d distinct frames == oracle (LM iterations, outlier bitmap, P 1e-6 m)" % len(distinct)
+            cpu = {"value": len(distinct) / tc, "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "%d frames, single thread, oracle/libvba_oracle.so" % len(distinct)}
+        out = {"metric": "IMU-aided PoseOptimization frames/sec (300 correspondences) [extra measurement]", "value": total / dt, "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "Optimizer::PoseOptimization(Frame*, KeyFrame*|Frame*, IMUPreintegrator, gw, bComputeMarg): 4 x optimize(10) LM + "
+                                      "reclassification + marginals per frame", "frames_per_gpu_per_step": nb, "distinct_frames": len(distinct)},
+               "roofline": None, "cpu_baseline": cpu, "verified": verified}
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -30,8 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=2048, help="windows per GPU per step")
     ap.add_argument("--distinct", type=int, default=16, help="distinct seeded windows generated per rank (cycled to fill the batch)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba"],
-                    help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, for extra measurements")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose"],
+                    help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, pose = IMU-aided per-frame pose optimisation: extra measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -59,6 +110,9 @@ def main():
     torch.cuda.set_device(local_rank)
 
     from mc_slam_amd import synth, backend, shard
+
+    if args.workload == "pose":
+        return bench_pose(args, rank, local_rank, world, dist, torch)
 
     # synthetic windows of configs[2]; window w of the job belongs to rank w % world, seed 100 + w
     n_distinct = min(args.distinct, args.batch)
