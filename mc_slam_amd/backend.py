@@ -135,12 +135,18 @@ class LocalBA:
         rr = (C.POINTER(abi.vba_frame_result) * n)(*[C.pointer(b.s) for b in bufs])
         return n, structs, bufs, pp, rr, frames
 
-    def pose_run(self, packed):
-        n, structs, bufs, pp, rr, frames = packed
-        for s, f in zip(structs, frames):   # a run starts from the frame's initial state
-            s.nav[:] = f.nav.tolist()
-        if self.lib.vba_pose_optimize(self.h, n, pp, rr) != 0:
+    def pose_reset(self, packed):
+        """vba_pose_optimize updates nav in place: put the frames' initial states back before the next run"""
+        for s, f in zip(packed[1], packed[5]):
+            C.memmove(C.addressof(s) + abi.vba_frame_problem.nav.offset, f.nav.ctypes.data, 8 * abi.NAV_STRIDE)
+
+    def pose_call(self, packed):
+        if self.lib.vba_pose_optimize(self.h, packed[0], packed[3], packed[4]) != 0:
             raise self._err("vba_pose_optimize")
+
+    def pose_run(self, packed):
+        self.pose_reset(packed)
+        self.pose_call(packed)
 
     def pose_optimize(self, frames):
         """vba_pose_optimize on copies of the FrameProblems: list of abi.FrameResult (with the optimised nav)"""

@@ -44,6 +44,26 @@ struct DevBuf {
     }
 };
 
+struct PinnedBuf {   // persistent pinned host staging (grown on demand)
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 enum {
     BUF_DESC, BUF_CTRL, BUF_POSE, BUF_VEL, BUF_BIAS, BUF_KFR, BUF_POSE0, BUF_VEL0, BUF_BIAS0, BUF_POSEBK, BUF_VELBK,
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
@@ -65,6 +85,7 @@ struct Handle {
     DevBuf buf[BUF_N];
     DevBuf preint;  // arena of vba_preintegrate
     DevBuf pose_arena;  // arena of vba_pose_optimize
+    PinnedBuf pose_host_in, pose_host_out;  // its pinned staging: one H2D and one D2H per call
     Batch B;
     std::vector<WinDesc> desc;
     std::vector<WinCtrl> hctrl;
@@ -1026,6 +1047,8 @@ int vba_destroy(void* handle) {
     for (auto& b : h->buf) b.release();
     h->preint.release();
     h->pose_arena.release();
+    h->pose_host_in.release();
+    h->pose_host_out.release();
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
     for (auto st : h->xstreams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (h->stop_host) (void)hipHostFree((void*)h->stop_host);
@@ -1166,37 +1189,55 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
     if (!h) return -1;
     if (n_frames <= 0 || !inout || !out) return fail(h, "vba_pose_optimize: bad arguments");
     HIPCHK(h, hipSetDevice(h->device));
-    std::vector<FrameDesc> desc(n_frames);
     size_t n_tot = 0;
     for (int f = 0; f < n_frames; f++) {
         const vba_frame_problem* F = inout[f];
         if (!F || !out[f] || F->n_obs < 0 || (F->n_obs > 0 && (!F->obs_pw || !F->obs_uv || !F->obs_w || !out[f]->outlier)))
             return fail(h, "vba_pose_optimize: bad frame");
+        if (F->last_is_frame < 0 || F->last_is_frame > 2) return fail(h, "vba_pose_optimize: unknown frame kind");
         if (F->last_is_frame == VBA_FRAME_FRAME && F->n_obs_last > 0 && (!F->last_pw || !F->last_uv || !F->last_w)) return fail(h, "vba_pose_optimize: bad last frame");
         n_tot += (size_t)F->n_obs + (F->last_is_frame == VBA_FRAME_FRAME ? (size_t)F->n_obs_last : 0);
     }
-    std::vector<double> pw(3 * n_tot + 3), uv(2 * n_tot + 2), ww(n_tot + 1);
-    size_t o = 0;
-    for (int f = 0; f < n_frames; f++) {
+    // one device arena and one pinned staging block with the same layout: [desc | pw | uv | w] go up in one copy,
+    // [out | lvl] come back in one
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_desc = up(sizeof(FrameDesc) * n_frames), b_pw = up((3 * n_tot + 3) * 8), b_uv = up((2 * n_tot + 2) * 8), b_w = up((n_tot + 1) * 8);
+    const size_t b_in = b_desc + b_pw + b_uv + b_w;
+    const size_t b_out = up(sizeof(FrameOut) * n_frames), b_lvl = up(n_tot + 1), b_err = up((2 * n_tot + 2) * 8);
+    HIPCHK(h, h->pose_arena.ensure(b_in + b_out + b_lvl + b_err));
+    HIPCHK(h, h->pose_host_in.ensure(b_in));
+    HIPCHK(h, h->pose_host_out.ensure(b_out + b_lvl));
+    char* hin = reinterpret_cast<char*>(h->pose_host_in.p);
+    FrameDesc* desc = reinterpret_cast<FrameDesc*>(hin);
+    double* pw = reinterpret_cast<double*>(hin + b_desc);
+    double* uv = reinterpret_cast<double*>(hin + b_desc + b_pw);
+    double* ww = reinterpret_cast<double*>(hin + b_desc + b_pw + b_uv);
+    {   // offsets first, then the frames are packed by a few host threads
+        size_t o = 0;
+        for (int f = 0; f < n_frames; f++) {
+            const vba_frame_problem* F = inout[f];
+            FrameDesc& d = desc[f];
+            std::memset(&d, 0, sizeof d);
+            d.last_is_frame = F->last_is_frame;
+            d.n_obs = F->n_obs;
+            d.n_last = (d.last_is_frame == VBA_FRAME_FRAME) ? F->n_obs_last : 0;
+            d.obs0 = (int)o; o += d.n_obs;
+            d.last0 = (int)o; o += d.n_last;
+        }
+    }
+    auto pack = [&](int f) {
         const vba_frame_problem* F = inout[f];
         FrameDesc& d = desc[f];
-        std::memset(&d, 0, sizeof d);
-        if (F->last_is_frame < 0 || F->last_is_frame > 2) return fail(h, "vba_pose_optimize: unknown frame kind");
-        d.last_is_frame = F->last_is_frame;
         d.compute_marg = F->compute_marg ? 1 : 0;
-        d.n_obs = F->n_obs;
-        d.n_last = (d.last_is_frame == VBA_FRAME_FRAME) ? F->n_obs_last : 0;
-        d.obs0 = (int)o;
+        size_t o = (size_t)d.obs0;
         std::memcpy(&pw[3 * o], F->obs_pw, 24 * (size_t)d.n_obs);
         std::memcpy(&uv[2 * o], F->obs_uv, 16 * (size_t)d.n_obs);
         std::memcpy(&ww[o], F->obs_w, 8 * (size_t)d.n_obs);
-        o += d.n_obs;
-        d.last0 = (int)o;
+        o = (size_t)d.last0;
         if (d.n_last) {
             std::memcpy(&pw[3 * o], F->last_pw, 24 * (size_t)d.n_last);
             std::memcpy(&uv[2 * o], F->last_uv, 16 * (size_t)d.n_last);
             std::memcpy(&ww[o], F->last_w, 8 * (size_t)d.n_last);
-            o += d.n_last;
         }
         std::memcpy(d.nav, F->nav, sizeof d.nav);
         std::memcpy(d.nav_last, F->nav_last, sizeof d.nav_last);
@@ -1210,33 +1251,34 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
         d.inv_bg = F->inv_bg_rw2; d.inv_ba = F->inv_ba_rw2;
         d.hub_prior = (double)(float)std::sqrt(30.5779); d.hub_pvr = (double)(float)std::sqrt(21.666);
         d.hub_bias = (double)(float)std::sqrt(16.812); d.hub_mono = (double)(float)std::sqrt(5.991);
+    };
+    {
+        const int nt = (n_frames >= 256) ? std::max(1, std::min(8, (int)std::thread::hardware_concurrency())) : 1;
+        std::atomic<int> next(0);
+        auto work = [&]() { for (int f = next.fetch_add(1); f < n_frames; f = next.fetch_add(1)) pack(f); };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
     }
-    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t b_desc = up(sizeof(FrameDesc) * n_frames), b_out = up(sizeof(FrameOut) * n_frames);
-    const size_t b_pw = up(pw.size() * 8), b_uv = up(uv.size() * 8), b_w = up(ww.size() * 8), b_err = up((2 * n_tot + 2) * 8), b_lvl = up(n_tot + 1);
-    HIPCHK(h, h->pose_arena.ensure(b_desc + b_out + b_pw + b_uv + b_w + b_err + b_lvl));
     char* base = reinterpret_cast<char*>(h->pose_arena.p);
     PoseBatch B;
     B.desc = reinterpret_cast<const FrameDesc*>(base);
-    B.out = reinterpret_cast<FrameOut*>(base + b_desc);
-    double* d_pw = reinterpret_cast<double*>(base + b_desc + b_out);
-    double* d_uv = reinterpret_cast<double*>(base + b_desc + b_out + b_pw);
-    double* d_w = reinterpret_cast<double*>(base + b_desc + b_out + b_pw + b_uv);
-    B.pw = d_pw; B.uv = d_uv; B.w = d_w;
-    B.err = reinterpret_cast<double*>(base + b_desc + b_out + b_pw + b_uv + b_w);
-    B.lvl = reinterpret_cast<unsigned char*>(base + b_desc + b_out + b_pw + b_uv + b_w + b_err);
+    B.pw = reinterpret_cast<const double*>(base + b_desc);
+    B.uv = reinterpret_cast<const double*>(base + b_desc + b_pw);
+    B.w = reinterpret_cast<const double*>(base + b_desc + b_pw + b_uv);
+    B.out = reinterpret_cast<FrameOut*>(base + b_in);
+    B.lvl = reinterpret_cast<unsigned char*>(base + b_in + b_out);
+    B.err = reinterpret_cast<double*>(base + b_in + b_out + b_lvl);
     B.n_frames = n_frames;
-    HIPCHK(h, hipMemcpyAsync(base, desc.data(), sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(d_pw, pw.data(), pw.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(d_uv, uv.data(), uv.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(d_w, ww.data(), ww.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(base, hin, b_in, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(64), 0, h->stream, B);
     HIPCHK(h, hipGetLastError());
-    std::vector<FrameOut> res(n_frames);
-    std::vector<unsigned char> lvl(n_tot + 1);
-    HIPCHK(h, hipMemcpyAsync(res.data(), B.out, sizeof(FrameOut) * n_frames, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(lvl.data(), B.lvl, n_tot + 1, hipMemcpyDeviceToHost, h->stream));
+    char* hout = reinterpret_cast<char*>(h->pose_host_out.p);
+    HIPCHK(h, hipMemcpyAsync(hout, base + b_in, b_out + b_lvl, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    const FrameOut* res = reinterpret_cast<const FrameOut*>(hout);
+    const unsigned char* lvl = reinterpret_cast<const unsigned char*>(hout + b_out);
     for (int f = 0; f < n_frames; f++) {
         vba_frame_problem* F = inout[f];
         vba_frame_result* R = out[f];
