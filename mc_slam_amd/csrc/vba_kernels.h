@@ -85,6 +85,13 @@ DEVI int imu_act(const Batch& B, const WinDesc& d, int i, int j) {
 }
 DEVI bool imu_robust(const WinDesc& d) { return !(d.protocol == 1 && !d.robust); }
 
+// upload: identity on the padded diagonal of S (rows np..nS, fewer than VBA_NB of them); the solve never touches the pads
+__global__ void __launch_bounds__(64) k_init_pads(Batch B) {
+    const WinDesc& d = B.desc[blockIdx.x];
+    const int i = d.np + threadIdx.x;
+    if (i < d.nS) B.S[d.S0 + (size_t)i * d.nS + i] = 1.0;
+}
+
 __global__ void __launch_bounds__(64) k_reset(Batch B) {
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
@@ -355,7 +362,7 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
 #define LIN2_PS 19   // LDS row stride of one landmark: dd, y(3), Xw(3), N0(9), ref_free, sD, beta
 #define LIN2_LDS ((256 * LIN2_ES + 64 * LIN2_PS + 4) * 8)   // 40 480 B: four workgroups per CU
 
-__global__ void __launch_bounds__(256) k_lin2(Batch B, int nblk_lin, int mode) {
+__global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode) {
     extern __shared__ double lsm[];
     double* ER = lsm;                       // 256 x LIN2_ES
     double* PT = lsm + 256 * LIN2_ES;       // 64 x LIN2_PS

@@ -653,14 +653,6 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_VEC].p, 0, (size_t)vec0 * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_YV].p, 0, (size_t)vec0 * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_BPOSE].p, 0, (size_t)vec0 * 16, h->stream));
-    {
-        std::vector<double> one(1, 1.0);
-        for (int w = 0; w < n; w++) {
-            const WinDesc& d = h->desc[w];
-            for (int i = d.np; i < d.nS; i++)
-                HIPCHK(h, hipMemcpyAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)i * d.nS + i, one.data(), 8, hipMemcpyHostToDevice, h->stream));
-        }
-    }
     Batch& B = h->B;
     B.desc = dp<WinDesc>(h, BUF_DESC); B.ctrl = dp<WinCtrl>(h, BUF_CTRL); B.n_win = n;
     B.pose = dp<double>(h, BUF_POSE); B.vel = dp<double>(h, BUF_VEL); B.bias = dp<double>(h, BUF_BIAS); B.kfR = dp<double>(h, BUF_KFR);
@@ -695,6 +687,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.out_outlier = dp<unsigned char>(h, BUF_OUTL); B.out_chi2 = dp<double>(h, BUF_OUTCHI);
     if (dalloc(h, BUF_DBG, 4096)) return -1;
     B.dbg = dp<double>(h, BUF_DBG);
+    static_assert(VBA_NB <= 64, "k_init_pads covers the pads with one wave");
+    hipLaunchKernelGGL(k_init_pads, dim3(n), dim3(64), 0, h->stream, B);
     const double t_enq = now_ms();
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (timing) fprintf(stderr, "[vba] upload %d windows: total %.3f ms (structure %.3f, pack+enqueue %.3f, sync %.3f)\n", n,
