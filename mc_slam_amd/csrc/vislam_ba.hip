@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <atomic>
 #include <mutex>
@@ -381,8 +382,22 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     return 0;
 }
 
+// std::vector whose resize() leaves new elements uninitialised: the concatenated upload arrays are grown first and filled
+// by the packing threads afterwards, so every byte is touched once
 template <typename T>
-int h2d(Handle* h, int id, const std::vector<T>& v) {
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+    template <typename U, typename... A>
+    void construct(U* q, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(q)) U;
+        else ::new (static_cast<void*>(q)) U(std::forward<A>(a)...);
+    }
+};
+template <typename T> using hvec = std::vector<T, NoInitAlloc<T>>;
+
+template <typename V>
+int h2d(Handle* h, int id, const V& v) {
+    typedef typename V::value_type T;
     HIPCHK(h, h->buf[id].ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
     if (!v.empty()) HIPCHK(h, hipMemcpyAsync(h->buf[id].p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
     return 0;
@@ -420,10 +435,11 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->uploaded = false;
     h->n_win = n;
     h->desc.assign(n, WinDesc());
-    std::vector<double> pose, vel, bias, pt, uv, ow, meas, info;
-    std::vector<unsigned char> kffix;
-    std::vector<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
-    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, offpair, pairmask, tlkb, tlk, slotperm, ptperm;
+    hvec<double> pose, vel, bias, pt, uv, ow, meas, info;
+    hvec<unsigned char> kffix;
+    hvec<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
+    hvec<int> offpair, pairmask, slotperm, ptperm;
+    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, tlkb, tlk;
     h->step_grid.clear();
     h->pan_grid.clear();
     h->step_npair_max.clear();
@@ -436,8 +452,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->max_offp = 1;
     h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
     h->max_its[0] = h->max_its[1] = 0;
-    // the per-window structure (item lists, IMU lists, symbolic tile factorisation: 0.7 ms for a C3 window) is built by a
-    // pool of host threads, a chunk of windows at a time; the concatenation below stays in window order
+    // Per chunk of windows: (1) the per-window structure (item lists, IMU lists, symbolic tile factorisation: 0.7 ms for a C3
+    // window) on a pool of host threads, (2) descriptors and offsets in window order on this thread, (3) the concatenated
+    // arrays grown once, (4) the pool again copies every window's arrays to its offsets (2.2 MB per C3 window).
     static const int n_threads = std::max(1, std::min(getenv("VBA_UPLOAD_THREADS") ? atoi(getenv("VBA_UPLOAD_THREADS")) : 16,
                                                       (int)std::thread::hardware_concurrency()));
     const int chunk = 8 * n_threads;
@@ -456,165 +473,191 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         pair_a.reserve(spair); pair_b.reserve(spair); offpair.reserve(spair); pairmask.reserve(spair);
         item_begin.reserve(spair + n); pimu_begin.reserve(spair + n);
     }
+    const bool pristine = use_left_looking(n);
     std::vector<Structure> sts;
-    int chunk0 = 0;
-    for (int w = 0; w < n; w++) {
-        const vba_problem* P = probs[w];
-        if (!P) return fail(h, "null problem");
-        if (w == chunk0 + (int)sts.size() || sts.empty()) {   // next chunk
-            chunk0 = w;
-            const int cn = std::min(chunk, n - w);
-            sts.assign(cn, Structure());
-            for (int q = 0; q < cn; q++)
-                if (!probs[w + q]) return fail(h, "null problem");
-            std::atomic<int> next(0), bad(0);
-            const double ts0 = now_ms();
-            auto work = [&]() {
-                for (int q = next.fetch_add(1); q < cn; q = next.fetch_add(1)) {
-                    const vba_problem* Q = probs[w + q];
-                    if (Q->variant < 0 || Q->variant > 2 || Q->n_kf_free <= 0 || Q->n_kf_free > Q->n_kf || Q->n_pt <= 0 || Q->n_obs <= 0) continue;  // reported below
-                    if (build_structure(h, Q, sts[q])) bad.store(1);
+    auto run_pool = [&](int cn, const std::function<void(int)>& job) {
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (int q = next.fetch_add(1); q < cn; q = next.fetch_add(1)) job(q);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < std::min(n_threads, cn); t++) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+    };
+    for (int chunk0 = 0; chunk0 < n; chunk0 += chunk) {
+        const int cn = std::min(chunk, n - chunk0);
+        for (int q = 0; q < cn; q++)
+            if (!probs[chunk0 + q]) return fail(h, "null problem");
+        // (1)
+        sts.assign(cn, Structure());
+        std::atomic<int> bad(0);
+        const double ts0 = now_ms();
+        run_pool(cn, [&](int q) {
+            const vba_problem* Q = probs[chunk0 + q];
+            if (Q->variant < 0 || Q->variant > 2 || Q->n_kf_free <= 0 || Q->n_kf_free > Q->n_kf || Q->n_pt <= 0 || Q->n_obs <= 0) return;  // reported below
+            if (build_structure(h, Q, sts[q])) bad.store(1);
+        });
+        t_struct += now_ms() - ts0;
+        if (bad.load()) return -1;
+        if (chunk0 == 0) {   // items: extrapolate from the first chunk
+            size_t it = 0, tp = 0;
+            for (auto& x : sts) { it += x.items.size(); tp += x.tpairs.size() + x.klist.size(); }
+            items.reserve((size_t)(1.1 * it / cn * n) + 1024);
+            tlpair.reserve((size_t)(1.1 * tp / cn * n) + 1024); tlk.reserve((size_t)(1.1 * tp / cn * n) + 1024);
+        }
+        // (2)
+        for (int w = chunk0; w < chunk0 + cn; w++) {
+            const vba_problem* P = probs[w];
+            if (P->variant < 0 || P->variant > 2 || (P->algo != VBA_ALGO_GN && P->algo != VBA_ALGO_LM)) return fail(h, "bad variant / algo");
+            if (P->variant == VBA_VARIANT_PRV_IDP && P->algo != VBA_ALGO_GN)
+                return fail(h, "inverse-depth landmarks are solved with Gauss-Newton only (as the reference does, src/Optimizer.cpp:136)");
+            if (P->variant != VBA_VARIANT_PRV_IDP && P->algo != VBA_ALGO_LM)
+                return fail(h, "XYZ landmarks are solved with Levenberg-Marquardt only (as the reference does, src/Optimizer.cpp:1028,3928)");
+            if (P->n_kf_free <= 0 || P->n_kf_free > P->n_kf || P->n_pt < 0 || P->n_obs < 0) return fail(h, "bad sizes");
+            if (P->n_pt == 0 || P->n_obs == 0) return fail(h, "a window without landmarks or observations has nothing to optimise");
+            if (w > 0 && (P->variant != probs[0]->variant || P->algo != probs[0]->algo)) return fail(h, "mixed batch");
+            if (P->its_stage1 > 30 || P->its_stage2 > 30 || P->its_stage1 < 0 || P->its_stage2 < 0) return fail(h, "its out of range");
+            if (P->protocol != VBA_PROTO_LOCAL && P->protocol != VBA_PROTO_SINGLE) return fail(h, "unknown protocol");
+            WinDesc& d = h->desc[w];
+            d.variant = P->variant; d.algo = P->algo;
+            d.protocol = P->protocol; d.robust = P->robust;
+            d.win = w;
+            d.n_kf = P->n_kf; d.n_free = P->n_kf_free; d.n_pt = P->n_pt; d.n_obs = P->n_obs;
+            d.n_imu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
+            d.pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
+            d.np = d.pdim * d.n_free;
+            d.nS = ((d.np + VBA_NB - 1) / VBA_NB) * VBA_NB;
+            d.nb = d.nS / VBA_NB;
+            d.its[0] = P->its_stage1; d.its[1] = P->its_stage2;
+            d.kf0 = kf0; d.pt0 = pt0; d.obs0 = obs0; d.imu0 = imu0;
+            d.pair0 = pair0; d.n_pairs = d.n_free * (d.n_free + 1) / 2;
+            d.item0 = item0; d.pimu0 = pimu0; d.vec0 = vec0; d.part0 = part0;
+            d.n_part_lin = (d.n_pt + 63) / 64;
+            if (P->variant == VBA_VARIANT_PRV_IDP) {
+                // k_lin2 work split: runs of consecutive landmarks with <= 256 edges and <= 64 landmarks per workgroup
+                d.lb0 = (int)linblk.size();
+                int nb2 = 0, p = 0;
+                while (p < d.n_pt) {
+                    linblk.push_back(p);
+                    nb2++;
+                    int ne = 0, np2 = 0;
+                    while (p < d.n_pt && np2 < 64) {
+                        const int k = P->pt_obs_begin[p + 1] - P->pt_obs_begin[p];
+                        if (k > 256) return fail(h, "a landmark with more than 256 observations is not supported");
+                        if (ne + k > 256) break;
+                        ne += k; np2++; p++;
+                    }
                 }
-            };
-            std::vector<std::thread> pool;
-            for (int t = 1; t < std::min(n_threads, cn); t++) pool.emplace_back(work);
-            work();
-            for (auto& t : pool) t.join();
-            t_struct += now_ms() - ts0;
-            if (bad.load()) return -1;
-            if (w == 0 && cn > 0) {   // items: extrapolate from the first chunk
-                size_t it = 0, tp = 0;
-                for (auto& x : sts) { it += x.items.size(); tp += x.tpairs.size() + x.klist.size(); }
-                items.reserve((size_t)(1.1 * it / cn * n) + 1024);
-                tlpair.reserve((size_t)(1.1 * tp / cn * n) + 1024); tlk.reserve((size_t)(1.1 * tp / cn * n) + 1024);
+                linblk.push_back(d.n_pt);
+                d.n_part_lin = nb2;
             }
-        }
-        if (P->variant < 0 || P->variant > 2 || (P->algo != VBA_ALGO_GN && P->algo != VBA_ALGO_LM)) return fail(h, "bad variant / algo");
-        if (P->variant == VBA_VARIANT_PRV_IDP && P->algo != VBA_ALGO_GN)
-            return fail(h, "inverse-depth landmarks are solved with Gauss-Newton only (as the reference does, src/Optimizer.cpp:136)");
-        if (P->variant != VBA_VARIANT_PRV_IDP && P->algo != VBA_ALGO_LM)
-            return fail(h, "XYZ landmarks are solved with Levenberg-Marquardt only (as the reference does, src/Optimizer.cpp:1028,3928)");
-        if (P->n_kf_free <= 0 || P->n_kf_free > P->n_kf || P->n_pt < 0 || P->n_obs < 0) return fail(h, "bad sizes");
-        if (P->n_pt == 0 || P->n_obs == 0) return fail(h, "a window without landmarks or observations has nothing to optimise");
-        if (w > 0 && (P->variant != probs[0]->variant || P->algo != probs[0]->algo)) return fail(h, "mixed batch");
-        if (P->its_stage1 > 30 || P->its_stage2 > 30 || P->its_stage1 < 0 || P->its_stage2 < 0) return fail(h, "its out of range");
-        if (P->protocol != VBA_PROTO_LOCAL && P->protocol != VBA_PROTO_SINGLE) return fail(h, "unknown protocol");
-        WinDesc& d = h->desc[w];
-        d.variant = P->variant; d.algo = P->algo;
-        d.protocol = P->protocol; d.robust = P->robust;
-        d.win = w;
-        d.n_kf = P->n_kf; d.n_free = P->n_kf_free; d.n_pt = P->n_pt; d.n_obs = P->n_obs;
-        d.n_imu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
-        d.pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
-        d.np = d.pdim * d.n_free;
-        d.nS = ((d.np + VBA_NB - 1) / VBA_NB) * VBA_NB;
-        d.nb = d.nS / VBA_NB;
-        d.its[0] = P->its_stage1; d.its[1] = P->its_stage2;
-        d.kf0 = kf0; d.pt0 = pt0; d.obs0 = obs0; d.imu0 = imu0;
-        d.pair0 = pair0; d.n_pairs = d.n_free * (d.n_free + 1) / 2;
-        d.item0 = item0; d.pimu0 = pimu0; d.vec0 = vec0; d.part0 = part0;
-        d.n_part_lin = (d.n_pt + 63) / 64;
-        if (P->variant == VBA_VARIANT_PRV_IDP) {
-            // k_lin2 work split: runs of consecutive landmarks with <= 256 edges and <= 64 landmarks per workgroup
-            d.lb0 = (int)linblk.size();
-            int nb2 = 0, p = 0;
-            while (p < d.n_pt) {
-                linblk.push_back(p);
-                nb2++;
-                int ne = 0, np2 = 0;
-                while (p < d.n_pt && np2 < 64) {
-                    const int k = P->pt_obs_begin[p + 1] - P->pt_obs_begin[p];
-                    if (k > 256) return fail(h, "a landmark with more than 256 observations is not supported");
-                    if (ne + k > 256) break;
-                    ne += k; np2++; p++;
-                }
+            d.S0 = (long long)S_tot;
+            for (int i = 0; i < 4; i++) d.K[i] = P->K[i];
+            quat_to_R_host(P->T_cb + 3, d.Rcb);
+            for (int i = 0; i < 3; i++) { d.tcb[i] = P->T_cb[i]; d.g[i] = P->g_w[i]; }
+            d.inv_bg = P->inv_bg_rw2; d.inv_ba = P->inv_ba_rw2;
+            d.hub_vis = P->huber_vis; d.hub_prv = P->huber_prv; d.hub_bias = P->huber_bias;
+            d.chi2_th = P->chi2_th; d.depth_min = P->depth_min; d.rho_min = P->rho_min;
+            Structure& st = sts[w - chunk0];
+            d.tl_step0 = (int)tlstep.size(); d.tl_pair0 = (int)tlpair.size(); d.tl_pan0 = (int)tlpan.size();
+            tlstep.insert(tlstep.end(), st.step_begin.begin(), st.step_begin.end());
+            tlpanb.insert(tlpanb.end(), st.pan_begin.begin(), st.pan_begin.end());
+            tlpair.insert(tlpair.end(), st.tpairs.begin(), st.tpairs.end());
+            tlpan.insert(tlpan.end(), st.pan.begin(), st.pan.end());
+            d.order = st.order;
+            if (d.pdim != 15) { d.vp_pr0 = 0; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 0; }
+            else if (d.order) { d.vp_pr0 = 0; d.vp_prs = 15; d.vp_vb0 = 6; d.vp_vbs = 15; }
+            else { d.vp_pr0 = 9 * d.n_free; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 9; }
+            d.tl_kb0 = (int)tlkb.size(); d.tl_k0 = (int)tlk.size();
+            tlkb.insert(tlkb.end(), st.kl_begin.begin(), st.kl_begin.end());
+            tlk.insert(tlk.end(), st.klist.begin(), st.klist.end());
+            if ((int)h->step_grid.size() < d.nb) { h->step_grid.resize(d.nb, 1); h->pan_grid.resize(d.nb, 0); h->step_npair_max.resize(d.nb, 0); }
+            for (int k = 0; k < d.nb; k++) {
+                h->step_grid[k] = std::max(h->step_grid[k], std::max(1, st.step_npairs[k]));
+                h->pan_grid[k] = std::max(h->pan_grid[k], st.pan_begin[k + 1] - st.pan_begin[k]);
+                h->step_npair_max[k] = std::max(h->step_npair_max[k], st.step_npairs[k]);
             }
-            linblk.push_back(d.n_pt);
-            d.n_part_lin = nb2;
+            h->tile_updates += (double)st.tpairs.size();
+            if ((int)st.pair_a.size() != d.n_pairs || (int)st.off_pair.size() != d.n_pairs || (int)st.pair_mask.size() != d.n_pairs ||
+                (int)st.item_begin.size() != d.n_pairs + 1 || (int)st.pimu_begin.size() != d.n_pairs + 1 ||
+                (int)st.obs_pt.size() != d.n_obs || (int)st.slot_perm.size() != d.n_obs || (int)st.pt_perm.size() != d.n_pt)
+                return fail(h, "internal: structure sizes");
+            kf0 += d.n_kf; pt0 += d.n_pt; obs0 += d.n_obs; imu0 += d.n_imu;
+            pair0 += d.n_pairs; item0 += (int)(st.items.size() / 2); pimu0 += (int)(st.pimu.size() / 2);
+            vec0 += d.nS;
+            const int obs_blk = (d.n_obs + 63) / 64;
+            part0 += std::max(3 * std::max(d.n_part_lin, (d.n_pt + 63) / 64), 2 * obs_blk) + 2;
+            S_tot += (size_t)d.nS * d.nS;
+            h->max_pt_blk = std::max(h->max_pt_blk, (d.n_pt + 63) / 64);
+            h->max_lin_blk = std::max(h->max_lin_blk, d.n_part_lin);
+            h->max_imu = std::max(h->max_imu, d.n_imu);
+            h->max_pairs = std::max(h->max_pairs, d.n_pairs);
+            h->max_free = std::max(h->max_free, d.n_free);
+            h->max_quads = std::max(h->max_quads, (d.n_pairs - d.n_free + 3) / 4);
+            h->max_offp = std::max(h->max_offp, d.n_pairs - d.n_free);
+            h->max_nb = std::max(h->max_nb, d.nb);
+            h->max_obs_blk = std::max(h->max_obs_blk, obs_blk);
+            h->max_kf_blk = std::max(h->max_kf_blk, (d.n_kf + 63) / 64);
+            h->max_ns_blk = std::max(h->max_ns_blk, (d.nS + 63) / 64);
+            h->max_nS = std::max(h->max_nS, d.nS);
+            h->max_its[0] = std::max(h->max_its[0], d.its[0]);
+            h->max_its[1] = std::max(h->max_its[1], d.its[1]);
         }
-        d.S0 = (long long)S_tot;
-        for (int i = 0; i < 4; i++) d.K[i] = P->K[i];
-        quat_to_R_host(P->T_cb + 3, d.Rcb);
-        for (int i = 0; i < 3; i++) { d.tcb[i] = P->T_cb[i]; d.g[i] = P->g_w[i]; }
-        d.inv_bg = P->inv_bg_rw2; d.inv_ba = P->inv_ba_rw2;
-        d.hub_vis = P->huber_vis; d.hub_prv = P->huber_prv; d.hub_bias = P->huber_bias;
-        d.chi2_th = P->chi2_th; d.depth_min = P->depth_min; d.rho_min = P->rho_min;
-        Structure& st = sts[w - chunk0];
-        d.tl_step0 = (int)tlstep.size(); d.tl_pair0 = (int)tlpair.size(); d.tl_pan0 = (int)tlpan.size();
-        tlstep.insert(tlstep.end(), st.step_begin.begin(), st.step_begin.end());
-        tlpanb.insert(tlpanb.end(), st.pan_begin.begin(), st.pan_begin.end());
-        tlpair.insert(tlpair.end(), st.tpairs.begin(), st.tpairs.end());
-        tlpan.insert(tlpan.end(), st.pan.begin(), st.pan.end());
-        d.order = st.order;
-        if (d.pdim != 15) { d.vp_pr0 = 0; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 0; }
-        else if (d.order) { d.vp_pr0 = 0; d.vp_prs = 15; d.vp_vb0 = 6; d.vp_vbs = 15; }
-        else { d.vp_pr0 = 9 * d.n_free; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 9; }
-        d.tl_kb0 = (int)tlkb.size(); d.tl_k0 = (int)tlk.size();
-        tlkb.insert(tlkb.end(), st.kl_begin.begin(), st.kl_begin.end());
-        tlk.insert(tlk.end(), st.klist.begin(), st.klist.end());
-        if ((int)h->step_grid.size() < d.nb) { h->step_grid.resize(d.nb, 1); h->pan_grid.resize(d.nb, 0); h->step_npair_max.resize(d.nb, 0); }
-        for (int k = 0; k < d.nb; k++) {
-            h->step_grid[k] = std::max(h->step_grid[k], std::max(1, st.step_npairs[k]));
-            h->pan_grid[k] = std::max(h->pan_grid[k], st.pan_begin[k + 1] - st.pan_begin[k]);
-            h->step_npair_max[k] = std::max(h->step_npair_max[k], st.step_npairs[k]);
-        }
-        h->tile_updates += (double)st.tpairs.size();
-        pose.insert(pose.end(), P->kf_pose, P->kf_pose + 7 * (size_t)d.n_kf);
-        for (int k = 0; k < d.n_kf; k++) kffix.push_back(P->kf_fix ? (unsigned char)(P->kf_fix[k] & 7) : 0);
-        if (P->kf_vel) vel.insert(vel.end(), P->kf_vel, P->kf_vel + 3 * (size_t)d.n_kf);
-        else vel.insert(vel.end(), 3 * (size_t)d.n_kf, 0.0);
-        if (P->kf_bias) bias.insert(bias.end(), P->kf_bias, P->kf_bias + 12 * (size_t)d.n_kf);
-        else bias.insert(bias.end(), 12 * (size_t)d.n_kf, 0.0);
-        pt.insert(pt.end(), P->pt, P->pt + 3 * (size_t)d.n_pt);
-        if (P->pt_ref_kf) ptref.insert(ptref.end(), P->pt_ref_kf, P->pt_ref_kf + d.n_pt);
-        else ptref.insert(ptref.end(), d.n_pt, 0);
-        ptobs.insert(ptobs.end(), P->pt_obs_begin, P->pt_obs_begin + d.n_pt + 1);
-        obskf.insert(obskf.end(), P->obs_kf, P->obs_kf + d.n_obs);
-        obspt.insert(obspt.end(), st.obs_pt.begin(), st.obs_pt.end());
-        slotperm.insert(slotperm.end(), st.slot_perm.begin(), st.slot_perm.end());
-        ptperm.insert(ptperm.end(), st.pt_perm.begin(), st.pt_perm.end());
-        uv.insert(uv.end(), P->obs_uv, P->obs_uv + 2 * (size_t)d.n_obs);
-        ow.insert(ow.end(), P->obs_w, P->obs_w + d.n_obs);
-        if (d.n_imu) {
-            imui.insert(imui.end(), P->imu_kf_i, P->imu_kf_i + d.n_imu);
-            imuj.insert(imuj.end(), P->imu_kf_j, P->imu_kf_j + d.n_imu);
-            meas.insert(meas.end(), P->imu_meas, P->imu_meas + 61 * (size_t)d.n_imu);
-            info.insert(info.end(), P->imu_info_prv, P->imu_info_prv + 81 * (size_t)d.n_imu);
-        }
-        pair_a.insert(pair_a.end(), st.pair_a.begin(), st.pair_a.end());
-        pair_b.insert(pair_b.end(), st.pair_b.begin(), st.pair_b.end());
-        offpair.insert(offpair.end(), st.off_pair.begin(), st.off_pair.end());
-        if (use_left_looking(n))   // S stays pristine: a sub-block nothing is ever added to keeps the zero of the upload
-            for (int pi = 0; pi < d.n_pairs; pi++)
-                if (st.pair_a[pi] != st.pair_b[pi] && st.pimu_begin[pi + 1] == st.pimu_begin[pi]) st.pair_mask[pi] &= 1;
-        pairmask.insert(pairmask.end(), st.pair_mask.begin(), st.pair_mask.end());
-        item_begin.insert(item_begin.end(), st.item_begin.begin(), st.item_begin.end());
-        items.insert(items.end(), st.items.begin(), st.items.end());
-        pimu_begin.insert(pimu_begin.end(), st.pimu_begin.begin(), st.pimu_begin.end());
-        pimu.insert(pimu.end(), st.pimu.begin(), st.pimu.end());
-        kf0 += d.n_kf; pt0 += d.n_pt; obs0 += d.n_obs; imu0 += d.n_imu;
-        pair0 += d.n_pairs; item0 += (int)(st.items.size() / 2); pimu0 += (int)(st.pimu.size() / 2);
-        vec0 += d.nS;
-        const int obs_blk = (d.n_obs + 63) / 64;
-        part0 += std::max(3 * std::max(d.n_part_lin, (d.n_pt + 63) / 64), 2 * obs_blk) + 2;
-        S_tot += (size_t)d.nS * d.nS;
-        h->max_pt_blk = std::max(h->max_pt_blk, (d.n_pt + 63) / 64);
-        h->max_lin_blk = std::max(h->max_lin_blk, d.n_part_lin);
-        h->max_imu = std::max(h->max_imu, d.n_imu);
-        h->max_pairs = std::max(h->max_pairs, d.n_pairs);
-        h->max_free = std::max(h->max_free, d.n_free);
-        h->max_quads = std::max(h->max_quads, (d.n_pairs - d.n_free + 3) / 4);
-        h->max_offp = std::max(h->max_offp, d.n_pairs - d.n_free);
-        h->max_nb = std::max(h->max_nb, d.nb);
-        h->max_obs_blk = std::max(h->max_obs_blk, obs_blk);
-        h->max_kf_blk = std::max(h->max_kf_blk, (d.n_kf + 63) / 64);
-        h->max_ns_blk = std::max(h->max_ns_blk, (d.nS + 63) / 64);
-        h->max_nS = std::max(h->max_nS, d.nS);
-        h->max_its[0] = std::max(h->max_its[0], d.its[0]);
-        h->max_its[1] = std::max(h->max_its[1], d.its[1]);
+        // (3)
+        const int nw = chunk0 + cn;   // windows packed so far
+        pose.resize(7 * (size_t)kf0); vel.resize(3 * (size_t)kf0); bias.resize(12 * (size_t)kf0); kffix.resize(kf0);
+        pt.resize(3 * (size_t)pt0); ptref.resize(pt0); ptperm.resize(pt0); ptobs.resize((size_t)pt0 + nw);
+        obskf.resize(obs0); obspt.resize(obs0); slotperm.resize(obs0); uv.resize(2 * (size_t)obs0); ow.resize(obs0);
+        imui.resize(imu0); imuj.resize(imu0); meas.resize(61 * (size_t)imu0); info.resize(81 * (size_t)imu0);
+        pair_a.resize(pair0); pair_b.resize(pair0); offpair.resize(pair0); pairmask.resize(pair0);
+        item_begin.resize((size_t)pair0 + nw); pimu_begin.resize((size_t)pair0 + nw);
+        items.resize(2 * (size_t)item0); pimu.resize(2 * (size_t)pimu0);
+        // (4)
+        run_pool(cn, [&](int q) {
+            const int w = chunk0 + q;
+            const vba_problem* P = probs[w];
+            const WinDesc& d = h->desc[w];
+            Structure& st = sts[q];
+            auto put = [](auto* dst, const auto* src, size_t cnt) { if (cnt) memcpy(dst, src, cnt * sizeof(*dst)); };
+            put(pose.data() + 7 * (size_t)d.kf0, P->kf_pose, 7 * (size_t)d.n_kf);
+            for (int k = 0; k < d.n_kf; k++) kffix[d.kf0 + k] = P->kf_fix ? (unsigned char)(P->kf_fix[k] & 7) : 0;
+            if (P->kf_vel) put(vel.data() + 3 * (size_t)d.kf0, P->kf_vel, 3 * (size_t)d.n_kf);
+            else std::fill_n(vel.data() + 3 * (size_t)d.kf0, 3 * (size_t)d.n_kf, 0.0);
+            if (P->kf_bias) put(bias.data() + 12 * (size_t)d.kf0, P->kf_bias, 12 * (size_t)d.n_kf);
+            else std::fill_n(bias.data() + 12 * (size_t)d.kf0, 12 * (size_t)d.n_kf, 0.0);
+            put(pt.data() + 3 * (size_t)d.pt0, P->pt, 3 * (size_t)d.n_pt);
+            if (P->pt_ref_kf) put(ptref.data() + d.pt0, P->pt_ref_kf, d.n_pt);
+            else std::fill_n(ptref.data() + d.pt0, d.n_pt, 0);
+            put(ptobs.data() + d.pt0 + w, P->pt_obs_begin, (size_t)d.n_pt + 1);
+            put(obskf.data() + d.obs0, P->obs_kf, d.n_obs);
+            put(obspt.data() + d.obs0, st.obs_pt.data(), d.n_obs);
+            put(slotperm.data() + d.obs0, st.slot_perm.data(), d.n_obs);
+            put(ptperm.data() + d.pt0, st.pt_perm.data(), d.n_pt);
+            put(uv.data() + 2 * (size_t)d.obs0, P->obs_uv, 2 * (size_t)d.n_obs);
+            put(ow.data() + d.obs0, P->obs_w, d.n_obs);
+            if (d.n_imu) {
+                put(imui.data() + d.imu0, P->imu_kf_i, d.n_imu);
+                put(imuj.data() + d.imu0, P->imu_kf_j, d.n_imu);
+                put(meas.data() + 61 * (size_t)d.imu0, P->imu_meas, 61 * (size_t)d.n_imu);
+                put(info.data() + 81 * (size_t)d.imu0, P->imu_info_prv, 81 * (size_t)d.n_imu);
+            }
+            put(pair_a.data() + d.pair0, st.pair_a.data(), d.n_pairs);
+            put(pair_b.data() + d.pair0, st.pair_b.data(), d.n_pairs);
+            put(offpair.data() + d.pair0, st.off_pair.data(), d.n_pairs);
+            if (pristine)   // S stays pristine: a sub-block nothing is ever added to keeps the zero of the upload
+                for (int pi = 0; pi < d.n_pairs; pi++)
+                    if (st.pair_a[pi] != st.pair_b[pi] && st.pimu_begin[pi + 1] == st.pimu_begin[pi]) st.pair_mask[pi] &= 1;
+            put(pairmask.data() + d.pair0, st.pair_mask.data(), d.n_pairs);
+            put(item_begin.data() + d.pair0 + w, st.item_begin.data(), (size_t)d.n_pairs + 1);
+            put(items.data() + 2 * (size_t)d.item0, st.items.data(), st.items.size());
+            put(pimu_begin.data() + d.pair0 + w, st.pimu_begin.data(), (size_t)d.n_pairs + 1);
+            put(pimu.data() + 2 * (size_t)d.pimu0, st.pimu.data(), st.pimu.size());
+        });
     }
     h->algo = probs[0]->algo;
     h->variant = probs[0]->variant;
+    const double t_pack = now_ms();
     // pads of S: identity on the padded diagonal, written once (the solve never touches them)
     if (h2d(h, BUF_DESC, h->desc)) return -1;
     if (dalloc(h, BUF_CTRL, sizeof(WinCtrl) * n)) return -1;
@@ -691,8 +734,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     hipLaunchKernelGGL(k_init_pads, dim3(n), dim3(64), 0, h->stream, B);
     const double t_enq = now_ms();
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (timing) fprintf(stderr, "[vba] upload %d windows: total %.3f ms (structure %.3f, pack+enqueue %.3f, sync %.3f)\n", n,
-                        now_ms() - t_begin, t_struct, t_enq - t_begin - t_struct, now_ms() - t_enq);
+    if (timing) fprintf(stderr, "[vba] upload %d windows: total %.3f ms (structure %.3f, pack %.3f, alloc+H2D enqueue %.3f, sync %.3f)\n", n,
+                        now_ms() - t_begin, t_struct, t_pack - t_begin - t_struct, t_enq - t_pack, now_ms() - t_enq);
     h->uploaded = true;
     h->ran = false;
     return 0;
