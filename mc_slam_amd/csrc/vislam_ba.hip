@@ -25,6 +25,19 @@
 
 namespace {
 
+// std::vector whose resize() leaves new elements uninitialised: the concatenated upload arrays are grown first and filled
+// by the packing threads afterwards, so every byte is touched once
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+    template <typename U, typename... A>
+    void construct(U* q, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(q)) U;
+        else ::new (static_cast<void*>(q)) U(std::forward<A>(a)...);
+    }
+};
+template <typename T> using hvec = std::vector<T, NoInitAlloc<T>>;
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -87,6 +100,8 @@ struct Handle {
     DevBuf preint;  // arena of vba_preintegrate
     DevBuf pose_arena;  // arena of vba_pose_optimize
     PinnedBuf pose_host_in, pose_host_out;  // its pinned staging: one H2D and one D2H per call
+    hvec<double> dl_pose, dl_vel, dl_bias, dl_pt, dl_chi2;  // host staging of vba_batch_download: one D2H per array, windows
+    hvec<unsigned char> dl_outl;                            // scattered to the callers' arrays by host threads
     Batch B;
     std::vector<WinDesc> desc;
     std::vector<WinCtrl> hctrl;
@@ -404,19 +419,6 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     st.off_pair.resize(npairs, 0);  // padded to the pair stride
     return 0;
 }
-
-// std::vector whose resize() leaves new elements uninitialised: the concatenated upload arrays are grown first and filled
-// by the packing threads afterwards, so every byte is touched once
-template <typename T>
-struct NoInitAlloc : std::allocator<T> {
-    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
-    template <typename U, typename... A>
-    void construct(U* q, A&&... a) {
-        if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(q)) U;
-        else ::new (static_cast<void*>(q)) U(std::forward<A>(a)...);
-    }
-};
-template <typename T> using hvec = std::vector<T, NoInitAlloc<T>>;
 
 template <typename V>
 int h2d(Handle* h, int id, const V& v) {
@@ -1040,32 +1042,80 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
     if (n != h->n_win) return fail(h, "window count mismatch");
     HIPCHK(h, hipSetDevice(h->device));
     const Batch& B = h->B;
-    for (int w = 0; w < n; w++) {
-        const WinDesc& d = h->desc[w];
-        const WinCtrl& c = h->hctrl[w];
-        vba_problem* P = inout ? inout[w] : nullptr;
-        vba_result* R = out ? out[w] : nullptr;
-        if (P && c.status != VBA_ABORTED_BEFORE) {
-            HIPCHK(h, hipMemcpy(P->kf_pose, B.pose + 7 * (size_t)d.kf0, 56 * (size_t)d.n_free, hipMemcpyDeviceToHost));
-            if (d.pdim == 15) {
-                if (P->kf_vel) HIPCHK(h, hipMemcpy(P->kf_vel, B.vel + 3 * (size_t)d.kf0, 24 * (size_t)d.n_free, hipMemcpyDeviceToHost));
-                if (P->kf_bias) HIPCHK(h, hipMemcpy(P->kf_bias, B.bias + 12 * (size_t)d.kf0, 96 * (size_t)d.n_free, hipMemcpyDeviceToHost));
-            }
-            if (d.n_pt) HIPCHK(h, hipMemcpy(P->pt, B.pt + 3 * (size_t)d.pt0, 24 * (size_t)d.n_pt, hipMemcpyDeviceToHost));
+    // Many windows: every result array crosses PCIe ONCE into host staging and host threads scatter it to the callers'
+    // arrays (per-window copies cost ~12 synchronous hipMemcpy calls per window, 0.25 ms).  Few windows: direct copies.
+    const bool staged = n >= 4;
+    if (staged) {
+        bool want_state = false, want_outl = false, want_chi2 = false;
+        for (int w = 0; w < n; w++) {
+            if (inout && inout[w] && h->hctrl[w].status != VBA_ABORTED_BEFORE) want_state = true;
+            if (out && out[w] && out[w]->obs_outlier) want_outl = true;
+            if (out && out[w] && out[w]->obs_chi2) want_chi2 = true;
         }
-        if (R) {
-            R->chi2_vis = c.chi2_vis; R->chi2_prv = c.chi2_prv; R->chi2_bias = c.chi2_bias;
-            R->its_done[0] = c.its_done[0]; R->its_done[1] = c.its_done[1];
-            R->n_outliers = c.n_outliers; R->status = c.status;
-            R->n_trace = c.n_trace;
-            for (int i = 0; i < c.n_trace && i < VBA_TRACE_MAX; i++) R->chi2_trace[i] = c.trace[i];
-            R->lambda_final = c.lambda;
-            if (c.status != VBA_ABORTED_BEFORE && d.n_obs) {
-                if (R->obs_outlier) HIPCHK(h, hipMemcpy(R->obs_outlier, B.out_outlier + d.obs0, (size_t)d.n_obs, hipMemcpyDeviceToHost));
-                if (R->obs_chi2) HIPCHK(h, hipMemcpy(R->obs_chi2, B.out_chi2 + d.obs0, 8 * (size_t)d.n_obs, hipMemcpyDeviceToHost));
+        const WinDesc& dl = h->desc[n - 1];
+        const size_t nkf = (size_t)dl.kf0 + dl.n_kf, npt = (size_t)dl.pt0 + dl.n_pt, nobs = (size_t)dl.obs0 + dl.n_obs;
+        if (want_state) {
+            h->dl_pose.resize(7 * nkf); h->dl_pt.resize(3 * npt);
+            HIPCHK(h, hipMemcpyAsync(h->dl_pose.data(), B.pose, 56 * nkf, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->dl_pt.data(), B.pt, 24 * npt, hipMemcpyDeviceToHost, h->stream));
+            if (h->variant != VBA_VARIANT_SE3_XYZ) {
+                h->dl_vel.resize(3 * nkf); h->dl_bias.resize(12 * nkf);
+                HIPCHK(h, hipMemcpyAsync(h->dl_vel.data(), B.vel, 24 * nkf, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipMemcpyAsync(h->dl_bias.data(), B.bias, 96 * nkf, hipMemcpyDeviceToHost, h->stream));
             }
         }
+        if (want_outl) {
+            h->dl_outl.resize(nobs);
+            HIPCHK(h, hipMemcpyAsync(h->dl_outl.data(), B.out_outlier, nobs, hipMemcpyDeviceToHost, h->stream));
+        }
+        if (want_chi2) {
+            h->dl_chi2.resize(nobs);
+            HIPCHK(h, hipMemcpyAsync(h->dl_chi2.data(), B.out_chi2, 8 * nobs, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
+    std::atomic<int> next(0), bad(0);
+    auto work = [&]() {
+        for (int w = next.fetch_add(1); w < n; w = next.fetch_add(1)) {
+            const WinDesc& d = h->desc[w];
+            const WinCtrl& c = h->hctrl[w];
+            vba_problem* P = inout ? inout[w] : nullptr;
+            vba_result* R = out ? out[w] : nullptr;
+            auto get = [&](void* dst, const void* dev, const void* host, size_t bytes) {
+                if (!bytes) return;
+                if (staged) memcpy(dst, host, bytes);
+                else if (hipMemcpy(dst, dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) bad.store(1);
+            };
+            if (P && c.status != VBA_ABORTED_BEFORE) {
+                get(P->kf_pose, B.pose + 7 * (size_t)d.kf0, h->dl_pose.data() + 7 * (size_t)d.kf0, 56 * (size_t)d.n_free);
+                if (d.pdim == 15) {
+                    if (P->kf_vel) get(P->kf_vel, B.vel + 3 * (size_t)d.kf0, h->dl_vel.data() + 3 * (size_t)d.kf0, 24 * (size_t)d.n_free);
+                    if (P->kf_bias) get(P->kf_bias, B.bias + 12 * (size_t)d.kf0, h->dl_bias.data() + 12 * (size_t)d.kf0, 96 * (size_t)d.n_free);
+                }
+                get(P->pt, B.pt + 3 * (size_t)d.pt0, h->dl_pt.data() + 3 * (size_t)d.pt0, 24 * (size_t)d.n_pt);
+            }
+            if (R) {
+                R->chi2_vis = c.chi2_vis; R->chi2_prv = c.chi2_prv; R->chi2_bias = c.chi2_bias;
+                R->its_done[0] = c.its_done[0]; R->its_done[1] = c.its_done[1];
+                R->n_outliers = c.n_outliers; R->status = c.status;
+                R->n_trace = c.n_trace;
+                for (int i = 0; i < c.n_trace && i < VBA_TRACE_MAX; i++) R->chi2_trace[i] = c.trace[i];
+                R->lambda_final = c.lambda;
+                if (c.status != VBA_ABORTED_BEFORE && d.n_obs) {
+                    if (R->obs_outlier) get(R->obs_outlier, B.out_outlier + d.obs0, h->dl_outl.data() + d.obs0, (size_t)d.n_obs);
+                    if (R->obs_chi2) get(R->obs_chi2, B.out_chi2 + d.obs0, h->dl_chi2.data() + d.obs0, 8 * (size_t)d.n_obs);
+                }
+            }
+        }
+    };
+    {
+        const int nt = staged ? std::max(1, std::min(std::min(16, (int)std::thread::hardware_concurrency()), n / 8)) : 1;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+    }
+    if (bad.load()) return fail(h, "hipMemcpy (download) failed");
     return 0;
 }
 

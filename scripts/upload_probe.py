@@ -11,5 +11,9 @@ for B in sizes:
     for rep in range(3):
         t0 = time.time(); ba.upload(batch); tu = time.time() - t0
         print("B=%d upload #%d %.2f ms (%.3f ms per window)" % (B, rep, tu * 1e3, tu * 1e3 / B), flush=True)
+    ba.run()
+    for rep in range(2):
+        t0 = time.time(); ba.download(); td = time.time() - t0
+        print("B=%d download #%d %.2f ms (%.3f ms per window, python wrapper included)" % (B, rep, td * 1e3, td * 1e3 / B), flush=True)
 for rep in range(4):
     t0 = time.time(); ba.solve(wins[rep]); print("vba_solve one window: %.2f ms" % ((time.time() - t0) * 1e3), flush=True)
