@@ -206,10 +206,12 @@ def main():
                 roofline["traffic_source"] = os.path.basename(tj)
         except Exception:
             pass
-        if dom == "factor":
-            flops = solves * (n_p ** 3) / 3.0
-            roofline["fp64_tflops"] = flops / dur_s / 1e12
-            roofline["fp64_peak_tflops"] = 78.6
+        # the dense solve (north_star: "MFMA utilisation reported against gfx950 peak"): FP64 flop the factorisation class
+        # executed with v_mfma_f64_16x16x4 (tile products of the symbolic lists x 2*32^3) over its HIP-event time, against
+        # the 78.6 TFLOP/s FP64 matrix peak of the MI355X
+        if classes["factor"]["ms"] > 0:
+            tf = classes["factor"]["flops"] / (classes["factor"]["ms"] * 1e-3) / 1e12
+            roofline["mfma_factor"] = {"achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "dtype": "f64"}
 
         cpu = None
         if not args.no_cpu_baseline:

@@ -115,6 +115,8 @@ typedef struct vba_profile {
     int64_t launches[VBA_PROF_N];
     double bytes[VBA_PROF_N];    /* algorithmic bytes moved per class (SURVEY 8d accounting) */
     double total_ms;             /* first launch -> last launch of the run */
+    double factor_flops;         /* FP64 flop the factorisation class executed on MFMA: 2*32^3 per tile product of the
+                                    symbolic tile lists, per solve (structurally zero tiles are never touched) */
 } vba_profile;
 
 /* One handle per host thread / GPU; owns device buffers and a stream.  Errors: nonzero return, message

@@ -160,5 +160,7 @@ class LocalBA:
     def get_profile(self):
         pf = abi.vba_profile()
         self.lib.vba_get_profile(self.h, C.byref(pf))
-        return {abi.PROF_NAMES[i]: dict(ms=pf.ms[i], launches=pf.launches[i], bytes=pf.bytes[i]) for i in range(7)} | \
-            {"total_ms": pf.total_ms}
+        d = {abi.PROF_NAMES[i]: dict(ms=pf.ms[i], launches=pf.launches[i], bytes=pf.bytes[i]) for i in range(7)}
+        d["factor"]["flops"] = pf.factor_flops
+        d["total_ms"] = pf.total_ms
+        return d

@@ -112,6 +112,7 @@ struct Handle {
     std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
     std::vector<int> pan_grid, step_npair_max;  // panel tiles / tile pairs per step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
+    std::vector<int> win_tiles;  // tile products of one factorisation of window w
     int algo = 0, variant = 2;
     volatile int* stop_host = nullptr;  // pinned, device-visible
     int* stop_dev = nullptr;
@@ -460,6 +461,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->uploaded = false;
     h->n_win = n;
     h->desc.assign(n, WinDesc());
+    h->win_tiles.assign(n, 0);
     hvec<double> pose, vel, bias, pt, uv, ow, meas, info;
     hvec<unsigned char> kffix;
     hvec<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
@@ -604,6 +606,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
                 h->step_npair_max[k] = std::max(h->step_npair_max[k], st.step_npairs[k]);
             }
             h->tile_updates += (double)st.tpairs.size();
+            h->win_tiles[w] = (int)st.tpairs.size();
             if ((int)st.pair_a.size() != d.n_pairs || (int)st.off_pair.size() != d.n_pairs || (int)st.pair_mask.size() != d.n_pairs ||
                 (int)st.item_begin.size() != d.n_pairs + 1 || (int)st.pimu_begin.size() != d.n_pairs + 1 ||
                 (int)st.obs_pt.size() != d.n_obs || (int)st.slot_perm.size() != d.n_obs || (int)st.pt_perm.size() != d.n_pt)
@@ -1031,6 +1034,7 @@ int do_run(Handle* h, const volatile int* stop_flag) {
             pf.bytes[VBA_PROF_LINEARIZE] += passes * (32.0 * d.n_obs + 36.0 * d.n_pt + 432.0 * d.n_free);
             pf.bytes[VBA_PROF_SCHUR] += solves * ((double)d.np * d.np * 8.0);
             pf.bytes[VBA_PROF_FACTOR] += solves * ((double)d.np * d.np * 8.0);
+            pf.factor_flops += solves * h->win_tiles[w] * (2.0 * VBA_NB * VBA_NB * VBA_NB);
         }
     }
     h->ran = true;
