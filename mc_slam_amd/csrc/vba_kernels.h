@@ -1476,7 +1476,7 @@ DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, do
             for (int q = 0; q < rr; q++) sacc -= Lk[rr * 33 + q] * z[q];
             z[rr] = (rr >= r) ? sacc : 0.0;
         }
-        double* W = B.winv + 1024 * (size_t)w;
+        double* W = B.winv + 1024 * (size_t)d.win;  // d.win: the batch-wide window index (w is relative to the window group)
 #pragma unroll
         for (int j = 0; j < 32; j++) W[j * 32 + r] = z[j] * rd[j];
     }
@@ -1528,7 +1528,7 @@ __global__ void __launch_bounds__(64) k_chol_panel_ll(Batch B, int J) {
             for (int i = 0; i < 4; i++) CT[(16 * ti + l4 + 4 * i) * 34 + 16 * tj + l15] = acc[ti][tj][i];
     {
         const int row = lane >> 1, c0 = (lane & 1) * 16;
-        const double* sw = B.winv + 1024 * (size_t)w + row * 32 + c0;
+        const double* sw = B.winv + 1024 * (size_t)d.win + row * 32 + c0;
 #pragma unroll
         for (int q = 0; q < 16; q++) WT[row * 34 + c0 + q] = sw[q];
     }

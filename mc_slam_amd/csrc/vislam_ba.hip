@@ -124,6 +124,7 @@ struct Handle {
     vba_profile prof;
     bool uploaded = false;
     bool ran = false;
+    bool ll_mode = false;  // left-looking factorisation kernels (batch size at upload >= VBA_LL_MIN)
 };
 
 #define HIPCHK(h, call)                                                                          \
@@ -501,6 +502,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         item_begin.reserve(spair + n); pimu_begin.reserve(spair + n);
     }
     const bool pristine = use_left_looking(n);
+    h->ll_mode = pristine;
     std::vector<Structure> sts;
     auto run_pool = [&](int cn, const std::function<void(int)>& job) {
         std::atomic<int> next(0);
@@ -801,8 +803,8 @@ void enqueue_solve_iteration(Handle* h) {
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
         static const int split_min = getenv("VBA_SPLIT_MIN") ? atoi(getenv("VBA_SPLIT_MIN")) : 64;
-        if (n >= split_min) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
-            const bool ll = use_left_looking(n);
+        const bool ll = h->ll_mode;  // decided for the whole batch at upload (S stays pristine, pair masks), also for its window groups
+        if (n >= split_min || ll) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
             for (int k = 0; k < h->max_nb && ll; k++) {  // every tile read once, updated in registers, written once
                 hipLaunchKernelGGL(k_chol_diag_ll, dim3(n), dim3(64), 0, h->stream, B, k);
                 if (h->pan_grid[k] > 0) hipLaunchKernelGGL(k_chol_panel_ll, dim3(h->pan_grid[k], n), dim3(64), 0, h->stream, B, k);
@@ -882,69 +884,100 @@ int enqueue_lm_stage(Handle* h, int stage, const volatile int* stop_flag) {
     return 0;
 }
 
-// the whole two-stage schedule of the windows currently selected in h->B / h->n_win, on h->stream
-int enqueue_schedule(Handle* h, const volatile int* stop_flag) {
-    const Batch& B = h->B;
-    const int n = h->n_win;
+// One group of windows of a batch with its own stream (the whole batch is the only group unless VBA_STREAMS > 1)
+struct Group {
+    Batch B;
+    int n_win;
+    hipStream_t stream;
+    volatile int* alive;  // pinned words of this group: [stage * 32 + it]
+    bool dead;
+};
+
+// The two-stage schedule of a batch cut into window groups.  The groups are independent; their launches are enqueued
+// INTERLEAVED, iteration by iteration, each on its own stream, so that while one group sits in the latency-bound block
+// columns of its factorisation another one streams through its bandwidth-bound linearise / Schur kernels.
+int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* stop_flag) {
     const int big_blk = std::max(std::max(h->max_kf_blk, h->max_pt_blk), h->max_obs_blk);
-    {
+    const Batch B_all = h->B;
+    const int n_all = h->n_win;
+    hipStream_t main_stream = h->stream;
+    auto use = [&](const Group& g) { h->B = g.B; h->n_win = g.n_win; h->stream = g.stream; };
+    auto restore = [&]() { h->B = B_all; h->n_win = n_all; h->stream = main_stream; };
+    int rc = 0;
+    for (auto& g : groups) {
+        use(g);
         ProfScope ps(h, VBA_PROF_MISC);
-        hipLaunchKernelGGL(k_reset, dim3(big_blk, n), dim3(64), 0, h->stream, B);
+        hipLaunchKernelGGL(k_reset, dim3(big_blk, g.n_win), dim3(64), 0, g.stream, g.B);
     }
-    for (int stage = 0; stage < 2; stage++) {
-        {
+    for (int stage = 0; stage < 2 && rc == 0; stage++) {
+        for (auto& g : groups) {
+            use(g);
             ProfScope ps(h, VBA_PROF_MISC);
-            hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, n), dim3(64), 0, h->stream, B, stage);
-            if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, n), dim3(64), 0, h->stream, B);
-            hipLaunchKernelGGL(k_stage_mark, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
+            hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
+            if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+            hipLaunchKernelGGL(k_stage_mark, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
         }
         if (h->algo == VBA_ALGO_LM) {
-            if (enqueue_lm_stage(h, stage, stop_flag)) return -1;
+            use(groups[0]);  // LM needs a host decision per trial: one group, one stream
+            if (enqueue_lm_stage(h, stage, stop_flag)) rc = -1;
         } else {
-            // The host stays at most two iterations ahead of the device: before enqueuing iteration it it waits for
-            // the control kernel of iteration it-2 and stops enqueuing once no window is iterating any more (the
-            // |dchi2| < 1e-3 stop usually ends stage 2 after 3 of its 10 iterations).  The device never starves:
-            // one full iteration is always queued behind the one being waited for.
-            volatile int* alive = h->stop_host + 64 + stage * 32;
-            std::vector<hipEvent_t> ev(h->max_its[stage], nullptr);
-            const bool pace = !h->profile && h->max_its[stage] <= 32;
-            for (int it = 0; it < h->max_its[stage]; it++) {
-                if (pace && it >= 2) {
-                    (void)hipEventSynchronize(ev[it - 2]);
-                    if (alive[it - 2] == 0) break;
+            // The host stays at most two iterations ahead of the device: before enqueuing iteration it of a group it waits
+            // for that group's control kernel of iteration it-2 and stops enqueuing for the group once none of its windows is
+            // iterating any more (the |dchi2| < 1e-3 stop usually ends stage 2 after 3 of its 10 iterations).  The device
+            // never starves: one full iteration is always queued behind the one being waited for.
+            const int nit = h->max_its[stage];
+            std::vector<std::vector<hipEvent_t>> ev(groups.size(), std::vector<hipEvent_t>(nit, nullptr));
+            const bool pace = !h->profile && nit <= 32;
+            for (auto& g : groups) g.dead = false;
+            for (int it = 0; it < nit; it++) {
+                bool any = false;
+                for (size_t gi = 0; gi < groups.size(); gi++) {
+                    Group& g = groups[gi];
+                    if (g.dead) continue;
+                    if (pace && it >= 2) {
+                        (void)hipEventSynchronize(ev[gi][it - 2]);
+                        if (g.alive[stage * 32 + it - 2] == 0) { g.dead = true; continue; }
+                    }
+                    any = true;
+                    use(g);
+                    enqueue_lin(h, LIN_FULL);
+                    {
+                        ProfScope ps(h, VBA_PROF_CONTROL);
+                        hipLaunchKernelGGL(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 0);
+                    }
+                    if (pace) {
+                        ev[gi][it] = get_evt(h);
+                        (void)hipEventRecord(ev[gi][it], g.stream);
+                    }
+                    enqueue_solve_iteration(h);
                 }
-                enqueue_lin(h, LIN_FULL);
-                {
-                    ProfScope ps(h, VBA_PROF_CONTROL);
-                    hipLaunchKernelGGL(k_ctrl_gn, dim3(n), dim3(64), 0, h->stream, B, 0);
-                }
-                if (pace) {
-                    ev[it] = get_evt(h);
-                    (void)hipEventRecord(ev[it], h->stream);
-                }
-                enqueue_solve_iteration(h);
+                if (!any) break;
             }
-            enqueue_lin(h, LIN_ERR);
-            {
+            for (auto& g : groups) {
+                use(g);
+                enqueue_lin(h, LIN_ERR);
                 ProfScope ps(h, VBA_PROF_CONTROL);
-                hipLaunchKernelGGL(k_ctrl_gn, dim3(n), dim3(64), 0, h->stream, B, 1);
+                hipLaunchKernelGGL(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 1);
             }
         }
-        if (h->variant != VBA_VARIANT_PRV_IDP) {
-            ProfScope ps(h, VBA_PROF_MISC);
-            hipLaunchKernelGGL(k_depth_xyz, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
-        }
+        if (h->variant != VBA_VARIANT_PRV_IDP)
+            for (auto& g : groups) {
+                use(g);
+                ProfScope ps(h, VBA_PROF_MISC);
+                hipLaunchKernelGGL(k_depth_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+            }
     }
-    if (h->variant != VBA_VARIANT_PRV_IDP) {
+    for (auto& g : groups) {
+        if (rc) break;
+        use(g);
         ProfScope ps(h, VBA_PROF_MISC);
-        hipLaunchKernelGGL(k_chi2_fresh_xyz, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
+        if (h->variant != VBA_VARIANT_PRV_IDP)
+            hipLaunchKernelGGL(k_chi2_fresh_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        hipLaunchKernelGGL(k_final_edges, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        hipLaunchKernelGGL(k_final_sum, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
     }
-    {
-        ProfScope ps(h, VBA_PROF_MISC);
-        hipLaunchKernelGGL(k_final_edges, dim3(std::max(h->max_obs_blk, 1), n), dim3(64), 0, h->stream, B);
-        hipLaunchKernelGGL(k_final_sum, dim3(n), dim3(64), 0, h->stream, B);
-    }
-    return 0;
+    restore();
+    return rc;
 }
 
 int do_run(Handle* h, const volatile int* stop_flag) {
@@ -953,7 +986,7 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     const Batch B = h->B;
     const int n = h->n_win;
     *h->stop_host = (stop_flag && *stop_flag) ? 1 : 0;
-    for (int i = 64; i < 128; i++) h->stop_host[i] = 0;
+    for (int i = 64; i < 1024; i++) h->stop_host[i] = 0;
     h->evts.clear();
     h->evt_used = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -962,40 +995,47 @@ int do_run(Handle* h, const volatile int* stop_flag) {
         ev_end = get_evt(h);
         (void)hipEventRecord(ev_begin, h->stream);
     }
-    // Large Gauss-Newton batches are cut into groups of windows, each with its own stream: the groups are
-    // independent, so while one group sits in its latency-bound factorisation steps another streams through
-    // its bandwidth-bound linearise / Schur kernels, and a group's intermediates are still cache-resident when
-    // they are read back.  (Profiling runs and LM, which needs a host decision per trial, use one stream.)
-    // measured on MI355X (C3 windows): concurrent groups are SLOWER than one lock-step stream (256 windows: 55.7 ms
-    // with 8 groups vs 46.6 ms), so the default is one stream; VBA_STREAMS > 1 keeps the path testable
-    static const int env_streams = getenv("VBA_STREAMS") ? atoi(getenv("VBA_STREAMS")) : 1;
-    const int max_streams = h->opt_streams > 0 ? h->opt_streams : env_streams;
+    // Large Gauss-Newton batches can be cut into groups of windows, each with its own stream (enqueue_schedule).
+    // (Profiling runs and LM, which needs a host decision per trial, use one group.)
+    // Measured on MI355X, C3 windows, windows/s with 1 / 2 / 4 / 8 groups: 64 windows 5.1k / 5.6k / 5.8k / 4.1k; 256: 7.5k / 8.0k /
+    // 8.5k / 6.1k; 512: 8.9k / 9.2k / 9.9k / 8.6k; 1024: 9.7k / 10.1k / 10.2k / 10.0k; 2048: 10.2k / 10.4k / 10.3k / 10.1k.
+    static const int env_streams = getenv("VBA_STREAMS") ? atoi(getenv("VBA_STREAMS")) : 0;
+    int want = h->opt_streams > 0 ? h->opt_streams : env_streams;
+    if (want <= 0) want = (n >= 2048) ? 2 : (n >= 64) ? 4 : (n >= 16) ? 2 : 1;   // default policy (16..48 windows: 2 groups +5..10 %, 4 groups -40 %)
+    const int max_streams = std::min(14, want);
     int ngroups = 1;
     if (!h->profile && h->algo == VBA_ALGO_GN && max_streams > 1 && n >= 8)
-        ngroups = std::max(1, std::min(max_streams, (int)std::lround(std::sqrt(n / 4.0))));
+        ngroups = std::max(1, std::min(max_streams, n / 4));
     while ((int)h->xstreams.size() < ngroups - 1) {
         hipStream_t st;
         HIPCHK(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         h->xstreams.push_back(st);
     }
-    hipStream_t main_stream = h->stream;
+    std::vector<Group> groups(ngroups);
     std::vector<hipEvent_t> done(ngroups);
-    int rc = 0;
-    for (int g = 0; g < ngroups && rc == 0; g++) {
+    for (int g = 0; g < ngroups; g++) {
         const int w0 = (int)((long long)n * g / ngroups), w1 = (int)((long long)n * (g + 1) / ngroups);
-        h->B = B;
-        h->B.desc = B.desc + w0;
-        h->B.ctrl = B.ctrl + w0;
-        h->B.n_win = w1 - w0;
-        h->n_win = w1 - w0;
-        h->stream = (g == 0) ? main_stream : h->xstreams[g - 1];
-        rc = enqueue_schedule(h, stop_flag);
-        done[g] = get_evt(h);
-        if (rc == 0 && hipEventRecord(done[g], h->stream) != hipSuccess) rc = -1;
+        groups[g].B = B;
+        groups[g].B.desc = B.desc + w0;
+        groups[g].B.ctrl = B.ctrl + w0;
+        groups[g].B.n_win = w1 - w0;
+        groups[g].B.alive_cnt = h->stop_dev + 64 + 64 * g;
+        groups[g].n_win = w1 - w0;
+        groups[g].stream = (g == 0) ? h->stream : h->xstreams[g - 1];
+        groups[g].alive = h->stop_host + 64 + 64 * g;
+        groups[g].dead = false;
     }
-    h->B = B;
-    h->n_win = n;
-    h->stream = main_stream;
+    // the other streams start after everything already queued on the main stream (upload, previous run)
+    if (ngroups > 1) {
+        hipEvent_t e0 = get_evt(h);
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+        for (int g = 1; g < ngroups; g++) HIPCHK(h, hipStreamWaitEvent(groups[g].stream, e0, 0));
+    }
+    int rc = enqueue_schedule(h, groups, stop_flag);
+    for (int g = 0; g < ngroups && rc == 0; g++) {
+        done[g] = get_evt(h);
+        if (hipEventRecord(done[g], groups[g].stream) != hipSuccess) rc = -1;
+    }
     if (rc) return fail(h, h->err.empty() ? "enqueue failed" : h->err);
     if (h->profile) (void)hipEventRecord(ev_end, h->stream);
     HIPCHK(h, hipGetLastError());
