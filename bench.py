@@ -29,7 +29,7 @@ def bench_pose(args, rank, local_rank, world, dist, torch):
     oracle's PoseOptimization restatement on the same frames beside it."""
     import numpy as np
     from mc_slam_amd import synth, backend, shard
-    nb = args.batch if args.batch != 2048 else 4096
+    nb = args.batch
     distinct = [synth.make_frame(seed=shard.window_seed(g), n_obs=300, last_is_frame=bool(i % 2))
                 for i, g in enumerate(shard.window_ids(16 * world, rank, world))]
     frames = [distinct[i % len(distinct)] for i in range(nb)]
@@ -84,13 +84,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=2048, help="windows per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default: 2048 for c2 / c3, 16 for c4, 4 for gba, 4096 frames for pose)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct seeded windows generated per rank (cycled to fill the batch)")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose"],
                     help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, pose = IMU-aided per-frame pose optimisation: extra measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = {"c2": 2048, "c3": 2048, "c4": 16, "gba": 4, "pose": 4096}[args.workload]
 
     import numpy as np
     import torch

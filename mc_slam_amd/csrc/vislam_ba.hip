@@ -1178,6 +1178,14 @@ int vba_create(int device, void** handle) {
         delete h;
         return -3;
     }
+    // The streams of the window groups are created NOW, before anything ran on the main stream: created after a first solve
+    // they do not run concurrently with it (measured: 64 windows in 4 groups 16.4 ms instead of 11.3 ms when a one-window
+    // solve came first) -- the runtime binds streams to its hardware queues when they are created.
+    for (int i = 0; i < 3; i++) {
+        hipStream_t st;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+        h->xstreams.push_back(st);
+    }
     void* hp = nullptr;
     if (hipHostMalloc(&hp, 4096, hipHostMallocMapped) != hipSuccess) { delete h; return -4; }
     memset(hp, 0, 4096);
