@@ -841,49 +841,6 @@ void enqueue_lin(Handle* h, int mode) {
         hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk + h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
 }
 
-// Levenberg-Marquardt stage (levenberg.cpp:61-164).  One trial = damp, Schur, factor, solve, update,
-// re-evaluate; the device decides accept / reject.  The host learns through one pinned word per trial whether
-// any window needs another trial (rho < 0) or another outer iteration, and enqueues only those.
-int enqueue_lm_stage(Handle* h, int stage, const volatile int* stop_flag) {
-    const Batch& B = h->B;
-    const int n = h->n_win;
-    const int big_blk = std::max(h->max_kf_blk, h->max_pt_blk);
-    const int ngrp = (n >= 8) ? 8 * ((n + 7) / 8) : n;
-    volatile int* flags = h->stop_host + 4;  // [0] another trial, [1] another outer iteration
-    for (int it = 0; it < h->max_its[stage]; it++) {
-        enqueue_lin(h, LIN_FULL);
-        {
-            ProfScope ps(h, VBA_PROF_CONTROL);
-            // H_pp diagonal for computeLambdaInit (the block it writes into S is rewritten by the first trial)
-            hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 1);
-            hipLaunchKernelGGL(k_ctrl_lm_outer, dim3(n), dim3(64), 0, h->stream, B);
-        }
-        bool more_outer = false;
-        for (int trial = 0; trial < 10; trial++) {
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            flags[0] = 0;
-            flags[1] = 0;
-            {
-                ProfScope ps(h, VBA_PROF_MISC);
-                hipLaunchKernelGGL(k_backup, dim3(big_blk, n), dim3(64), 0, h->stream, B);
-            }
-            enqueue_solve_iteration(h);
-            enqueue_lin(h, LIN_ERR_TRIAL);
-            {
-                ProfScope ps(h, VBA_PROF_CONTROL);
-                hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(n), dim3(64), 0, h->stream, B, h->stop_dev + 4);
-                hipLaunchKernelGGL(k_restore, dim3(big_blk, n), dim3(64), 0, h->stream, B);
-            }
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            if (stop_flag && *stop_flag) *h->stop_host = 1;
-            more_outer = flags[1] != 0;
-            if (!flags[0]) break;
-        }
-        if (!more_outer) break;
-    }
-    return 0;
-}
-
 // One group of windows of a batch with its own stream (the whole batch is the only group unless VBA_STREAMS > 1)
 struct Group {
     Batch B;
@@ -893,10 +850,129 @@ struct Group {
     bool dead;
 };
 
+// Levenberg-Marquardt schedule (levenberg.cpp:61-164) of a batch cut into window groups.  One trial = damp, Schur, factor,
+// solve, update, re-evaluate; the device decides accept / reject.  The host learns through two pinned words per group
+// whether any of its windows needs another trial (rho < 0) or another outer iteration, and enqueues only those -- one
+// host round trip per trial.  With several groups the round trip of one group is hidden behind the kernels of the
+// others: a single host thread polls the groups' events and enqueues the next piece of whichever group is ready.
+int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile int* stop_flag) {
+    const int big_blk = std::max(std::max(h->max_kf_blk, h->max_pt_blk), h->max_obs_blk);
+    const int kp_blk = std::max(h->max_kf_blk, h->max_pt_blk);
+    const Batch B_all = h->B;
+    const int n_all = h->n_win;
+    hipStream_t main_stream = h->stream;
+    auto use = [&](const Group& g) { h->B = g.B; h->n_win = g.n_win; h->stream = g.stream; };
+    struct State { int stage = 0, it = 0, trial = 0; bool waiting = false, done = false; hipEvent_t ev = nullptr; };
+    std::vector<State> st(groups.size());
+    auto stage_begin = [&](Group& g, int stage) {
+        ProfScope ps(h, VBA_PROF_MISC);
+        hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
+        if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+        hipLaunchKernelGGL(k_stage_mark, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+    };
+    auto stage_end = [&](Group& g) {
+        if (h->variant == VBA_VARIANT_PRV_IDP) return;
+        ProfScope ps(h, VBA_PROF_MISC);
+        hipLaunchKernelGGL(k_depth_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+    };
+    auto outer = [&](Group& g) {   // linearise + computeLambdaInit of one outer iteration
+        enqueue_lin(h, LIN_FULL);
+        ProfScope ps(h, VBA_PROF_CONTROL);
+        const int ngrp = (g.n_win >= 8) ? 8 * ((g.n_win + 7) / 8) : g.n_win;
+        // H_pp diagonal for computeLambdaInit (the block it writes into S is rewritten by the first trial)
+        hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, g.stream, g.B, h->max_free, 1);
+        hipLaunchKernelGGL(k_ctrl_lm_outer, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
+    };
+    auto trial = [&](Group& g, size_t gi, State& s) -> int {
+        volatile int* flags = h->stop_host + 4 + 2 * gi;  // [0] another trial, [1] another outer iteration
+        flags[0] = 0;
+        flags[1] = 0;
+        {
+            ProfScope ps(h, VBA_PROF_MISC);
+            hipLaunchKernelGGL(k_backup, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+        }
+        enqueue_solve_iteration(h);
+        enqueue_lin(h, LIN_ERR_TRIAL);
+        {
+            ProfScope ps(h, VBA_PROF_CONTROL);
+            hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(g.n_win), dim3(64), 0, g.stream, g.B, h->stop_dev + 4 + 2 * gi);
+            hipLaunchKernelGGL(k_restore, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+        }
+        if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) return -1;
+        if (hipEventRecord(s.ev, g.stream) != hipSuccess) return -1;
+        s.waiting = true;
+        return 0;
+    };
+    auto finish = [&](Group& g) {
+        ProfScope ps(h, VBA_PROF_MISC);
+        if (h->variant != VBA_VARIANT_PRV_IDP)
+            hipLaunchKernelGGL(k_chi2_fresh_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        hipLaunchKernelGGL(k_final_edges, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        hipLaunchKernelGGL(k_final_sum, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
+    };
+    // a stage with zero iterations still runs its prologue / epilogue (optimize(0) is a no-op in g2o)
+    auto start_stage = [&](Group& g, size_t gi, State& s) -> int {
+        for (;;) {
+            stage_begin(g, s.stage);
+            if (h->max_its[s.stage] > 0) {
+                s.it = 0; s.trial = 0;
+                outer(g);
+                return trial(g, gi, s);
+            }
+            stage_end(g);
+            if (s.stage == 1) { finish(g); s.done = true; return 0; }
+            s.stage = 1;
+        }
+    };
+    int rc = 0;
+    for (size_t gi = 0; gi < groups.size() && rc == 0; gi++) {
+        Group& g = groups[gi];
+        use(g);
+        {
+            ProfScope ps(h, VBA_PROF_MISC);
+            hipLaunchKernelGGL(k_reset, dim3(big_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+        }
+        rc = start_stage(g, gi, st[gi]);
+    }
+    size_t n_done = 0;
+    for (auto& s : st) n_done += s.done ? 1 : 0;
+    while (rc == 0 && n_done < groups.size()) {
+        bool progressed = false;
+        for (size_t gi = 0; gi < groups.size() && rc == 0; gi++) {
+            State& s = st[gi];
+            if (s.done || !s.waiting) continue;
+            if (groups.size() == 1) { if (hipEventSynchronize(s.ev) != hipSuccess) { rc = -1; break; } }
+            else {
+                const hipError_t q = hipEventQuery(s.ev);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) { rc = -1; break; }
+            }
+            progressed = true;
+            s.waiting = false;
+            Group& g = groups[gi];
+            use(g);
+            if (stop_flag && *stop_flag) *h->stop_host = 1;
+            volatile int* flags = h->stop_host + 4 + 2 * gi;
+            const bool more_trial = flags[0] != 0, more_outer = flags[1] != 0;
+            if (more_trial && s.trial + 1 < 10) { s.trial++; rc = trial(g, gi, s); continue; }
+            if (more_outer && s.it + 1 < h->max_its[s.stage]) { s.it++; s.trial = 0; outer(g); rc = trial(g, gi, s); continue; }
+            stage_end(g);
+            if (s.stage == 0) { s.stage = 1; rc = start_stage(g, gi, s); if (s.done) n_done++; }
+            else { finish(g); s.done = true; n_done++; }
+        }
+        if (!progressed) std::this_thread::yield();
+    }
+    for (auto& s : st)
+        if (s.ev) (void)hipEventDestroy(s.ev);
+    h->B = B_all; h->n_win = n_all; h->stream = main_stream;
+    return rc;
+}
+
 // The two-stage schedule of a batch cut into window groups.  The groups are independent; their launches are enqueued
 // INTERLEAVED, iteration by iteration, each on its own stream, so that while one group sits in the latency-bound block
 // columns of its factorisation another one streams through its bandwidth-bound linearise / Schur kernels.
 int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* stop_flag) {
+    if (h->algo == VBA_ALGO_LM) return enqueue_schedule_lm(h, groups, stop_flag);
     const int big_blk = std::max(std::max(h->max_kf_blk, h->max_pt_blk), h->max_obs_blk);
     const Batch B_all = h->B;
     const int n_all = h->n_win;
@@ -917,10 +993,7 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
             if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
             hipLaunchKernelGGL(k_stage_mark, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
         }
-        if (h->algo == VBA_ALGO_LM) {
-            use(groups[0]);  // LM needs a host decision per trial: one group, one stream
-            if (enqueue_lm_stage(h, stage, stop_flag)) rc = -1;
-        } else {
+        {
             // The host stays at most two iterations ahead of the device: before enqueuing iteration it of a group it waits
             // for that group's control kernel of iteration it-2 and stops enqueuing for the group once none of its windows is
             // iterating any more (the |dchi2| < 1e-3 stop usually ends stage 2 after 3 of its 10 iterations).  The device
@@ -999,12 +1072,13 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     // (Profiling runs and LM, which needs a host decision per trial, use one group.)
     // Measured on MI355X, C3 windows, windows/s with 1 / 2 / 4 / 8 groups: 64 windows 5.1k / 5.6k / 5.8k / 4.1k; 256: 7.5k / 8.0k /
     // 8.5k / 6.1k; 512: 8.9k / 9.2k / 9.9k / 8.6k; 1024: 9.7k / 10.1k / 10.2k / 10.0k; 2048: 10.2k / 10.4k / 10.3k / 10.1k.
+    // LM (C2 windows, 1 / 2 / 4 groups): 256 windows 5.9k / 6.2k / 6.5k, 2048: 6.4k / 6.6k / 6.8k.
     static const int env_streams = getenv("VBA_STREAMS") ? atoi(getenv("VBA_STREAMS")) : 0;
     int want = h->opt_streams > 0 ? h->opt_streams : env_streams;
-    if (want <= 0) want = (n >= 2048) ? 2 : (n >= 64) ? 4 : (n >= 16) ? 2 : 1;   // default policy (16..48 windows: 2 groups +5..10 %, 4 groups -40 %)
+    if (want <= 0) want = (n >= 2048 && h->algo == VBA_ALGO_GN) ? 2 : (n >= 64) ? 4 : (n >= 16) ? 2 : 1;   // default policy (16..48 windows: 2 groups +5..10 %, 4 groups -40 %)
     const int max_streams = std::min(14, want);
     int ngroups = 1;
-    if (!h->profile && h->algo == VBA_ALGO_GN && max_streams > 1 && n >= 8)
+    if (!h->profile && max_streams > 1 && n >= 8)
         ngroups = std::max(1, std::min(max_streams, n / 4));
     while ((int)h->xstreams.size() < ngroups - 1) {
         hipStream_t st;
