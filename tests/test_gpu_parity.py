@@ -150,19 +150,28 @@ def test_lm_batch_of_ragged_windows_equals_single_solves(ba, oracle):
         assert r9[i].its_done == rs[i % 3].its_done
 
 
-def test_window_groups_on_several_streams_give_identical_results(ba):
-    """the optional multi-stream schedule (groups of windows on their own streams) must not change any window"""
-    ps = [synth.make_window(abi.VARIANT_PRV_IDP, n_kf=8 + (i % 3), n_fixed=1, n_pt=150 + 10 * (i % 5), n_obs=700 + 40 * (i % 5), seed=80 + i % 5)
+@pytest.mark.parametrize("variant", [abi.VARIANT_PRV_IDP, abi.VARIANT_PRV_XYZ])
+def test_window_groups_on_several_streams_give_identical_results(ba, variant):
+    """the multi-stream schedule (groups of windows on their own streams, interleaved enqueue; Gauss-Newton and the
+    Levenberg-Marquardt state machine) must not change any window: one group vs the default policy vs 3 and 4 groups"""
+    ps = [synth.make_window(variant, n_kf=8 + (i % 3), n_fixed=1, n_pt=150 + 10 * (i % 5), n_obs=700 + 40 * (i % 5), seed=80 + i % 5)
           for i in range(37)]
-    ba.upload(ps); ba.run(); q1, r1 = ba.download()
-    ba.lib.vba_debug_set_streams(ba.h, 4)
+    ba.upload(ps)
+    runs = []
     try:
-        ba.run(); q4, r4 = ba.download()
+        for streams in (1, 0, 3, 4):   # 0: default policy (two groups for 37 windows)
+            ba.lib.vba_debug_set_streams(ba.h, streams)
+            ba.run()
+            q, r = ba.download()
+            runs.append(([x.copy() for x in q], r))   # download() returns the wrapper's own problem objects
     finally:
         ba.lib.vba_debug_set_streams(ba.h, 0)
-    for a, b, ra, rb in zip(q1, q4, r1, r4):
-        assert ra.its_done == rb.its_done and ra.status == rb.status == 0
-        assert (a.kf_pose == b.kf_pose).all() and (a.pt == b.pt).all() and ra.chi2_vis == rb.chi2_vis
+    q1, r1 = runs[0]
+    assert all(r.status == 0 for r in r1)
+    for qn, rn in runs[1:]:
+        for a, b, ra, rb in zip(q1, qn, r1, rn):
+            assert ra.its_done == rb.its_done and ra.status == rb.status == 0
+            assert (a.kf_pose == b.kf_pose).all() and (a.pt == b.pt).all() and ra.chi2_vis == rb.chi2_vis
 
 
 def test_rerun_is_bit_reproducible(ba):
