@@ -40,7 +40,7 @@ DEVI void lin_point_xyz(const Batch& B, const WinDesc& d, const WinCtrl& c, int 
             Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
         }
         B.depth_e[go] = Pc[2];
-        double* rec = B.erec + VBA_EREC * go;
+        double* rec = B.erec + VBA_EREC * (size_t)(d.obs0 + B.slot_perm[go]);  // records live keyframe-major (slot_perm)
         if (B.lvl[go]) {
             if (mode == LIN_FULL)
                 for (int i = 0; i < 30; i++) rec[i] = 0.0;
@@ -248,8 +248,9 @@ __global__ void __launch_bounds__(64) k_dinv(Batch B) {
     const int* ob = B.pt_obs_begin + d.pt0 + d.win;
     double* slots = B.slot + VBA_SLOT3 * (size_t)(d.obs0 + d.pt0);
     for (int o = ob[p]; o < ob[p + 1]; o++) {
-        const double* rec = B.erec + VBA_EREC * (size_t)(d.obs0 + o);
-        double* sl = slots + VBA_SLOT3 * (size_t)o;
+        const int pe = B.slot_perm[d.obs0 + o];
+        const double* rec = B.erec + VBA_EREC * (size_t)(d.obs0 + pe);
+        double* sl = slots + VBA_SLOT3 * (size_t)pe;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             const double w0 = rec[i] * rec[12] + rec[6 + i] * rec[15];  // W = Bi^T A  (6x3)
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(64) k_update_xyz(Batch B, int nblk_pt) {
                 for (int o = ob[p]; o < ob[p + 1]; o++) {
                     const int kf = B.obs_kf[d.obs0 + o];
                     if (kf >= d.n_free) continue;
-                    const double* sl = slots + VBA_SLOT3 * (size_t)o;
+                    const double* sl = slots + VBA_SLOT3 * (size_t)B.slot_perm[d.obs0 + o];
 #pragma unroll
                     for (int i = 0; i < 6; i++) {
                         const double xi = x[vpos(d, kf, i)];

@@ -234,13 +234,13 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
                 if (kf < 0 || kf >= P->n_kf) return fail(h, "obs_kf out of range");
                 k = std::min(k, kf);
             }
-            key[p] = (P->variant == VBA_VARIANT_PRV_IDP && !no_perm && !no_track_order) ? k : 0;
+            key[p] = (!no_perm && !no_track_order) ? k : 0;
             start[key[p] + 1]++;
         }
         for (int k = 0; k < P->n_kf; k++) start[k + 1] += start[k];
         for (int p = 0; p < P->n_pt; p++) lm_order[start[key[p]]++] = p;
     }
-    if (P->variant == VBA_VARIANT_PRV_IDP && !no_perm) {
+    if (!no_perm) {
         // counting sort by observing / reference keyframe (stable: lm_order inside a keyframe)
         std::vector<int> start(P->n_kf + 1, 0);
         for (int o = 0; o < P->n_obs; o++) start[P->obs_kf[o] + 1]++;
@@ -249,12 +249,15 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
             const int p = lm_order[q];
             for (int o = P->pt_obs_begin[p]; o < P->pt_obs_begin[p + 1]; o++) st.slot_perm[o] = start[P->obs_kf[o]]++;
         }
-        start.assign(P->n_kf + 1, 0);
+    } else {
+        for (int o = 0; o < P->n_obs; o++) st.slot_perm[o] = o;
+    }
+    if (P->variant == VBA_VARIANT_PRV_IDP && !no_perm) {   // landmark records (reference slot, point record, N0) by reference keyframe
+        std::vector<int> start(P->n_kf + 1, 0);
         for (int p = 0; p < P->n_pt; p++) start[P->pt_ref_kf[p] + 1]++;
         for (int k = 0; k < P->n_kf; k++) start[k + 1] += start[k];
         for (int q = 0; q < P->n_pt; q++) st.pt_perm[lm_order[q]] = start[P->pt_ref_kf[lm_order[q]]]++;
-    } else {
-        for (int o = 0; o < P->n_obs; o++) st.slot_perm[o] = o;
+    } else {   // XYZ landmarks have no reference keyframe: their point records stay in landmark order
         for (int p = 0; p < P->n_pt; p++) st.pt_perm[p] = p;
     }
     std::vector<int> cnt(npairs + 1, 0);
