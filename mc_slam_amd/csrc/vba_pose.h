@@ -40,10 +40,11 @@ struct PoseBatch {
 
 #define PO_N 30
 // LDS layout (doubles)
-#define PO_H 0                  // 30x30
+#define PO_A 0                  // damped copy / Cholesky factor (30x30); the Gauss-Jordan workspace [30][60] of the marginals
+                                // spans PO_A .. PO_A + 1800, i.e. A and H (H is dead by then): 30.6 KB per frame, five frames per CU
+#define PO_H (PO_A + 900)       // 30x30
 #define PO_HL (PO_H + 900)      // Hessian of the last linearisation (computeMarginals)
-#define PO_A (PO_HL + 900)      // damped copy / Cholesky factor; Gauss-Jordan workspace [30][60] spans PO_A..PO_A+1800
-#define PO_J (PO_A + 1800)      // edge Jacobian d x 30 (d <= 15)
+#define PO_J (PO_HL + 900)      // edge Jacobian d x 30 (d <= 15)
 #define PO_T (PO_J + 450)       // Omega J
 #define PO_B (PO_T + 450)       // b (30)
 #define PO_X (PO_B + 30)        // x (30)
@@ -512,7 +513,8 @@ DEVI bool po_solve(double* sm, int n, double lambda) {
 }
 
 // inverse of the n x n matrix src (row stride ls) into dst (row stride ld) by Gauss-Jordan with partial pivoting, the
-// rows of every elimination step spread over the lanes; workspace sm[PO_A .. PO_A + 1800)
+// rows of every elimination step spread over the lanes; workspace sm[PO_A .. PO_A + 60 n): for n = 30 that is PO_A and PO_H.
+// src may equal dst (the source is copied into the workspace first)
 DEVI void po_inverse(double* sm, const double* src, int ls, int n, double* dst, int ld) {
     const int t = threadIdx.x;
     double* M = sm + PO_A;  // [n][2n], row stride 60
@@ -662,17 +664,16 @@ __global__ void __launch_bounds__(64) k_pose_opt(PoseBatch B) {
     if (d.compute_marg && !vision) {
         // computeMarginals on the Hessian of the last linearisation (:2244-2254 / :2005-2019)
         __syncthreads();
-        double* Hi = sm + PO_H;  // H itself is no longer needed
+        double* Hi = sm + PO_HL;  // in place: po_inverse copies its source into the workspace before it writes
         po_inverse(sm, sm + PO_HL, n, n, Hi, n);
+        double* tmp = sm + PO_H;  // the smaller inverses (n <= 15) only use the PO_A half of the workspace
         if (!lif) {
-            double* tmp = sm + PO_HL;
             po_inverse(sm, Hi, n, 9, tmp, 9);
             for (int q = t; q < 81; q += 64) out.marg[15 * (q / 9) + q % 9] = tmp[q];
             __syncthreads();
             po_inverse(sm, Hi + 9 * n + 9, n, 6, tmp, 6);
             for (int q = t; q < 36; q += 64) out.marg[15 * (9 + q / 6) + 9 + q % 6] = tmp[q];
         } else {
-            double* tmp = sm + PO_HL;
             po_inverse(sm, Hi, n, 15, tmp, 15);
             for (int q = t; q < 225; q += 64) out.marg[q] = tmp[q];
         }
