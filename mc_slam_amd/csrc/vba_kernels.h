@@ -1322,6 +1322,10 @@ __global__ void __launch_bounds__(64) k_chol_update(Batch B, int k) {
 //                   needs no serial triangular solve)
 //   panel tile    : C_IJ, then L_IJ = C_IJ W_J as one more MFMA product.
 // ------------------------------------------------------------------------------------------------
+// PF: register double buffer -- the tiles of step e+1 are in flight while the MFMAs of step e run.  It pays for the
+// diagonal tile (one wave per window: the launch is latency-bound and the extra registers cost nothing) and not for the
+// panel tiles (many waves per window: 171 instead of 118 VGPRs drop the occupancy from 3 to 2 waves per SIMD).
+template <bool PF>
 DEVI void ll_accumulate(const Batch& B, const WinDesc& d, int I, int J, int kb, int ke, double* XI, double* XJ, double* ys,
                         d4_t (&acc)[2][2], double* rhs_dot) {
     __shared__ double dgs[32];
@@ -1340,43 +1344,36 @@ DEVI void ll_accumulate(const Batch& B, const WinDesc& d, int I, int J, int kb, 
         }
     const int* kl = B.tl_kl + d.tl_k0;
     double sdot = 0.0;
-#ifndef LL_PREFETCH
-#define LL_PREFETCH 0
-#endif
-#if LL_PREFETCH
-    // register double buffer: the tiles of step e+1 are in flight while the MFMAs of step e run
-    double pi[16], pj[16], pd[16], py = 0.0;
-    if (kb < ke) {
+    double pi[PF ? 16 : 1], pj[PF ? 16 : 1], pd[PF ? 16 : 1], py = 0.0;
+    if (PF && kb < ke) {
         const size_t dk = (size_t)kl[kb] * 32;
         const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
         const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
         const double* sd = B.dvec + d.vec0 + dk + c0;
 #pragma unroll
-        for (int q = 0; q < 16; q++) { pi[q] = si[q]; pj[q] = sj[q]; pd[q] = sd[q]; }
+        for (int q = 0; q < (PF ? 16 : 1); q++) { pi[q] = si[q]; pj[q] = sj[q]; pd[q] = sd[q]; }
         if (rhs_dot && lane < 32) py = B.yv[d.vec0 + dk + lane];
     }
-#endif
     for (int e = kb; e < ke; e++) {
         __syncthreads();  // the previous step's MFMAs are done with XI / XJ
-#if LL_PREFETCH
+        if (PF) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            XI[row * 34 + c0 + q] = pi[q];
-            XJ[row * 34 + c0 + q] = pj[q] * pd[q];
-        }
-        if (rhs_dot && lane < 32) ys[lane] = py;
-        __syncthreads();
-        if (e + 1 < ke) {
-            const size_t dk = (size_t)kl[e + 1] * 32;
-            const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
-            const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
-            const double* sd = B.dvec + d.vec0 + dk + c0;
+            for (int q = 0; q < (PF ? 16 : 1); q++) {
+                XI[row * 34 + c0 + q] = pi[q];
+                XJ[row * 34 + c0 + q] = pj[q] * pd[q];
+            }
+            if (rhs_dot && lane < 32) ys[lane] = py;
+            __syncthreads();
+            if (e + 1 < ke) {
+                const size_t dk = (size_t)kl[e + 1] * 32;
+                const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
+                const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
+                const double* sd = B.dvec + d.vec0 + dk + c0;
 #pragma unroll
-            for (int q = 0; q < 16; q++) { pi[q] = si[q]; pj[q] = sj[q]; pd[q] = sd[q]; }
-            if (rhs_dot && lane < 32) py = B.yv[d.vec0 + dk + lane];
-        }
-#else
-        {
+                for (int q = 0; q < (PF ? 16 : 1); q++) { pi[q] = si[q]; pj[q] = sj[q]; pd[q] = sd[q]; }
+                if (rhs_dot && lane < 32) py = B.yv[d.vec0 + dk + lane];
+            }
+        } else {
             const size_t dk = (size_t)kl[e] * 32;
             if (lane < 32) {   // D_k (and y_k) once per wave through LDS, not 16 doubles per lane from memory
                 dgs[lane] = B.dvec[d.vec0 + dk + lane];
@@ -1390,9 +1387,8 @@ DEVI void ll_accumulate(const Batch& B, const WinDesc& d, int I, int J, int kb, 
                 XI[row * 34 + c0 + q] = si[q];
                 XJ[row * 34 + c0 + q] = sj[q] * dgs[c0 + q];
             }
+            __syncthreads();
         }
-        __syncthreads();
-#endif
         if (rhs_dot && lane < 32) {
 #pragma unroll
             for (int q = 0; q < 32; q++) sdot += XI[lane * 34 + q] * ys[q];
@@ -1422,7 +1418,7 @@ DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, do
     const int l15 = lane & 15, l4 = lane >> 4;
     d4_t acc[2][2];
     double sdot = 0.0;
-    ll_accumulate(B, d, J, J, klb[ent], klb[ent + 1], XI, XJ, ys, acc, &sdot);
+    ll_accumulate<true>(B, d, J, J, klb[ent], klb[ent + 1], XI, XJ, ys, acc, &sdot);
     // C_JJ through LDS into one row per lane
     double* CT = XI;
 #pragma unroll
@@ -1482,8 +1478,8 @@ DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, do
     }
 }
 
-// (A fused variant -- the wave that owns tile (J+1,J) going on to factor diagonal tile J+1 -- and a register double buffer
-// for the tile loads were measured: no gain at 512 windows)
+// (A fused variant -- the wave that owns tile (J+1,J) going on to factor diagonal tile J+1 -- was measured: no gain at 512
+// windows)
 __global__ void __launch_bounds__(64) k_chol_diag_ll(Batch B, int J) {
     __shared__ double XI[32 * 34];
     __shared__ double XJ[32 * 34];
@@ -1516,7 +1512,7 @@ __global__ void __launch_bounds__(64) k_chol_panel_ll(Batch B, int J) {
     const int lane = threadIdx.x, n = d.nS;
     const int l15 = lane & 15, l4 = lane >> 4;
     d4_t acc[2][2];
-    ll_accumulate(B, d, I, J, klb[ent], klb[ent + 1], XI, XJ, ys, acc, nullptr);
+    ll_accumulate<false>(B, d, I, J, klb[ent], klb[ent + 1], XI, XJ, ys, acc, nullptr);
     // L_IJ = C_IJ W_J
     double* CT = XI;
     double* WT = XJ;
