@@ -40,7 +40,7 @@ struct WinDesc {
     int tl_step0;   // offset of this window's step_begin / pan_begin rows (nb + 1 entries each)
     int tl_pair0;   // offset into the tile-pair list
     int tl_pan0;    // offset into the panel-tile list
-    int lb0;        // offset into the k_lin2 landmark-run table
+    int lb0;        // first record of the window in the k_lin2 run table
     int win;        // index of this window in the uploaded batch: the CSR-style tables (pt_obs_begin, item_begin,
                     // pimu_begin) carry one extra entry per window, so their rows start at offset + win
     int tl_kb0;     // offset of this window's column-entry table of the left-looking factorisation (pan entries + nb + 1)

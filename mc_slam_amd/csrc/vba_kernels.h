@@ -40,7 +40,7 @@ struct Batch {
     // structure (g2o buildStructure analogue, built on the host at upload)
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
     const int *off_pair, *pair_mask;  // off-diagonal pair indices; per pair: which sub-blocks of S are ever read
-    const int* lin_blk;  // k_lin2: first landmark of every workgroup's run (n_part_lin + 1 entries per window)
+    const int* lin_blk;  // k_lin2: per workgroup its run of landmarks and edges (p0, p1, e0, e1), n_part_lin records per window
     // tile structure of the factor (symbolic factorisation on 32x32 tiles, built at upload)
     const int *tl_step_begin, *tl_pairs, *tl_pan_begin, *tl_pan;
     const int *tl_kl_begin, *tl_kl;  // left-looking factorisation: per column entry (J,J),(I,J).. the steps k < J that update it
@@ -381,12 +381,29 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
     }
     const int lb = blockIdx.x;
     if (lb >= d.n_part_lin) return;
-    const int* tbl = B.lin_blk + d.lb0;
-    const int p0 = tbl[lb], p1 = tbl[lb + 1];
+    const int4 run = reinterpret_cast<const int4*>(B.lin_blk)[d.lb0 + lb];  // one load instead of the chain table -> CSR
+    const int p0 = run.x, p1 = run.y, e0 = run.z, e1 = run.w;
     const int* ob = B.pt_obs_begin + d.pt0 + d.win;
-    const int e0 = ob[p0], e1 = ob[p1];
     const int ne = e1 - e0, npb = p1 - p0;
     const double fx = d.K[0], fy = d.K[1], cx = d.K[2], cy = d.K[3];
+    // the edge lanes fetch their own inputs BEFORE phase A: the chain obs_kf -> keyframe R|t then overlaps with phase A's
+    // pt_ref -> reference R|t instead of following it behind the barrier
+    int pl = 0, e_kf = 0, e_pe = 0;
+    bool e_out = true;
+    double Ri[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, e_t[3] = {0, 0, 0}, e_u = 0, e_v = 0, e_w = 0;
+    if (t < ne) {
+        const size_t go = d.obs0 + e0 + t;
+        pl = B.obs_pt[go] - p0;
+        e_kf = B.obs_kf[go];
+        e_pe = B.slot_perm[go];
+        e_out = B.lvl[go] != 0;
+        e_u = B.obs_uv[2 * go]; e_v = B.obs_uv[2 * go + 1];
+        e_w = B.obs_w[go];
+        const double* Ci = B.kfR + 12 * (size_t)(d.kf0 + e_kf);
+#pragma unroll
+        for (int i = 0; i < 9; i++) Ri[i] = Ci[i];
+        e_t[0] = Ci[9]; e_t[1] = Ci[10]; e_t[2] = Ci[11];
+    }
     // A. one lane per landmark: quantities shared by all its edges
     if (t < npb) {
         const size_t gp = d.pt0 + p0 + t;
@@ -423,17 +440,11 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
     double ub[6] = {0, 0, 0, 0, 0, 0};      // Bi^T a: numerator of the edge's slot record
     double rpc[3] = {0, 0, 1}, rsc = 0.0;   // edge record: P_c and the Jacobian scale (0: no Jacobian for the readers)
     double a[2] = {0, 0}, r2[2] = {0, 0};
-    int pl = 0;
     if (t < ne) {
         const size_t go = d.obs0 + e0 + t;
-        pl = B.obs_pt[go] - p0;
         const double* q = PT + pl * LIN2_PS;
-        const int kf = B.obs_kf[go];
-        const double* Ci = B.kfR + 12 * (size_t)(d.kf0 + kf);
-        double Ri[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) Ri[i] = Ci[i];
-        const double v[3] = {q[4] - Ci[9], q[5] - Ci[10], q[6] - Ci[11]};
+        const int kf = e_kf;
+        const double v[3] = {q[4] - e_t[0], q[5] - e_t[1], q[6] - e_t[2]};
         double ta[3], Pc[3];
         mtv3(Ri, v, ta);
         mv3(d.Rcb, ta, Pc);
@@ -441,11 +452,11 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
         B.depth_e[go] = Pc[2];
         rpc[0] = Pc[0]; rpc[1] = Pc[1]; rpc[2] = Pc[2];
         double A[6] = {0, 0, 0, 0, 0, 0};
-        if (!B.lvl[go]) {
+        if (!e_out) {
             const double iz = 1.0 / Pc[2];
-            const double ex = B.obs_uv[2 * go] - (Pc[0] * iz * fx + cx);
-            const double ey = B.obs_uv[2 * go + 1] - (Pc[1] * iz * fy + cy);
-            const double wgt = B.obs_w[go];
+            const double ex = e_u - (Pc[0] * iz * fx + cx);
+            const double ey = e_v - (Pc[1] * iz * fy + cy);
+            const double wgt = e_w;
             const double s = ex * (wgt * ex) + ey * (wgt * ey);
             B.chi2_e[go] = s;
             double rw = 1.0;
@@ -585,7 +596,7 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
     //    from which the Schur kernels rebuild Bi, g = -Bi^T r and Br = [-A | A N0].  Records live keyframe-major (slot_perm).
     if (t < ne) {
         const double sD = PT[pl * LIN2_PS + 17], beta = PT[pl * LIN2_PS + 18];
-        const int pe = B.slot_perm[d.obs0 + e0 + t];
+        const int pe = e_pe;
         double* sl = B.slot + VBA_SLOT * (size_t)(d.obs0 + d.pt0 + pe);
 #pragma unroll
         for (int i = 0; i < 6; i++) sl[i] = ub[i] * sD;

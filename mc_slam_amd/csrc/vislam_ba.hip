@@ -568,10 +568,11 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             d.n_part_lin = (d.n_pt + 63) / 64;
             if (P->variant == VBA_VARIANT_PRV_IDP) {
                 // k_lin2 work split: runs of consecutive landmarks with <= 256 edges and <= 64 landmarks per workgroup
-                d.lb0 = (int)linblk.size();
+                // (one 16-B record per workgroup: first / end landmark, first / end edge)
+                d.lb0 = (int)(linblk.size() / 4);
                 int nb2 = 0, p = 0;
                 while (p < d.n_pt) {
-                    linblk.push_back(p);
+                    const int p_first = p;
                     nb2++;
                     int ne = 0, np2 = 0;
                     while (p < d.n_pt && np2 < 64) {
@@ -580,8 +581,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
                         if (ne + k > 256) break;
                         ne += k; np2++; p++;
                     }
+                    linblk.push_back(p_first); linblk.push_back(p);
+                    linblk.push_back(P->pt_obs_begin[p_first]); linblk.push_back(P->pt_obs_begin[p]);
                 }
-                linblk.push_back(d.n_pt);
                 d.n_part_lin = nb2;
             }
             d.S0 = (long long)S_tot;
