@@ -404,6 +404,14 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
         for (int i = 0; i < 9; i++) Ri[i] = Ci[i];
         e_t[0] = Ci[9]; e_t[1] = Ci[10]; e_t[2] = Ci[11];
     }
+    // likewise the phase-C lanes (four per landmark): CSR bounds and record position of their landmark
+    int c_ob = 0, c_oe = 0, c_pp = 0;
+    if (t < 4 * npb) {
+        const int p = p0 + (t >> 2);
+        c_ob = ob[p] - e0;
+        c_oe = ob[p + 1] - e0;
+        c_pp = B.pt_perm[d.pt0 + p];
+    }
     // A. one lane per landmark: quantities shared by all its edges
     if (t < npb) {
         const size_t gp = d.pt0 + p0 + t;
@@ -513,7 +521,7 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
         const int p = p0 + jl;
         const size_t gp = d.pt0 + p;
         double D = 0, bl = 0, M[6] = {0, 0, 0, 0, 0, 0}, wa[3] = {0, 0, 0}, wr[3] = {0, 0, 0};
-        for (int o = ob[p] - e0 + sub; o < ob[p + 1] - e0; o += 4) {
+        for (int o = c_ob + sub; o < c_oe; o += 4) {
             const double* er = ER + o * LIN2_ES;
             const double a0 = er[6], a1 = er[7], q0 = er[8], q1 = er[9];
             D += a0 * a0 + a1 * a1;
@@ -542,7 +550,7 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
         double N0[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) N0[i] = q[7 + i];
-        const int pp = B.pt_perm[gp];  // landmark records grouped by reference keyframe
+        const int pp = c_pp;  // landmark records grouped by reference keyframe
         if (sub == 0) {
             q[17] = sD;
             q[18] = beta;
