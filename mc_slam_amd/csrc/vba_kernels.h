@@ -1648,12 +1648,35 @@ __global__ void __launch_bounds__(64) k_update(Batch B, int nblk_pt) {
 #pragma unroll
             for (int i = 0; i < 6; i++) cl -= sr[i] * x[vpos(d, rf, i)];
         const int* ob = B.pt_obs_begin + d.pt0 + d.win;
-        for (int o = ob[p]; o < ob[p + 1]; o++) {
-            const int kf = B.obs_kf[d.obs0 + o];
-            if (kf >= d.n_free) continue;
-            const double* sl = slots + VBA_SLOT * (size_t)B.slot_perm[d.obs0 + o];
+        // two edges per trip, their indices fetched one trip ahead: per landmark ~n/2 + 1 dependent round trips instead of 2 n
+        const int o0 = ob[p], o1 = ob[p + 1];
+        int kfn[2] = {0, 0}, spn[2] = {0, 0};
 #pragma unroll
-            for (int i = 0; i < 6; i++) cl -= sl[i] * x[vpos(d, kf, i)];
+        for (int u = 0; u < 2; u++)
+            if (o0 + u < o1) { kfn[u] = B.obs_kf[d.obs0 + o0 + u]; spn[u] = B.slot_perm[d.obs0 + o0 + u]; }
+        for (int o = o0; o < o1; o += 2) {
+            const int kf0 = kfn[0], kf1 = kfn[1], sp0 = spn[0], sp1 = spn[1];
+            const bool two = o + 1 < o1;
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (o + 2 + u < o1) { kfn[u] = B.obs_kf[d.obs0 + o + 2 + u]; spn[u] = B.slot_perm[d.obs0 + o + 2 + u]; }
+            const bool on0 = kf0 < d.n_free, on1 = two && kf1 < d.n_free;
+            const double* sl0 = slots + VBA_SLOT * (size_t)sp0;
+            const double* sl1 = slots + VBA_SLOT * (size_t)(on1 ? sp1 : sp0);
+            double u0[6], u1[6], x0[6], x1[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                u0[i] = sl0[i]; u1[i] = sl1[i];
+                x0[i] = x[vpos(d, on0 ? kf0 : 0, i)]; x1[i] = x[vpos(d, on1 ? kf1 : 0, i)];
+            }
+            if (on0) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) cl -= u0[i] * x0[i];
+            }
+            if (on1) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) cl -= u1[i] * x1[i];
+            }
         }
         double rho = B.pt[3 * gp] + sD * cl;
         if (rho < 1e-6) rho = 1e-6;  // VertexIDP::oplusImpl, g2otypes.h:50-55
