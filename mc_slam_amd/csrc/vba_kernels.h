@@ -162,11 +162,13 @@ __global__ void __launch_bounds__(64) k_stage_mark(Batch B) {
     int* va = B.var_act + d.vec0;
     if (t < d.n_obs && !B.lvl[d.obs0 + t]) {
         const int kf = B.obs_kf[d.obs0 + t];
-        if (kf_free(B, d, kf) & 1)
+        // thousands of edges mark the same few hundred flags: look before storing (whoever set the first flag of a block
+        // sets the other five as well), the stores to one line would otherwise serialise in the L2
+        if ((kf_free(B, d, kf) & 1) && !va[vpos(d, kf, 0)])
             for (int i = 0; i < 6; i++) va[vpos(d, kf, i)] = 1;
         if (d.variant == 2) {
             const int rf = B.pt_ref[d.pt0 + B.obs_pt[d.obs0 + t]];
-            if (kf_free(B, d, rf) & 1)
+            if ((kf_free(B, d, rf) & 1) && !va[vpos(d, rf, 0)])
                 for (int i = 0; i < 6; i++) va[vpos(d, rf, i)] = 1;
         }
     }
