@@ -19,6 +19,7 @@
 #include <functional>
 #include <string>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -194,7 +195,10 @@ int vpos_host(int order, int pdim, int nf, int a, int r) {
     return order ? 15 * a + r : (r < 6 ? 9 * nf + 6 * a + r : 9 * a + (r - 6));
 }
 
+double now_ms();
 int build_structure(Handle* h, const vba_problem* P, Structure& st) {
+    static const bool timing = getenv("VBA_TIMING") != nullptr;
+    const double t_b0 = timing ? now_ms() : 0.0;
     const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2;
     auto pidx = [nf](int a, int b) { return a * nf - a * (a - 1) / 2 + (b - a); };
     st.pair_a.resize(npairs);
@@ -266,49 +270,66 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     // per pair the items are ordered: first the pairs of two observation slots, then the pairs that involve the
     // landmark's reference keyframe (these also carry a direct H_pp term; grouping them keeps waves uniform)
     std::vector<int> cnt2(npairs + 1, 0);
-    for (int pass = 0; pass < 2; pass++) {
-        std::vector<int> fill, fill2;
-        if (pass == 1) {
-            st.item_begin.assign(npairs + 1, 0);
-            for (int i = 0; i < npairs; i++) st.item_begin[i + 1] = st.item_begin[i] + cnt[i] + cnt2[i];
-            st.items.resize(2 * (size_t)st.item_begin[npairs]);
-            fill.assign(st.item_begin.begin(), st.item_begin.end() - 1);
-            fill2.resize(npairs);
-            for (int i = 0; i < npairs; i++) fill2[i] = st.item_begin[i] + cnt[i];
+    // one walk over the landmarks records every item (pair index, kind, slot ids) and counts per pair; a second, linear
+    // pass scatters the recorded items to their places (the walk -- sorting, pair indices -- is not repeated)
+    size_t rec_max = 0;
+    for (int p = 0; p < P->n_pt; p++) {
+        const size_t m = (size_t)(P->pt_obs_begin[p + 1] - P->pt_obs_begin[p]) + (idp ? 1 : 0);
+        rec_max += m * (m + 1) / 2;
+    }
+    std::unique_ptr<int[]> rec(new int[3 * rec_max + 3]);   // uninitialised on purpose
+    size_t nrec = 0;
+    for (int q = 0; q < P->n_pt; q++) {
+        const int p = lm_order[q];
+        sl.clear();
+        const int o0 = P->pt_obs_begin[p], o1 = P->pt_obs_begin[p + 1];
+        bool sorted = true;
+        if (idp) {
+            const int rf = P->pt_ref_kf[p];
+            if (rf < nf) sl.push_back({rf, -1});
         }
-        for (int q = 0; q < P->n_pt; q++) {
-            const int p = lm_order[q];
-            sl.clear();
-            const int o0 = P->pt_obs_begin[p], o1 = P->pt_obs_begin[p + 1];
-            if (idp) {
-                const int rf = P->pt_ref_kf[p];
-                if (rf < 0 || rf >= P->n_kf) return fail(h, "pt_ref_kf out of range");
-                if (rf < nf) sl.push_back({rf, -1});
+        for (int o = o0; o < o1; o++) {
+            const int kf = P->obs_kf[o];
+            if (idp && kf == P->pt_ref_kf[p]) return fail(h, "observation from the reference keyframe is not an edge");
+            st.obs_pt[o] = p;
+            if (kf < nf) {
+                if (!sl.empty() && kf <= sl.back().first) sorted = false;
+                sl.push_back({kf, o});
             }
-            for (int o = o0; o < o1; o++) {
-                const int kf = P->obs_kf[o];
-                if (kf < 0 || kf >= P->n_kf) return fail(h, "obs_kf out of range");
-                if (idp && kf == P->pt_ref_kf[p]) return fail(h, "observation from the reference keyframe is not an edge");
-                st.obs_pt[o] = p;
-                if (kf < nf) sl.push_back({kf, o});
+        }
+        if (!sorted) std::sort(sl.begin(), sl.end());
+        for (size_t i = 1; i < sl.size(); i++)
+            if (sl[i].first == sl[i - 1].first) return fail(h, "a landmark is observed twice from one keyframe");
+        const int ref_slot = P->n_obs + st.pt_perm[p];   // slot ids: observation o -> its record position; reference keyframe -> n_obs + landmark record
+        for (size_t i1 = 0; i1 < sl.size(); i1++) {
+            const int a = sl[i1].first, sa = sl[i1].second >= 0 ? st.slot_perm[sl[i1].second] : ref_slot;
+            const int row = a * nf - a * (a - 1) / 2 - a;   // pidx(a, b) = row + b
+            for (size_t i2 = i1; i2 < sl.size(); i2++) {
+                const int pi = row + sl[i2].first;
+                const bool refpair = (i1 != i2) && (sl[i1].second < 0 || sl[i2].second < 0);
+                if (refpair) cnt2[pi]++; else cnt[pi]++;
+                rec[nrec] = 2 * pi + (refpair ? 1 : 0);
+                rec[nrec + 1] = sa;
+                rec[nrec + 2] = sl[i2].second >= 0 ? st.slot_perm[sl[i2].second] : ref_slot;
+                nrec += 3;
             }
-            std::sort(sl.begin(), sl.end());
-            for (size_t i = 1; i < sl.size(); i++)
-                if (sl[i].first == sl[i - 1].first) return fail(h, "a landmark is observed twice from one keyframe");
-            for (size_t i1 = 0; i1 < sl.size(); i1++)
-                for (size_t i2 = i1; i2 < sl.size(); i2++) {
-                    const int pi = pidx(sl[i1].first, sl[i2].first);
-                    const bool refpair = (i1 != i2) && (sl[i1].second < 0 || sl[i2].second < 0);
-                    if (pass == 0) { if (refpair) cnt2[pi]++; else cnt[pi]++; }
-                    else {
-                        int* it = &st.items[2 * (size_t)(refpair ? fill2[pi]++ : fill[pi]++)];
-                        // slot ids: observation o -> o ; reference keyframe of landmark p -> n_obs + p
-                        it[0] = sl[i1].second >= 0 ? st.slot_perm[sl[i1].second] : P->n_obs + st.pt_perm[p];
-                        it[1] = sl[i2].second >= 0 ? st.slot_perm[sl[i2].second] : P->n_obs + st.pt_perm[p];
-                    }
-                }
         }
     }
+    {
+        st.item_begin.assign(npairs + 1, 0);
+        for (int i = 0; i < npairs; i++) st.item_begin[i + 1] = st.item_begin[i] + cnt[i] + cnt2[i];
+        st.items.resize(2 * (size_t)st.item_begin[npairs]);
+        // per pair the items are ordered: first the pairs of two observation slots, then the ones with the reference keyframe
+        std::vector<int> fill(st.item_begin.begin(), st.item_begin.end() - 1), fill2(npairs);
+        for (int i = 0; i < npairs; i++) fill2[i] = st.item_begin[i] + cnt[i];
+        for (size_t r = 0; r < nrec; r += 3) {
+            const int pi = rec[r] >> 1;
+            int* it = &st.items[2 * (size_t)((rec[r] & 1) ? fill2[pi]++ : fill[pi]++)];
+            it[0] = rec[r + 1];
+            it[1] = rec[r + 2];
+        }
+    }
+    const double t_b1 = timing ? now_ms() : 0.0;
     // IMU edges per block pair
     std::vector<std::vector<std::pair<int, int>>> pl(npairs);
     const int nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
@@ -422,6 +443,7 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     }
     symbolic(st.order);
     st.off_pair.resize(npairs, 0);  // padded to the pair stride
+    if (timing) fprintf(stderr, "[vba] structure: orders + item lists %.3f ms, IMU lists + symbolic factorisation %.3f ms\n", t_b1 - t_b0, now_ms() - t_b1);
     return 0;
 }
 
