@@ -1569,7 +1569,7 @@ __global__ void __launch_bounds__(64) k_chol_panel_ll(Batch B, int J) {
 }
 
 // K_trsv: L^T x = y.  One 256-thread workgroup per window walks the block columns from the bottom: the
-// column's nonzero tiles are gathered by all four waves, the 32x32 triangular solve runs in wave 0 on
+// column's nonzero tiles are gathered by the four waves (one tile per wave and trip), the 32x32 triangular solve runs in wave 0 on
 // registers (column of L per lane, v_readlane broadcasts).
 __global__ void __launch_bounds__(256) k_trsv(Batch B) {
     extern __shared__ double xs[];  // nS doubles + 8*32 partials + 32*33 diagonal tile
@@ -1586,20 +1586,37 @@ __global__ void __launch_bounds__(256) k_trsv(Batch B) {
     const int* pan = B.tl_pan + d.tl_pan0;
     for (int q = t; q < n; q += 256) xs[q] = yv[q];
     __syncthreads();
-    const int cc = t & 31, rl = t >> 5;
+    // the column's panel tiles are dealt to the four waves; a lane takes 16 rows of a tile, so its 16 loads are in flight
+    // together and a column with m tiles costs ceil(m / 4) memory round trips, not m
+    const int cc = t & 31, rl = t >> 5, wave = t >> 6, half = (t >> 5) & 1;
+    // the diagonal tile of the next block column is fetched while this one is solved
+    double nx[4];
+    {
+        const size_t dk = (size_t)(d.nb - 1) * 32;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = t + 256 * u; nx[u] = S[(dk + (q >> 5)) * n + dk + (q & 31)]; }
+    }
     for (int k = d.nb - 1; k >= 0; k--) {
         const size_t dk = (size_t)k * 32;
         double s = 0.0;
-        for (int idx = pb[k]; idx < pb[k + 1]; idx++) {
-            const int I = pan[idx];
+        const int i0 = pb[k], m = pb[k + 1] - i0;
+        for (int i = wave; i < m; i += 4) {
+            const int I = pan[i0 + i];
+            const int r0 = I * 32 + half * 16;
+            double lv[16];
 #pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const int row = I * 32 + rl + 8 * rr;
-                s += S[(size_t)row * n + dk + cc] * xs[row];
-            }
+            for (int rr = 0; rr < 16; rr++) lv[rr] = S[(size_t)(r0 + rr) * n + dk + cc];
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) s += lv[rr] * xs[r0 + rr];
         }
         part[rl * 32 + cc] = s;
-        for (int q = t; q < 1024; q += 256) Lt[(q >> 5) * 33 + (q & 31)] = S[(dk + (q >> 5)) * n + dk + (q & 31)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = t + 256 * u; Lt[(q >> 5) * 33 + (q & 31)] = nx[u]; }
+        if (k > 0) {
+            const size_t dn = dk - 32;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int q = t + 256 * u; nx[u] = S[(dn + (q >> 5)) * n + dn + (q & 31)]; }
+        }
         __syncthreads();
         if (t < 64) {
             const int c = t & 31;
