@@ -1086,6 +1086,17 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
     const double* arow = S + (dk + r) * n + dk;
 #pragma unroll
     for (int q = 0; q < 32; q++) a[q] = (q <= r) ? arow[q] : 0.0;
+    // the trailing tile C_IJ is requested now as well: it arrives while the diagonal tile is factored and the panels solved
+    const int l15 = lane & 15, l4 = lane >> 4;
+    d4_t cacc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            const double* C = S + ((size_t)I * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
+#pragma unroll
+            for (int i = 0; i < 4; i++) cacc[ti][tj][i] = has_pair ? C[(size_t)(l4 + 4 * i) * n + l15] : 0.0;
+        }
     // L D L^T of the diagonal tile (unit lower L, D on the diagonal), as Eigen's SimplicialLDLT does: negative
     // pivots are fine, only an exactly zero / non-finite pivot fails (linear_solver_eigen.h:105-111)
     bool bad = false;
@@ -1157,16 +1168,13 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
     }
     __syncthreads();
     const double* XJp = XJ;
-    const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int ti = 0; ti < 2; ti++)
 #pragma unroll
         for (int tj = 0; tj < 2; tj++) {
             if (diagp && tj > ti) continue;
             double* C = S + ((size_t)I * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
-            d4_t acc;
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] = C[(size_t)(l4 + 4 * i) * n + l15];
+            d4_t acc = cacc[ti][tj];
 #pragma unroll
             for (int ks = 0; ks < 8; ks++) {
                 const double av = -XI[(16 * ti + l15) * 34 + 4 * ks + l4];
