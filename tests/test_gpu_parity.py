@@ -69,6 +69,48 @@ def test_xyz_variants_match_oracle(ba, oracle, variant, algo, kw):
         assert abs(r.lambda_final - ro.lambda_final) <= 1e-6 * ro.lambda_final
 
 
+def _shuffled(p, seed, drop_middle=False):
+    """the same window with its landmarks in another order and the observations of every landmark in another order
+    (the caller's order is arbitrary: the structure build sorts where it has to); drop_middle removes the middle
+    observation of every long track, so that tracks are no longer runs of consecutive keyframes"""
+    rng = np.random.default_rng(seed)
+    q = p.copy()
+    nb = p.pt_obs_begin
+    order = rng.permutation(len(nb) - 1)
+    idx, begin = [], [0]
+    for i in order:
+        o = np.arange(nb[i], nb[i + 1])
+        if drop_middle and len(o) >= 5:
+            o = np.delete(o, len(o) // 2)
+        o = rng.permutation(o)
+        idx.append(o)
+        begin.append(begin[-1] + len(o))
+    idx = np.concatenate(idx)
+    q.pt = p.pt[order].copy()
+    if p.pt_ref_kf is not None:
+        q.pt_ref_kf = p.pt_ref_kf[order].copy()
+    q.obs_kf = p.obs_kf[idx].copy(); q.obs_uv = p.obs_uv[idx].copy(); q.obs_w = p.obs_w[idx].copy()
+    q.pt_obs_begin = np.asarray(begin, dtype=np.int32)
+    return q
+
+
+@pytest.mark.parametrize("variant,drop", [(abi.VARIANT_PRV_IDP, False), (abi.VARIANT_PRV_IDP, True), (abi.VARIANT_PRV_XYZ, True),
+                                          (abi.VARIANT_SE3_XYZ, False)])
+def test_arbitrary_landmark_and_observation_order(ba, oracle, variant, drop):
+    """records and item lists are ordered by track on the device; the caller's order must not matter"""
+    algo = abi.ALGO_GN if variant == abi.VARIANT_PRV_IDP else abi.ALGO_LM
+    p0 = synth.make_window(variant, algo=algo, n_kf=12, n_fixed=2 if variant == abi.VARIANT_SE3_XYZ else 1, n_pt=400, n_obs=2400, seed=41)
+    p = _shuffled(p0, 5, drop_middle=drop)
+    assert any((np.diff(p.obs_kf[p.pt_obs_begin[i]:p.pt_obs_begin[i + 1]]) < 0).any() for i in range(50))   # really unsorted
+    q, r = ba.solve(p)
+    qo, ro = oracle.solve(p)
+    _check(p, q, r, qo, ro)
+    # a batch of the shuffled window and its twins: every code path of the structure build (threaded upload)
+    ba.upload([p] * 9); ba.run(); qs, rs = ba.download()
+    for qq, rr in zip(qs, rs):
+        assert rr.its_done == r.its_done and np.abs(qq.kf_pose - q.kf_pose).max() < 1e-9
+
+
 def test_empty_window_is_refused_with_a_message(ba):
     p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31)
     q = abi.Problem(variant=p.variant, n_kf_free=p.n_kf_free, kf_pose=p.kf_pose, pt=np.zeros((0, 3)), pt_obs_begin=[0], obs_kf=[],
