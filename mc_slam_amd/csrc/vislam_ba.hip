@@ -1027,7 +1027,7 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
             // never starves: one full iteration is always queued behind the one being waited for.
             const int nit = h->max_its[stage];
             std::vector<std::vector<hipEvent_t>> ev(groups.size(), std::vector<hipEvent_t>(nit, nullptr));
-            const bool pace = !h->profile && nit <= 32;
+            const bool pace = nit <= 32;  // also when profiling: the launch counts (and hence the per-launch averages) then equal those of a normal run
             for (auto& g : groups) g.dead = false;
             for (int it = 0; it < nit; it++) {
                 bool any = false;
