@@ -21,7 +21,7 @@ def ba():
     b.close()
 
 
-def _check(p, q, r, qo, ro, tight=True):
+def _check(p, q, r, qo, ro, tight=True, trace_rtol=1e-7):
     assert r.status == ro.status
     assert r.its_done == ro.its_done, (r.its_done, ro.its_done, r.chi2_trace, ro.chi2_trace)
     assert abs(r.chi2_vis - ro.chi2_vis) <= CHI2_RTOL * max(ro.chi2_vis, 1e-12)
@@ -32,8 +32,8 @@ def _check(p, q, r, qo, ro, tight=True):
     assert np.abs(q.kf_vel - qo.kf_vel).max() <= 1e-5
     assert np.abs(q.pt - qo.pt).max() <= 1e-6 * max(1.0, np.abs(qo.pt).max())
     assert (r.obs_outlier == ro.obs_outlier).all()
-    np.testing.assert_allclose(r.chi2_trace, ro.chi2_trace, rtol=1e-7)
-    np.testing.assert_allclose(r.obs_chi2, ro.obs_chi2, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r.chi2_trace, ro.chi2_trace, rtol=trace_rtol)
+    np.testing.assert_allclose(r.obs_chi2, ro.obs_chi2, rtol=max(1e-5, 100 * trace_rtol), atol=1e-7)
     # fixed keyframes never move
     assert (q.kf_pose[p.n_kf_free:] == p.kf_pose[p.n_kf_free:]).all()
 

