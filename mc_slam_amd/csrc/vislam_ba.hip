@@ -640,6 +640,12 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
                 (int)st.item_begin.size() != d.n_pairs + 1 || (int)st.pimu_begin.size() != d.n_pairs + 1 ||
                 (int)st.obs_pt.size() != d.n_obs || (int)st.slot_perm.size() != d.n_obs || (int)st.pt_perm.size() != d.n_pt)
                 return fail(h, "internal: structure sizes");
+            {   // the per-window offsets are 32-bit: refuse a batch that would overflow them instead of wrapping
+                const long long lim = 2147483647LL - 64;
+                if ((long long)obs0 + d.n_obs > lim || (long long)item0 + (long long)(st.items.size() / 2) > lim ||
+                    (long long)tlpair.size() > lim || (long long)tlk.size() > lim || (long long)vec0 + d.nS > lim)
+                    return fail(h, "batch too large for 32-bit offsets: split it into several calls");
+            }
             kf0 += d.n_kf; pt0 += d.n_pt; obs0 += d.n_obs; imu0 += d.n_imu;
             pair0 += d.n_pairs; item0 += (int)(st.items.size() / 2); pimu0 += (int)(st.pimu.size() / 2);
             vec0 += d.nS;
