@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default: 2048 for c2 / c3, 16 for c4, 4 for gba, 4096 frames for pose)")
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default: 4096 for c3, 2048 for c2, 16 for c4, 4 for gba, 4096 frames for pose)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct seeded windows generated per rank (cycled to fill the batch)")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose"],
                     help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, pose = IMU-aided per-frame pose optimisation: extra measurements")
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = {"c2": 2048, "c3": 2048, "c4": 16, "gba": 4, "pose": 4096}[args.workload]
+        args.batch = {"c2": 2048, "c3": 4096, "c4": 16, "gba": 4, "pose": 4096}[args.workload]
 
     import numpy as np
     import torch

@@ -10,6 +10,6 @@ args="$root/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $args > $out.bench_trace.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $args > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $args > /dev/null 2>&1
-python3 $root/scripts/pmc_summary.py $out/trace/*/*_kernel_trace.csv $out/fetch/*/*_counter_collection.csv $out/write/*/*_counter_collection.csv $out.traffic.json 2048
+python3 $root/scripts/pmc_summary.py $out/trace/*/*_kernel_trace.csv $out/fetch/*/*_counter_collection.csv $out/write/*/*_counter_collection.csv $out.traffic.json 4096
 cp $out/trace/*/*_kernel_stats.csv $out.kernel_stats.csv
 rm -rf $out/trace/*/*_kernel_trace.csv $out/fetch $out/write
