@@ -228,6 +228,18 @@ def main():
             cpu = None if n_done == 0 else {"value": n_done / t_cpu, "unit": "windows/s", "cores": 1, "kind": "port",
                    "sample": "%d solves of the same C3 windows, single thread, oracle/libvba_oracle.so (restatement of "
                              "the reference's g2o path, -O3; the reference itself cannot be built here)" % n_done}
+            if cpu is not None and args.workload in ("c2", "c3"):
+                # the same oracle on every host core at once, one window per thread (the reference itself
+                # solves on one thread, src/System.cpp:198; this is the generous reading).  ctypes releases the GIL.
+                from concurrent.futures import ThreadPoolExecutor
+                ncores = max(1, min(os.cpu_count() or 1, 64))
+                per = 2
+                t1 = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=ncores) as ex:
+                    list(ex.map(lambda k: oracle_lib.solve(wins[k % len(wins)], solver_mode=1), range(per * ncores)))
+                t_all = time.perf_counter() - t1
+                cpu["all_cores"] = {"value": per * ncores / t_all, "unit": "windows/s", "cores": ncores,
+                                    "sample": "%d solves, %d threads, one window per thread" % (per * ncores, ncores)}
         out = {
             "metric": {"c3": "LocalBA windows/sec (50 KF, 5k pts, 30k obs, IMU edges)",
                        "c2": "vision-only LocalBundleAdjustment windows/sec (20 KF, 2k pts, 12k obs) [extra measurement]",
