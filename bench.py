@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- LocalBA windows/sec on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (the whole two-stage LocalBAPRVIDP solve, src/Optimizer.cpp:458-517 of
-the reference) over one BATCH of synthetic windows per GPU.  Workload at every N: BASELINE.json configs[2]
-(50 KF = 49 free + fixed predecessor / 5 000 inverse-depth landmarks / 30 000 EdgePRIDP + 49 PRV + 49 bias
-edges, Gauss-Newton 5+10), `--batch` windows per GPU, inputs already resident in HBM when the timed region
-starts (vba_batch_upload before, vba_batch_run timed).  Weak scaling: every rank solves its own batch, no
-data-path collective (windows are independent); torch.distributed (RCCL) only carries the
-barrier and the max-over-ranks time.
+A "step" is one pass of the hot path (the whole two-stage LocalBAPRVIDP solve, src/Optimizer.cpp:458-517 of the
+reference) over one BATCH of synthetic windows per GPU.  Workload at every N: BASELINE.json configs[2] (LocalBAPRVIDP
+window: 50 KF / 5 000 inverse-depth landmarks / 30 000 EdgePRIDP + PRV + bias edges, Gauss-Newton 5+10), `--batch` windows
+per GPU built from `--distinct` seeded windows whose sizes are drawn AROUND that configuration (40..60 keyframes, mean 50;
+`--uniform` = every window exactly 50 / 5 000 / 30 000).
+
+Three figures per run, all on the same batch:
+  value             windows/s with the inputs already resident in HBM when the clock starts (vba_batch_upload before,
+                    K x vba_batch_run timed) -- the bench contract's `value`;
+  value_end_to_end  windows/s of FRESH windows: host arrays in, solved host arrays out (vba_batch_solve = H2D + structure
+                    build + solve + D2H, chunks of the batch in flight concurrently) -- SURVEY 8(d) "copies included";
+  single_window_ms  median latency of one vba_solve (upload + solve + download of ONE window, the way LocalMapping calls
+                    the reference) beside the 1-core CPU oracle on the same window.
+Weak scaling: every rank solves its own batch, no data-path collective (windows are independent);
+torch.distributed (RCCL) only carries the barrier and the max-over-ranks time.  `--gpus N` without torchrun starts the N
+ranks itself (mc_slam_amd/launch.py); under torchrun every process is a rank already.
 
 One JSON line on rank 0, with `roofline` (dominant kernel class, HIP events on the backend's own stream) and
 `cpu_baseline` (the CPU oracle = restatement of the reference's g2o path, 1 core, bounded sample).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,6 +31,33 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def csrc_sha():
+    """hash of the kernel sources: a PMC traffic profile only describes the kernels it was taken from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mc_slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _gen_window(spec):
+    """(workload, seed, uniform) -> Problem; runs in forked worker processes (numpy only, no GPU, no torch)"""
+    from mc_slam_amd import synth
+    wl, seed, uniform = spec
+    if wl == "c3":
+        return synth.config_c3(seed=seed) if uniform else synth.config_c3_ragged(seed=seed)
+    return {"c2": synth.config_c2, "c4": synth.config_c4, "gba": synth.config_gba}[wl](seed=seed)
+
+
+def make_windows(specs, n_proc):
+    if n_proc <= 1 or len(specs) < 4:
+        return [_gen_window(s) for s in specs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(n_proc, len(specs))) as pool:   # forked BEFORE anything touches the GPU
+        return pool.map(_gen_window, specs, chunksize=1)
 
 
 def bench_pose(args, rank, local_rank, world, dist, torch):
@@ -79,27 +116,55 @@ def bench_pose(args, rank, local_rank, world, dist, torch):
         print(json.dumps(out))
 
 
+def matches_oracle(np, sol, res, qo, ro):
+    """BASELINE.json bars: same iteration counts and outlier bitmap, final chi2 <= 1e-4 rel, keyframe translations <= 1e-6 m"""
+    return (ro.its_done == res.its_done and ro.status == res.status and abs(ro.chi2_vis - res.chi2_vis) <= 1e-4 * max(ro.chi2_vis, 1e-300)
+            and (ro.obs_outlier == res.obs_outlier).all() and np.abs(qo.kf_pose[:, :3] - sol.kf_pose[:, :3]).max() <= 1e-6)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default: 4096 for c3, 2048 for c2, 16 for c4, 4 for gba, 4096 frames for pose)")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct seeded windows generated per rank (cycled to fill the batch)")
+    ap.add_argument("--distinct", type=int, default=None, help="distinct seeded windows generated per rank and replicated to fill the batch (default: 256 for c3, 16 for c2, 2 for c4 / gba)")
+    ap.add_argument("--uniform", action="store_true", help="c3: every window exactly 50 KF / 5 000 landmarks / 30 000 edges instead of sizes drawn around it")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose"],
                     help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, pose = IMU-aided per-frame pose optimisation: extra measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--e2e-steps", type=int, default=4, help="timed vba_batch_solve calls over fresh copies of the batch (0: skip)")
+    ap.add_argument("--single-reps", type=int, default=21, help="vba_solve repetitions behind single_window_ms (0: skip)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = {"c2": 2048, "c3": 4096, "c4": 16, "gba": 4, "pose": 4096}[args.workload]
+    if args.distinct is None:
+        args.distinct = {"c2": 16, "c3": 256, "c4": 2, "gba": 2, "pose": 16}[args.workload]
 
-    import numpy as np
-    import torch
+    # `python bench.py --gpus N` (no torchrun): start the N ranks ourselves, before this process touches torch or the GPU
+    from mc_slam_amd import launch
+    if launch.needs_self_launch(args.gpus, os.environ):
+        sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+
+    # synthetic windows; window w of the job belongs to rank w % world, seed 100 + w (BASELINE.md).  Generated by forked
+    # worker processes before torch / HIP are initialised in this one.
+    from mc_slam_amd import shard
+    specs = []
+    if args.workload != "pose":
+        n_distinct = max(1, min(args.distinct, args.batch))
+        specs = [(args.workload, shard.window_seed(g), args.uniform) for g in shard.window_ids(n_distinct * world, rank, world)]
+    n_proc = max(1, min(16, (os.cpu_count() or 1) // max(1, local_world)))
+    wins = make_windows(specs, n_proc)
+
+    import numpy as np
+    import torch
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -116,23 +181,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU path")
     torch.cuda.set_device(local_rank)
 
-    from mc_slam_amd import synth, backend, shard
+    from mc_slam_amd import backend
 
     if args.workload == "pose":
         return bench_pose(args, rank, local_rank, world, dist, torch)
 
-    # synthetic windows of configs[2]; window w of the job belongs to rank w % world, seed 100 + w
-    n_distinct = min(args.distinct, args.batch)
-    gids = shard.window_ids(n_distinct * world, rank, world)
-    make = {"c2": synth.config_c2, "c3": synth.config_c3, "c4": synth.config_c4, "gba": synth.config_gba}[args.workload]
-    if args.workload in ("c4", "gba"):
-        n_distinct = min(n_distinct, 2)
-        gids = gids[:n_distinct]
-    wins = [make(seed=shard.window_seed(g)) for g in gids]
     batch = [wins[i % len(wins)] for i in range(args.batch)]
     ba = backend.LocalBA(local_rank)
     ba.upload(batch)
 
+    # ---- (1) resident: inputs in HBM, K x vba_batch_run ----
     meter = shard.ThroughputMeter(dist, torch.cuda.synchronize)
     for _ in range(args.warmup):
         ba.run()
@@ -142,48 +200,108 @@ def main():
     total_windows, dt = meter.stop(args.batch * args.steps, device="cuda")
     value = total_windows / dt
 
-    # the timed work must be the real work: every window of the last timed run finished both stages, windows built
-    # from the same seed agree bit for bit, and window 0 matches the CPU oracle (chi2 <= 1e-4 rel, translations <= 1e-6 m)
+    # the timed work must be the real work: every window of the last timed run finished both stages, windows built from the
+    # same seed agree bit for bit, and (rank 0) EVERY distinct window matches the CPU oracle
+    def check_twins(sol, res, what):
+        for i, r in enumerate(res):
+            j = i % len(wins)
+            if r.status != 0 or r.its_done[0] < 1 or (min(r.its_done) < 1 and batch[0].protocol == 0) or r.its_done != res[j].its_done \
+                    or r.chi2_vis != res[j].chi2_vis or (sol[i].kf_pose != sol[j].kf_pose).any():
+                raise SystemExit("bench (%s): window %d did not solve like its twin %d: %s vs %s" % (what, i, j, (r.status, r.its_done), res[j].its_done))
     sol, res = ba.download()
-    for i, r in enumerate(res):
-        j = i % len(wins)
-        if r.status != 0 or r.its_done[0] < 1 or (min(r.its_done) < 1 and batch[0].protocol == 0) or r.its_done != res[j].its_done or r.chi2_vis != res[j].chi2_vis:
-            raise SystemExit("bench: window %d did not solve like its twin %d: %s vs %s" % (i, j, (r.status, r.its_done), res[j].its_done))
-    verified = "batch self-consistent"
-    if rank == 0 and not args.no_cpu_baseline:
+    check_twins(sol, res, "resident")
+    verified = "every window finished both stages; replicas agree bit for bit"
+    oracle_res, oracle_ms = None, None
+    full_oracle = args.workload in ("c2", "c3")   # the oracle's dense solve takes minutes at C4 / GBA size: those are pytest property tests
+    if rank == 0 and not args.no_cpu_baseline and full_oracle:
         import oracle_lib
-        if args.workload in ("c4", "gba"):
-            ok = True   # the oracle's dense solve takes minutes at n_p = 2985: full-size C4 parity is a pytest property test
-        else:
-            qo, ro = oracle_lib.solve(wins[0])
-        ok = ok if args.workload in ("c4", "gba") else (ro.its_done == res[0].its_done and abs(ro.chi2_vis - res[0].chi2_vis) <= 1e-4 * ro.chi2_vis
-              and np.abs(qo.kf_pose[:, :3] - sol[0].kf_pose[:, :3]).max() <= 1e-6)
-        if not ok:
-            raise SystemExit("bench: window 0 does not match the CPU oracle")
-        if args.workload not in ("c4", "gba"):
-            verified += "; window 0 == oracle (chi2 1e-4 rel, t 1e-6 m)"
+        from concurrent.futures import ThreadPoolExecutor
+        oracle_lib.lib()
+        nthr = max(1, min(os.cpu_count() or 1, 64) // max(1, local_world))
+
+        def one(w):
+            t1 = time.perf_counter()
+            r = oracle_lib.solve(w)
+            return r, time.perf_counter() - t1
+        with ThreadPoolExecutor(max_workers=nthr) as ex:   # ctypes releases the GIL
+            oracle_res = list(ex.map(one, wins))
+        for i, ((qo, ro), _t) in enumerate(oracle_res):
+            if not matches_oracle(np, sol[i], res[i], qo, ro):
+                raise SystemExit("bench: distinct window %d (seed %d) does not match the CPU oracle: its %s vs %s, chi2 %r vs %r" % (
+                    i, specs[i][1], res[i].its_done, ro.its_done, res[i].chi2_vis, ro.chi2_vis))
+        verified += "; all %d distinct windows == oracle (iterations, outlier bitmap, chi2 1e-4 rel, t 1e-6 m)" % len(wins)
+    its_hist = {}
+    for r in res[:len(wins)]:
+        k = "%d+%d" % tuple(r.its_done)
+        its_hist[k] = its_hist.get(k, 0) + 1
+
+    # ---- (2) end to end: fresh host arrays in, solved host arrays out ----
+    e2e = None
+    if args.e2e_steps > 0:
+        packed = ba.pack(batch)
+        ba.solve_packed(packed)                      # warm-up: lanes, pinned staging and device buffers get allocated
+        tot_e, dt_e = 0, 0.0
+        for _ in range(args.e2e_steps):
+            ba.pack_reset(packed)                    # the solve writes the states in place: the reset stays outside the clock
+            meter.start()
+            ba.solve_packed(packed)
+            n_step, t_step = meter.stop(args.batch, device="cuda")
+            tot_e += n_step
+            dt_e += t_step
+        sol_e, res_e = ba.pack_results(packed)
+        check_twins(sol_e, res_e, "end to end")
+        for i in range(len(wins)):                   # the streamed call must give what upload + run + download gave
+            if res_e[i].its_done != res[i].its_done or res_e[i].chi2_vis != res[i].chi2_vis or (sol_e[i].kf_pose != sol[i].kf_pose).any() \
+                    or (sol_e[i].pt != sol[i].pt).any() or (res_e[i].obs_outlier != res[i].obs_outlier).any():
+                raise SystemExit("bench: vba_batch_solve and upload+run+download disagree on window %d" % i)
+        e2e = {"value": tot_e / dt_e, "unit": "windows/s", "steps": args.e2e_steps, "ms_per_step": dt_e / args.e2e_steps * 1e3,
+               "frac_of_resident": (tot_e / dt_e) / value,
+               "what": "vba_batch_solve on fresh copies of the batch: host packing + H2D + structure build + solve + D2H + scatter, chunks in flight concurrently"}
+        del packed, sol_e, res_e
 
     out = None
     if rank == 0:
-        # roofline of the dominant kernel class: a separate profiled run (HIP events around every launch of the
+        # ---- (3) one window at a time, the way LocalMapping calls the reference (src/LocalMapping.cpp:1026-1037) ----
+        single = None
+        if args.single_reps > 0 and args.workload in ("c2", "c3"):
+            import ctypes as C
+            from mc_slam_amd import abi, synth
+            w1 = synth.config_c3(seed=3) if args.workload == "c3" else wins[0]
+            ba1 = backend.LocalBA(local_rank)
+            ts = []
+            for k in range(args.single_reps + 3):
+                q = w1.copy()
+                s = q.as_struct()
+                rb = abi.ResultBuf(q.n_obs)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                if ba1.lib.vba_solve(ba1.h, C.byref(s), C.byref(rb.s), None) != 0:
+                    raise SystemExit("bench: vba_solve failed")
+                ts.append(time.perf_counter() - t1)
+            ts = sorted(ts[3:])
+            single = {"ms": ts[len(ts) // 2] * 1e3, "min_ms": ts[0] * 1e3, "reps": len(ts),
+                      "what": "median wall time of vba_solve (H2D + structure + two-stage solve + D2H) on one fresh window, BASELINE configs[%d] seed %s" % (
+                          2 if args.workload == "c3" else 1, "3" if args.workload == "c3" else str(specs[0][1]))}
+            if not args.no_cpu_baseline:
+                import oracle_lib
+                t1 = time.perf_counter()
+                qo, ro = oracle_lib.solve(w1)
+                single["cpu_oracle_1core_ms"] = (time.perf_counter() - t1) * 1e3
+                single["speedup_vs_cpu_1core"] = single["cpu_oracle_1core_ms"] / single["ms"]
+                if not matches_oracle(np, q, rb.get(), qo, ro):
+                    raise SystemExit("bench: the single window does not match the CPU oracle")
+            ba1.close()
+
+        # ---- roofline of the dominant kernel class: a separate profiled run (HIP events around every launch of the
         # class, on the backend's stream), never mixed into `value`
         ba.set_profile(True)
         ba.run()
         pf = ba.get_profile()
         ba.set_profile(False)
-        _, res = ba.download()
         classes = {k: v for k, v in pf.items() if k != "total_ms"}
         dom = max(classes, key=lambda k: classes[k]["ms"])
         its = [sum(r.its_done) for r in res]
-        # algorithmic work of the dominant class
-        n_p = (6 if batch[0].variant == 0 else 15) * batch[0].n_kf_free
-        solves = float(sum(its))
-        if dom in ("factor", "trsv", "schur"):
-            # dense FP64 factorisation of the reduced system: n^3/3 flop per solve; its HBM floor is the matrix
-            # read + written once (n_p^2 * 8 B * 2)
-            alg_bytes = solves * 2.0 * n_p * n_p * 8.0
-        else:
-            alg_bytes = classes[dom]["bytes"]
+        alg_bytes = classes[dom]["bytes"]   # algorithmic bytes of the class over the whole run (vba_profile)
         dur_s = classes[dom]["ms"] * 1e-3
         launches = max(1, classes[dom]["launches"])
         achieved = alg_bytes / dur_s / 1e9 if dur_s > 0 else 0.0
@@ -191,21 +309,23 @@ def main():
                     "frac": achieved / 8000.0, "traffic": None,
                     "avg_launch_ms": classes[dom]["ms"] / launches, "launches": launches,
                     "class_ms": {k: round(v["ms"], 4) for k, v in classes.items() if v["launches"]},
+                    "class_frac": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 5) for k, v in classes.items() if v["launches"] and v["ms"] > 0 and v["bytes"] > 0},
                     "profiled_total_ms": pf["total_ms"]}
-        # HBM traffic of the dominant class from the committed rocprofv3 PMC passes (FETCH_SIZE corrected x2 per the
-        # MI355X guide, + WRITE_SIZE), per class launch, when a summary for this batch size exists
+        # HBM traffic of the dominant class from the committed rocprofv3 PMC passes (FETCH_SIZE corrected x2 per the MI355X
+        # guide, + WRITE_SIZE), per class launch -- only when that profile was taken from THESE kernel sources and batch size
         try:
             import glob
-            tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))[-1]
+            tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), key=os.path.getmtime)[-1]
             tr = json.load(open(tj))
-            if tr["batch"] == args.batch:
-                kmap = {"schur": ["k_schur_all", "k_schur_diag", "k_schur_off"], "linearize": ["k_lin2"],
+            if tr.get("batch") == args.batch and tr.get("csrc_sha") == csrc_sha() and tr.get("workload", "c3") == args.workload:
+                kmap = {"schur": ["k_schur_all", "k_schur_diag", "k_schur_off", "k_schur_ref"], "linearize": ["k_lin2", "k_lin_imu"],
                         "factor": ["k_chol_step", "k_chol_panel", "k_chol_update", "k_chol_diag_ll", "k_chol_panel_ll"], "trsv": ["k_trsv"], "update": ["k_update"]}
                 ks = [tr["kernels"][k] for k in kmap.get(dom, []) if k in tr["kernels"]]
-                n_it = tr["kernels"]["k_schur_all" if "k_schur_all" in tr["kernels"] else "k_schur_diag"]["active_launches"]
-                n_cls = tr["kernels"]["k_lin2"]["active_launches"] if dom == "linearize" else n_it
+                n_cls = max(k["active_launches"] for k in ks)
                 roofline["traffic"] = sum((k["fetch_corrected"] + k["write"]) * k["active_launches"] for k in ks) / n_cls
                 roofline["traffic_source"] = os.path.basename(tj)
+            else:
+                roofline["traffic_note"] = "no PMC profile of these kernel sources (csrc %s) at this batch size is committed" % csrc_sha()
         except Exception:
             pass
         # the dense solve (north_star: "MFMA utilisation reported against gfx950 peak"): FP64 flop the factorisation class
@@ -219,18 +339,28 @@ def main():
         if not args.no_cpu_baseline:
             import oracle_lib
             oracle_lib.lib()
-            n_done, t_cpu = 0, 0.0
-            while t_cpu < args.cpu_seconds and n_done < 4 * len(wins) and not (args.workload == "c4" and n_done >= 1) and args.workload != "gba":
-                t1 = time.perf_counter()
-                oracle_lib.solve(wins[n_done % len(wins)], solver_mode=1)
-                t_cpu += time.perf_counter() - t1
-                n_done += 1
-            cpu = None if n_done == 0 else {"value": n_done / t_cpu, "unit": "windows/s", "cores": 1, "kind": "port",
-                   "sample": "%d solves of the same C3 windows, single thread, oracle/libvba_oracle.so (restatement of "
-                             "the reference's g2o path, -O3; the reference itself cannot be built here)" % n_done}
-            if cpu is not None and args.workload in ("c2", "c3"):
+            if oracle_res is not None:
+                # every distinct window was solved by the oracle above (one window per thread); its 1-core rate is measured
+                # on a bounded sample, one solve at a time, nothing else running
+                n_done, t_cpu = 0, 0.0
+                while t_cpu < args.cpu_seconds and n_done < len(wins):
+                    t1 = time.perf_counter()
+                    oracle_lib.solve(wins[n_done], solver_mode=1)
+                    t_cpu += time.perf_counter() - t1
+                    n_done += 1
+            else:
+                n_done, t_cpu = 0, 0.0
+                if args.workload == "c4":
+                    t1 = time.perf_counter()
+                    oracle_lib.solve(wins[0], solver_mode=1)
+                    t_cpu, n_done = time.perf_counter() - t1, 1
+            if n_done:
+                cpu = {"value": n_done / t_cpu, "unit": "windows/s", "cores": 1, "kind": "port",
+                       "sample": "%d solves of the first distinct windows of the batch, single thread, oracle/libvba_oracle.so (restatement of "
+                                 "the reference's g2o path, -O3; the reference itself cannot be built here)" % n_done}
+            if cpu is not None and oracle_res is not None:
                 # the same oracle on every host core at once, one window per thread (the reference itself
-                # solves on one thread, src/System.cpp:198; this is the generous reading).  ctypes releases the GIL.
+                # solves on one thread, src/System.cpp:198; this is the generous reading)
                 from concurrent.futures import ThreadPoolExecutor
                 ncores = max(1, min(os.cpu_count() or 1, 64))
                 per = 2
@@ -240,6 +370,7 @@ def main():
                 t_all = time.perf_counter() - t1
                 cpu["all_cores"] = {"value": per * ncores / t_all, "unit": "windows/s", "cores": ncores,
                                     "sample": "%d solves, %d threads, one window per thread" % (per * ncores, ncores)}
+        rng = lambda f: [int(min(f(w) for w in wins)), int(max(f(w) for w in wins))]
         out = {
             "metric": {"c3": "LocalBA windows/sec (50 KF, 5k pts, 30k obs, IMU edges)",
                        "c2": "vision-only LocalBundleAdjustment windows/sec (20 KF, 2k pts, 12k obs) [extra measurement]",
@@ -249,8 +380,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": {"c3": "BASELINE configs[2]: LocalBAPRVIDP window, 50 KF (49 free) / 5000 IDP landmarks / "
-                                         "30000 EdgePRIDP + 49 PRV + 49 bias edges, GN 5+10",
+            "value_end_to_end": None if e2e is None else e2e["value"],
+            "single_window_ms": None if single is None else single["ms"],
+            "config": {"workload": {"c3": "BASELINE configs[2]: LocalBAPRVIDP windows, 50 KF (49 free + fixed predecessor) / 5000 IDP landmarks / "
+                                          "30000 EdgePRIDP + 49 PRV + 49 bias edges, GN 5+10" + ("" if args.uniform else
+                                          "; sizes drawn per seed around it: 40..60 KF (mean 50), 100 landmarks per KF, 6 edges per landmark"),
                                     "c2": "BASELINE configs[1]: vision-only LocalBundleAdjustment, 20 KF (18 free) / 2000 XYZ landmarks / "
                                           "12000 EdgeSE3ProjectXYZ, LM 5+10",
                                     "c4": "BASELINE configs[3]: synthetic VI graph, 200 KF / 50000 IDP landmarks / 500000 EdgePRIDP + IMU "
@@ -258,8 +392,12 @@ def main():
                                     "gba": "GlobalBundleAdjustmentNavStatePRV, 300 KF / 30000 XYZ landmarks / 180000 EdgeNavStatePRPointXYZ "
                                            "+ IMU chain, LM optimize(10)"}[args.workload],
                        "windows_per_gpu_per_step": args.batch, "distinct_windows": len(wins),
+                       "n_kf_range": rng(lambda w: w.n_kf), "n_pt_range": rng(lambda w: w.n_pt), "n_obs_range": rng(lambda w: w.n_obs),
+                       "mean_n_kf": float(np.mean([w.n_kf for w in batch])), "mean_n_obs": float(np.mean([w.n_obs for w in batch])),
+                       "its_done_histogram": its_hist,
                        "parallelism": "independent windows sharded %d per GPU, no data-path collective" % args.batch,
                        "mean_outer_iterations": float(np.mean(its))},
+            "end_to_end": e2e, "single_window": single,
             "roofline": roofline, "cpu_baseline": cpu, "verified": verified,
         }
     if dist is not None:

@@ -139,6 +139,13 @@ int vba_batch_upload(void *handle, int32_t n_windows, vba_problem *const *proble
 int vba_batch_run(void *handle, const volatile int *stop_flag);
 int vba_batch_download(void *handle, int32_t n_windows, vba_problem *const *inout, vba_result *const *out);
 
+/* Streamed form of the same: n FRESH windows in, n solved windows out (states updated in place, results filled), for callers
+ * that have many independent windows at once (map-server replays, multi-session back-ends).  Equivalent to
+ * upload + run + download of the whole batch, but the call cuts the batch into chunks and keeps several in flight, so the
+ * host packing, the PCIe transfers and the structure build of one chunk overlap the solve of another. */
+int vba_batch_solve(void *handle, int32_t n_windows, vba_problem *const *inout, vba_result *const *out,
+                    const volatile int *stop_flag);
+
 /* On-device IMU preintegration: IMUPreintegrator::update (src/IMU/IMUPreintegrator.cpp:63-112) applied
  * over the samples of n_edges keyframe intervals, the way KeyFrame::ComputePreInt feeds it (src/KeyFrame.cpp:195-252:
  * the caller lists the samples and their dt, including the duplicated first sample).  gyr/acc are bias-corrected

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("VBA_LIB", os.path.join(_HERE, "csrc", "libvislam_ba.s
 _lib = None
 
 EXPORTS = ["vba_create", "vba_destroy", "vba_last_error", "vba_solve", "vba_batch_upload", "vba_batch_run",
-           "vba_batch_download", "vba_preintegrate", "vba_pose_optimize", "vba_problem_save", "vba_problem_load", "vba_problem_free", "vba_set_profile", "vba_get_profile"]
+           "vba_batch_download", "vba_batch_solve", "vba_preintegrate", "vba_pose_optimize", "vba_problem_save", "vba_problem_load", "vba_problem_free", "vba_set_profile", "vba_get_profile"]
 
 
 def load_library():
@@ -35,6 +35,7 @@ def load_library():
     lib.vba_batch_upload.argtypes = [C.c_void_p, C.c_int32, PP]
     lib.vba_batch_run.argtypes = [C.c_void_p, C.c_void_p]
     lib.vba_batch_download.argtypes = [C.c_void_p, C.c_int32, PP, PR]
+    lib.vba_batch_solve.argtypes = [C.c_void_p, C.c_int32, PP, PR, C.c_void_p]
     _pd, _pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     lib.vba_preintegrate.argtypes = [C.c_void_p, C.c_int32, _pi, _pd, _pd, _pd, C.c_double, C.c_double, _pd, _pd, _pd]
     lib.vba_pose_optimize.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(abi.vba_frame_problem)), C.POINTER(C.POINTER(abi.vba_frame_result))]
@@ -108,6 +109,38 @@ class LocalBA:
         if self.lib.vba_batch_download(self.h, n, self._parr, rarr) != 0:
             raise self._err("vba_batch_download")
         return self._probs, [r.get() for r in rbs]
+
+    # ---- fresh windows in, solved windows out (vba_batch_solve: chunks of the batch in flight concurrently) ----
+    def pack(self, probs):
+        """private copies of the windows + the ctypes views vba_batch_solve needs (kept alive by the returned dict)"""
+        n = len(probs)
+        own = [p.copy() for p in probs]
+        structs = [p.as_struct() for p in own]
+        rbs = [abi.ResultBuf(p.n_obs) for p in own]
+        return dict(n=n, src=list(probs), own=own, structs=structs, rbs=rbs,
+                    parr=(C.POINTER(abi.vba_problem) * n)(*[C.pointer(s) for s in structs]),
+                    rarr=(C.POINTER(abi.vba_result) * n)(*[C.pointer(r.s) for r in rbs]))
+
+    @staticmethod
+    def pack_reset(packed):
+        """the solve updates the states in place: put the initial states back (outside any timed region)"""
+        for q, p in zip(packed["own"], packed["src"]):
+            for k in ("kf_pose", "kf_vel", "kf_bias", "pt"):
+                getattr(q, k)[...] = getattr(p, k)
+
+    def solve_packed(self, packed, stop=None):
+        if self.lib.vba_batch_solve(self.h, packed["n"], packed["parr"], packed["rarr"], self._stop_ptr(stop)) != 0:
+            raise self._err("vba_batch_solve")
+
+    @staticmethod
+    def pack_results(packed):
+        return packed["own"], [r.get() for r in packed["rbs"]]
+
+    def solve_batch(self, probs, stop=None):
+        """vba_batch_solve on copies of probs: (solved copies, Results)"""
+        packed = self.pack(probs)
+        self.solve_packed(packed, stop)
+        return self.pack_results(packed)
 
     def preintegrate(self, sample_begin, gyr, acc, dt, want_info=True):
         """vba_preintegrate: (imu_meas [E,61], cov_PVphi [E,9,9], info_PphiV [E,9,9] or None)"""

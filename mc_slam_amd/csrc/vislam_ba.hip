@@ -79,6 +79,60 @@ struct PinnedBuf {   // persistent pinned host staging (grown on demand)
     }
 };
 
+// Growable array in pinned host memory with the few std::vector members the upload / download code uses.  The staging
+// arrays of a handle persist from call to call, so the H2D / D2H copies are true DMA transfers (no pageable bounce
+// buffer) and run concurrently with the kernels of other streams; growth (rare after the first call) re-allocates.
+template <typename T>
+struct PinVec {
+    typedef T value_type;
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    bool ok = true;   // false after a failed allocation (checked once per upload / download)
+    void reserve(size_t want) {
+        if (want <= cap) return;
+        const size_t nc = want + want / 4 + 1024;
+        void* q = nullptr;
+        if (hipHostMalloc(&q, nc * sizeof(T), hipHostMallocDefault) != hipSuccess) { ok = false; return; }
+        if (n) memcpy(q, p, n * sizeof(T));
+        if (p) (void)hipHostFree(p);
+        p = reinterpret_cast<T*>(q);
+        cap = nc;
+    }
+    void resize(size_t m) {
+        reserve(m);
+        if (m <= cap) n = m;
+    }
+    void clear() { n = 0; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = cap = 0;
+    }
+};
+
+// pinned staging of vba_batch_upload (the concatenated arrays of a batch) and vba_batch_download
+struct Staging {
+    PinVec<double> pose, vel, bias, pt, uv, ow, meas, info;
+    PinVec<unsigned char> kffix;
+    PinVec<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
+    PinVec<int> offpair, pairmask, slotperm, ptperm;
+    PinVec<double> dl_pose, dl_vel, dl_bias, dl_pt, dl_chi2;
+    PinVec<unsigned char> dl_outl;
+    template <typename F> void each(F f) {
+        f(pose); f(vel); f(bias); f(pt); f(uv); f(ow); f(meas); f(info); f(kffix);
+        f(ptref); f(ptobs); f(obskf); f(obspt); f(imui); f(imuj); f(pair_a); f(pair_b); f(item_begin); f(items); f(pimu_begin); f(pimu);
+        f(offpair); f(pairmask); f(slotperm); f(ptperm);
+        f(dl_pose); f(dl_vel); f(dl_bias); f(dl_pt); f(dl_chi2); f(dl_outl);
+    }
+    bool ok() { bool r = true; each([&](auto& v) { r = r && v.ok; }); return r; }
+    void release() { each([](auto& v) { v.release(); }); }
+};
+
 enum {
     BUF_DESC, BUF_CTRL, BUF_POSE, BUF_VEL, BUF_BIAS, BUF_KFR, BUF_POSE0, BUF_VEL0, BUF_BIAS0, BUF_POSEBK, BUF_VELBK,
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
@@ -101,8 +155,9 @@ struct Handle {
     DevBuf preint;  // arena of vba_preintegrate
     DevBuf pose_arena;  // arena of vba_pose_optimize
     PinnedBuf pose_host_in, pose_host_out;  // its pinned staging: one H2D and one D2H per call
-    hvec<double> dl_pose, dl_vel, dl_bias, dl_pt, dl_chi2;  // host staging of vba_batch_download: one D2H per array, windows
-    hvec<unsigned char> dl_outl;                            // scattered to the callers' arrays by host threads
+    Staging stg;   // pinned staging: upload arrays; download: one D2H per array, windows scattered to the callers' arrays by host threads
+    std::vector<Handle*> lanes;   // sub-handles of vba_batch_solve (chunks of a large batch in flight concurrently)
+    bool is_lane = false;
     Batch B;
     std::vector<WinDesc> desc;
     std::vector<WinCtrl> hctrl;
@@ -118,6 +173,7 @@ struct Handle {
     volatile int* stop_host = nullptr;  // pinned, device-visible
     int* stop_dev = nullptr;
     bool profile = false;
+    int opt_chunk = 0, opt_lanes = 0;  // > 0: chunk size / lanes of vba_batch_solve (test hook; defaults from VBA_CHUNK, VBA_LANES)
     int opt_streams = 0;  // > 0: window groups / streams for GN batches (test hook; default from VBA_STREAMS, 1)
     std::vector<ProfEvt> evts;
     std::vector<hipEvent_t> evt_pool;
@@ -488,10 +544,13 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->n_win = n;
     h->desc.assign(n, WinDesc());
     h->win_tiles.assign(n, 0);
-    hvec<double> pose, vel, bias, pt, uv, ow, meas, info;
-    hvec<unsigned char> kffix;
-    hvec<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
-    hvec<int> offpair, pairmask, slotperm, ptperm;
+    Staging& G = h->stg;
+    auto &pose = G.pose, &vel = G.vel, &bias = G.bias, &pt = G.pt, &uv = G.uv, &ow = G.ow, &meas = G.meas, &info = G.info;
+    auto& kffix = G.kffix;
+    auto &ptref = G.ptref, &ptobs = G.ptobs, &obskf = G.obskf, &obspt = G.obspt, &imui = G.imui, &imuj = G.imuj, &pair_a = G.pair_a, &pair_b = G.pair_b;
+    auto &item_begin = G.item_begin, &items = G.items, &pimu_begin = G.pimu_begin, &pimu = G.pimu;
+    auto &offpair = G.offpair, &pairmask = G.pairmask, &slotperm = G.slotperm, &ptperm = G.ptperm;
+    G.each([](auto& v) { v.clear(); });
     std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, tlkb, tlk;
     h->step_grid.clear();
     h->pan_grid.clear();
@@ -676,6 +735,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         pair_a.resize(pair0); pair_b.resize(pair0); offpair.resize(pair0); pairmask.resize(pair0);
         item_begin.resize((size_t)pair0 + nw); pimu_begin.resize((size_t)pair0 + nw);
         items.resize(2 * (size_t)item0); pimu.resize(2 * (size_t)pimu0);
+        if (!G.ok()) return fail(h, "out of pinned host memory (upload staging)");
         // (4)
         run_pool(cn, [&](int q) {
             const int w = chunk0 + q;
@@ -1108,6 +1168,8 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     // LM (C2 windows, 1 / 2 / 4 groups): 256 windows 5.9k / 6.2k / 6.5k, 2048: 6.4k / 6.6k / 6.8k.
     static const int env_streams = getenv("VBA_STREAMS") ? atoi(getenv("VBA_STREAMS")) : 0;
     int want = h->opt_streams > 0 ? h->opt_streams : env_streams;
+    static const int lane_streams = getenv("VBA_LANE_STREAMS") ? atoi(getenv("VBA_LANE_STREAMS")) : 2;
+    if (want <= 0 && h->is_lane) want = lane_streams;   // several lanes share the chip: fewer window groups each
     if (want <= 0) want = (n >= 2048 && h->algo == VBA_ALGO_GN) ? 2 : (n >= 64) ? 4 : (n >= 16) ? 2 : 1;   // default policy (16..48 windows: 2 groups +5..10 %, 4 groups -40 %)
     const int max_streams = std::min(14, want);
     int ngroups = 1;
@@ -1179,8 +1241,12 @@ int do_run(Handle* h, const volatile int* stop_flag) {
             for (int s = 0; s < 2; s++)
                 if (c.its_done[s] > 0) { passes += c.its_done[s] + 1; solves += c.its_done[s]; }
             pf.bytes[VBA_PROF_LINEARIZE] += passes * (32.0 * d.n_obs + 36.0 * d.n_pt + 432.0 * d.n_free);
+            // reduced system ("write n_p^2 8 B + read once by solver"): the Schur class writes S once, the factorisation
+            // reads S and writes L once, the two triangular solves read L once each (half the square each)
             pf.bytes[VBA_PROF_SCHUR] += solves * ((double)d.np * d.np * 8.0);
-            pf.bytes[VBA_PROF_FACTOR] += solves * ((double)d.np * d.np * 8.0);
+            pf.bytes[VBA_PROF_FACTOR] += solves * ((double)d.np * d.np * 8.0 * 2.0);
+            pf.bytes[VBA_PROF_TRSV] += solves * ((double)d.np * d.np * 8.0);
+            pf.bytes[VBA_PROF_UPDATE] += solves * (36.0 * d.n_pt + 432.0 * d.n_free);   // per point 28 B read + 8 B write, per free KF 432 B
             pf.factor_flops += solves * h->win_tiles[w] * (2.0 * VBA_NB * VBA_NB * VBA_NB);
         }
     }
@@ -1205,24 +1271,23 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
         }
         const WinDesc& dl = h->desc[n - 1];
         const size_t nkf = (size_t)dl.kf0 + dl.n_kf, npt = (size_t)dl.pt0 + dl.n_pt, nobs = (size_t)dl.obs0 + dl.n_obs;
+        const bool vi = h->variant != VBA_VARIANT_SE3_XYZ;
+        Staging& G = h->stg;
+        if (want_state) { G.dl_pose.resize(7 * nkf); G.dl_pt.resize(3 * npt); }
+        if (want_state && vi) { G.dl_vel.resize(3 * nkf); G.dl_bias.resize(12 * nkf); }
+        if (want_outl) G.dl_outl.resize(nobs);
+        if (want_chi2) G.dl_chi2.resize(nobs);
+        if (!G.ok()) return fail(h, "out of pinned host memory (download staging)");
         if (want_state) {
-            h->dl_pose.resize(7 * nkf); h->dl_pt.resize(3 * npt);
-            HIPCHK(h, hipMemcpyAsync(h->dl_pose.data(), B.pose, 56 * nkf, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(h->dl_pt.data(), B.pt, 24 * npt, hipMemcpyDeviceToHost, h->stream));
-            if (h->variant != VBA_VARIANT_SE3_XYZ) {
-                h->dl_vel.resize(3 * nkf); h->dl_bias.resize(12 * nkf);
-                HIPCHK(h, hipMemcpyAsync(h->dl_vel.data(), B.vel, 24 * nkf, hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(h, hipMemcpyAsync(h->dl_bias.data(), B.bias, 96 * nkf, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(G.dl_pose.data(), B.pose, 56 * nkf, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(G.dl_pt.data(), B.pt, 24 * npt, hipMemcpyDeviceToHost, h->stream));
+            if (vi) {
+                HIPCHK(h, hipMemcpyAsync(G.dl_vel.data(), B.vel, 24 * nkf, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipMemcpyAsync(G.dl_bias.data(), B.bias, 96 * nkf, hipMemcpyDeviceToHost, h->stream));
             }
         }
-        if (want_outl) {
-            h->dl_outl.resize(nobs);
-            HIPCHK(h, hipMemcpyAsync(h->dl_outl.data(), B.out_outlier, nobs, hipMemcpyDeviceToHost, h->stream));
-        }
-        if (want_chi2) {
-            h->dl_chi2.resize(nobs);
-            HIPCHK(h, hipMemcpyAsync(h->dl_chi2.data(), B.out_chi2, 8 * nobs, hipMemcpyDeviceToHost, h->stream));
-        }
+        if (want_outl) HIPCHK(h, hipMemcpyAsync(G.dl_outl.data(), B.out_outlier, nobs, hipMemcpyDeviceToHost, h->stream));
+        if (want_chi2) HIPCHK(h, hipMemcpyAsync(G.dl_chi2.data(), B.out_chi2, 8 * nobs, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     std::atomic<int> next(0), bad(0);
@@ -1238,12 +1303,12 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
                 else if (hipMemcpy(dst, dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) bad.store(1);
             };
             if (P && c.status != VBA_ABORTED_BEFORE) {
-                get(P->kf_pose, B.pose + 7 * (size_t)d.kf0, h->dl_pose.data() + 7 * (size_t)d.kf0, 56 * (size_t)d.n_free);
+                get(P->kf_pose, B.pose + 7 * (size_t)d.kf0, h->stg.dl_pose.data() + 7 * (size_t)d.kf0, 56 * (size_t)d.n_free);
                 if (d.pdim == 15) {
-                    if (P->kf_vel) get(P->kf_vel, B.vel + 3 * (size_t)d.kf0, h->dl_vel.data() + 3 * (size_t)d.kf0, 24 * (size_t)d.n_free);
-                    if (P->kf_bias) get(P->kf_bias, B.bias + 12 * (size_t)d.kf0, h->dl_bias.data() + 12 * (size_t)d.kf0, 96 * (size_t)d.n_free);
+                    if (P->kf_vel) get(P->kf_vel, B.vel + 3 * (size_t)d.kf0, h->stg.dl_vel.data() + 3 * (size_t)d.kf0, 24 * (size_t)d.n_free);
+                    if (P->kf_bias) get(P->kf_bias, B.bias + 12 * (size_t)d.kf0, h->stg.dl_bias.data() + 12 * (size_t)d.kf0, 96 * (size_t)d.n_free);
                 }
-                get(P->pt, B.pt + 3 * (size_t)d.pt0, h->dl_pt.data() + 3 * (size_t)d.pt0, 24 * (size_t)d.n_pt);
+                get(P->pt, B.pt + 3 * (size_t)d.pt0, h->stg.dl_pt.data() + 3 * (size_t)d.pt0, 24 * (size_t)d.n_pt);
             }
             if (R) {
                 R->chi2_vis = c.chi2_vis; R->chi2_prv = c.chi2_prv; R->chi2_bias = c.chi2_bias;
@@ -1253,8 +1318,8 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
                 for (int i = 0; i < c.n_trace && i < VBA_TRACE_MAX; i++) R->chi2_trace[i] = c.trace[i];
                 R->lambda_final = c.lambda;
                 if (c.status != VBA_ABORTED_BEFORE && d.n_obs) {
-                    if (R->obs_outlier) get(R->obs_outlier, B.out_outlier + d.obs0, h->dl_outl.data() + d.obs0, (size_t)d.n_obs);
-                    if (R->obs_chi2) get(R->obs_chi2, B.out_chi2 + d.obs0, h->dl_chi2.data() + d.obs0, 8 * (size_t)d.n_obs);
+                    if (R->obs_outlier) get(R->obs_outlier, B.out_outlier + d.obs0, h->stg.dl_outl.data() + d.obs0, (size_t)d.n_obs);
+                    if (R->obs_chi2) get(R->obs_chi2, B.out_chi2 + d.obs0, h->stg.dl_chi2.data() + d.obs0, 8 * (size_t)d.n_obs);
                 }
             }
         }
@@ -1311,8 +1376,11 @@ int vba_create(int device, void** handle) {
 int vba_destroy(void* handle) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
+    for (Handle* l : h->lanes) (void)vba_destroy(l);
+    h->lanes.clear();
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    h->stg.release();
     for (auto& b : h->buf) b.release();
     h->preint.release();
     h->pose_arena.release();
@@ -1364,6 +1432,51 @@ int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile 
     return do_download(h, 1, ps, rs);
 }
 
+// Fresh windows in, solved windows out: the batch is cut into chunks and several chunks are in flight at once, each on its
+// own lane (a sub-handle with its own streams, device buffers and pinned staging), so that the host-side packing, the H2D
+// transfer and the structure build of chunk k+1 and the D2H + scatter of chunk k-1 run while chunk k is being solved.
+// Windows are independent (one function-local optimiser per call in the reference, src/Optimizer.cpp:130): results do not
+// depend on the chunking (same kernels, same summation orders).
+int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_result* const* out, const volatile int* stop_flag) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    if (n <= 0 || !inout) return fail(h, "vba_batch_solve: bad arguments");
+    static const int env_lanes = getenv("VBA_LANES") ? atoi(getenv("VBA_LANES")) : 3;
+    static const int env_chunk = getenv("VBA_CHUNK") ? atoi(getenv("VBA_CHUNK")) : 512;
+    const int chunk_max = std::max(1, h->opt_chunk > 0 ? h->opt_chunk : env_chunk);
+    const int n_chunks = (n + chunk_max - 1) / chunk_max;
+    const int n_lanes = std::max(1, std::min(h->opt_lanes > 0 ? h->opt_lanes : env_lanes, n_chunks));
+    if (n_chunks == 1) {
+        if (do_upload(h, n, inout) || do_run(h, stop_flag)) return -1;
+        return do_download(h, n, inout, out);
+    }
+    while ((int)h->lanes.size() < n_lanes) {
+        void* l = nullptr;
+        if (vba_create(h->device, &l) != 0) return fail(h, "vba_batch_solve: could not create a lane");
+        reinterpret_cast<Handle*>(l)->is_lane = true;
+        h->lanes.push_back(reinterpret_cast<Handle*>(l));
+    }
+    const int chunk = (n + n_chunks - 1) / n_chunks;   // balanced: no tiny tail chunk
+    std::atomic<int> next(0), bad(0);
+    std::mutex mu;
+    auto work = [&](Handle* lane) {
+        for (int c = next.fetch_add(1); c < n_chunks && !bad.load(); c = next.fetch_add(1)) {
+            const int w0 = c * chunk, cn = std::min(chunk, n - w0);
+            if (cn <= 0) break;
+            if (do_upload(lane, cn, inout + w0) || do_run(lane, stop_flag) || do_download(lane, cn, inout + w0, out ? out + w0 : nullptr)) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!bad.exchange(1)) h->err = "vba_batch_solve, windows " + std::to_string(w0) + ".." + std::to_string(w0 + cn - 1) + ": " + lane->err;
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int l = 1; l < n_lanes; l++) pool.emplace_back(work, h->lanes[l]);
+    work(h->lanes[0]);
+    for (auto& t : pool) t.join();
+    return bad.load() ? -1 : 0;
+}
+
 // test/debug hook (not part of include/vislam_ba.h): raw copy out of one device buffer of the last batch
 int vba_debug_copy(void* handle, int32_t buf_id, uint64_t offset_bytes, void* dst, uint64_t nbytes) {
     Handle* h = reinterpret_cast<Handle*>(handle);
@@ -1375,6 +1488,13 @@ int vba_debug_set_streams(void* handle, int32_t n) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
     h->opt_streams = n;
+    return 0;
+}
+int vba_debug_set_chunking(void* handle, int32_t chunk, int32_t lanes) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    h->opt_chunk = chunk;
+    h->opt_lanes = lanes;
     return 0;
 }
 int vba_debug_buf_id(const char* name) {

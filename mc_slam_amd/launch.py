@@ -1,0 +1,79 @@
+"""Self-launcher of the one-process-per-GPU job: `bench.py --gpus N` without torchrun.
+
+Windows are sharded one rank per GPU (mc_slam_amd/shard.py); this module only starts the ranks.  The parent
+process never touches the GPU (no torch.cuda / HIP call, it does not even import torch): it spawns N children
+with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank 0's stdout (the JSON line),
+forwards the children's stderr, and exits non-zero when any child fails.  No process is ever re-exec'd.
+"""
+import os
+import socket
+import subprocess
+import sys
+import threading
+import time
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rank_env(base_env, rank: int, world: int, port: int):
+    """environment of child `rank`: what torch.distributed.run would set on one node"""
+    env = dict(base_env)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+    return env
+
+
+def needs_self_launch(n_gpus: int, env) -> bool:
+    """True when this process was started plainly (`python bench.py --gpus N`, N > 1) and must start the ranks itself;
+    under torchrun (WORLD_SIZE set) every process already is a rank."""
+    return n_gpus > 1 and "WORLD_SIZE" not in env
+
+
+def spawn_ranks(n: int, argv, env=None, out=None, err=None, poll_s: float = 0.05) -> int:
+    """Start `n` ranks of `argv` (a full command line), wait for all of them, relay rank 0's stdout to `out` and every
+    rank's stderr to `err`.  Returns 0 when every rank exited 0, otherwise the first non-zero exit code; as soon as one
+    rank fails the others are terminated (they would otherwise wait in a collective for ever)."""
+    env = os.environ if env is None else env
+    out = sys.stdout if out is None else out
+    err = sys.stderr if err is None else err
+    port = free_port()
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(list(argv), env=rank_env(env, r, n, port), stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=subprocess.PIPE, text=True))
+    lock = threading.Lock()
+
+    def pump(stream, sink, prefix):
+        for line in stream:
+            with lock:
+                sink.write(prefix + line)
+                sink.flush()
+
+    pumps = [threading.Thread(target=pump, args=(procs[0].stdout, out, ""), daemon=True)]
+    pumps += [threading.Thread(target=pump, args=(p.stderr, err, "[rank %d] " % r), daemon=True) for r, p in enumerate(procs)]
+    for t in pumps:
+        t.start()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:          # exactly the children started above, by PID
+                    procs[q].terminate()
+        if alive:
+            time.sleep(poll_s)
+    for t in pumps:
+        t.join(timeout=5)
+    return rc

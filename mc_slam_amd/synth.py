@@ -154,13 +154,14 @@ def prv_information(cov_pvphi):
 
 # ---------------------------------------------------------------- the generator
 def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_obs=30000, seed=3,
-                kf_dt=0.25, imu_dt=0.005, outlier_frac=0.05, algo=None, noise=True):
+                kf_dt=0.25, imu_dt=0.005, outlier_frac=0.05, algo=None, noise=True, init_scale=1.0):
     """Build one synthetic local-BA window.
 
     n_kf keyframes in time order t0..; the FIRST n_fixed in time are fixed (the window's predecessor and,
     if n_fixed > 1, older co-observers).  In the returned Problem free keyframes come first (time order),
     fixed ones after.  n_obs counts reprojection EDGES (variant 2: the reference keyframe's own
-    observation is not an edge, src/Optimizer.cpp:395-398).
+    observation is not an edge, src/Optimizer.cpp:395-398).  init_scale multiplies the perturbation of the initial
+    guess (poses, velocities, depths / points): < 1 = a window that starts close to its optimum.
     """
     rng = np.random.default_rng(seed)
     R_bc, p_bc, T_cb = extrinsics()
@@ -288,11 +289,11 @@ def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_ob
         outlier_frac = 0.0   # the reference observation defines the bearing: noisy but never a gross outlier
         uvr, _w, _o, depth = measure(np.arange(n_pt), ref_tk)
         outlier_frac = _of
-        depth0 = depth * (1 + (rng.normal(0, 0.03, n_pt) if noise else 0.0))
+        depth0 = depth * (1 + (init_scale * rng.normal(0, 0.03, n_pt) if noise else 0.0))
         pt_arr = np.stack([1.0 / depth0, (uvr[:, 0] - cx) / fx, (uvr[:, 1] - cy) / fy], axis=1)
         pt_ref = pidx[ref_tk]
     else:
-        pt_arr = pts_w + (rng.normal(0, 0.05, (n_pt, 3)) if noise else 0)
+        pt_arr = pts_w + (init_scale * rng.normal(0, 0.05, (n_pt, 3)) if noise else 0)
         if variant == abi.VARIANT_SE3_XYZ:
             pt_arr = np.float32(pt_arr).astype(np.float64)
         pt_ref = np.zeros(n_pt, dtype=np.int64)
@@ -309,9 +310,9 @@ def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_ob
         else:
             pose_gt[i] = np.concatenate([Pk, rot_to_quat(Rk)])
         if i < n_free and noise:
-            Rn = Rk @ so3_exp(rng.normal(0, np.deg2rad(0.5), 3))
-            Pn = Pk + rng.normal(0, 0.02, 3)
-            Vn = Vk + rng.normal(0, 0.05, 3)
+            Rn = Rk @ so3_exp(init_scale * rng.normal(0, np.deg2rad(0.5), 3))
+            Pn = Pk + init_scale * rng.normal(0, 0.02, 3)
+            Vn = Vk + init_scale * rng.normal(0, 0.05, 3)
         else:
             Rn, Pn, Vn = Rk, Pk, Vk
         if variant == abi.VARIANT_SE3_XYZ:
@@ -368,6 +369,16 @@ def config_c2(seed=2):
 def config_c3(seed=3, n_kf=50, n_pt=5000, n_obs=30000):
     """LocalBAPRVIDP: 50 KF (49 free + fixed predecessor) / 5k pts / 30k EdgePRIDP + 49 PRV + 49 bias, GN."""
     return make_window(abi.VARIANT_PRV_IDP, n_kf=n_kf, n_fixed=1, n_pt=n_pt, n_obs=n_obs, seed=seed)
+
+
+def config_c3_ragged(seed=3):
+    """A LocalBAPRVIDP window whose size is drawn around BASELINE configs[2]: 40..60 keyframes (mean 50), 100 landmarks per
+    keyframe, 6 edges per landmark (mean 5 000 / 30 000), 2..8 % gross outliers -- so that the windows of a batch differ in
+    size, co-visibility and iteration counts the way the windows of a real session do (the sizes depend on the seed only)."""
+    r = np.random.default_rng(1000003 * seed + 17)
+    n_kf = int(r.integers(40, 61))
+    return make_window(abi.VARIANT_PRV_IDP, n_kf=n_kf, n_fixed=1, n_pt=100 * n_kf, n_obs=600 * n_kf, seed=seed,
+                       outlier_frac=float(r.uniform(0.02, 0.08)))
 
 
 def config_c4(seed=4):

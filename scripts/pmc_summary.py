@@ -25,11 +25,21 @@ def per_kernel(path, value_key):
     return d
 
 
-def main(trace_csv, fetch_csv, write_csv, out_json, batch):
+def csrc_sha():
+    import hashlib, os
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mc_slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main(trace_csv, fetch_csv, write_csv, out_json, batch, workload="c3"):
     dur = per_kernel(trace_csv, "dur")
     fe = per_kernel(fetch_csv, "ctr")
     wr = per_kernel(write_csv, "ctr")
-    out = {"batch": int(batch), "unit": "bytes per launch (active launches)", "kernels": {}}
+    out = {"batch": int(batch), "workload": workload, "csrc_sha": csrc_sha(), "unit": "bytes per launch (active launches)", "kernels": {}}
     for k, v in dur.items():
         if not k.startswith("k_"):
             continue
@@ -47,4 +57,4 @@ def main(trace_csv, fetch_csv, write_csv, out_json, batch):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])

@@ -216,6 +216,38 @@ def test_window_groups_on_several_streams_give_identical_results(ba, variant):
             assert (a.kf_pose == b.kf_pose).all() and (a.pt == b.pt).all() and ra.chi2_vis == rb.chi2_vis
 
 
+@pytest.mark.parametrize("variant", [abi.VARIANT_PRV_IDP, abi.VARIANT_SE3_XYZ])
+def test_batch_solve_streams_fresh_windows_like_upload_run_download(ba, oracle, variant):
+    """vba_batch_solve (fresh host arrays in, solved ones out, chunks of the batch on concurrent lanes) gives every window
+    bit for bit what upload + run + download of the whole batch gives, whatever the chunking; and the oracle's result"""
+    kw = dict(n_fixed=1) if variant == abi.VARIANT_PRV_IDP else dict(n_fixed=2)
+    ps = [synth.make_window(variant, n_kf=7 + (i % 4), n_pt=120 + 15 * (i % 6), n_obs=600 + 70 * (i % 6), seed=300 + i % 6, **kw)
+          for i in range(29)]
+    ba.upload(ps); ba.run(); q0, r0 = ba.download()
+    q0 = [x.copy() for x in q0]
+    try:
+        for chunk, lanes in ((1000, 1), (10, 3), (4, 2), (7, 1)):
+            ba.lib.vba_debug_set_chunking(ba.h, chunk, lanes)
+            q, r = ba.solve_batch(ps)
+            for a, b, ra, rb in zip(q0, q, r0, r):
+                assert ra.status == rb.status == 0 and ra.its_done == rb.its_done and ra.chi2_vis == rb.chi2_vis
+                assert (a.kf_pose == b.kf_pose).all() and (a.pt == b.pt).all() and (a.kf_vel == b.kf_vel).all()
+                assert (ra.obs_outlier == rb.obs_outlier).all() and (ra.obs_chi2 == rb.obs_chi2).all()
+    finally:
+        ba.lib.vba_debug_set_chunking(ba.h, 0, 0)
+    for i in range(6):
+        qo, ro = oracle.solve(ps[i])
+        _check(ps[i], q[i], r[i], qo, ro)
+    # the inputs were not touched (solve_batch works on copies), and a bad window fails the call with a message
+    bad = ps[3].copy(); bad.obs_kf = bad.obs_kf.copy(); bad.obs_kf[5] = 99
+    ba.lib.vba_debug_set_chunking(ba.h, 4, 2)
+    try:
+        with pytest.raises(RuntimeError, match="vba_batch_solve"):
+            ba.solve_batch(ps[:9] + [bad] + ps[:3])
+    finally:
+        ba.lib.vba_debug_set_chunking(ba.h, 0, 0)
+
+
 def test_rerun_is_bit_reproducible(ba):
     p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=10, n_fixed=1, n_pt=400, n_obs=2000, seed=7)
     ba.upload([p]); ba.run(); q1, r1 = ba.download()
