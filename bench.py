@@ -309,7 +309,8 @@ def main():
                     "frac": achieved / 8000.0, "traffic": None,
                     "avg_launch_ms": classes[dom]["ms"] / launches, "launches": launches,
                     "class_ms": {k: round(v["ms"], 4) for k, v in classes.items() if v["launches"]},
-                    "class_frac": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 5) for k, v in classes.items() if v["launches"] and v["ms"] > 0 and v["bytes"] > 0},
+                    "class_frac": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 5) for k, v in classes.items()
+                                   if k in ("linearize", "schur", "factor", "update") and v["launches"] and v["ms"] > 0 and v["bytes"] > 0},
                     "profiled_total_ms": pf["total_ms"]}
         # HBM traffic of the dominant class from the committed rocprofv3 PMC passes (FETCH_SIZE corrected x2 per the MI355X
         # guide, + WRITE_SIZE), per class launch -- only when that profile was taken from THESE kernel sources and batch size

@@ -364,6 +364,19 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
 #define LIN2_PS 19   // LDS row stride of one landmark: dd, y(3), Xw(3), N0(9), ref_free, sD, beta
 #define LIN2_LDS ((256 * LIN2_ES + 64 * LIN2_PS + 4) * 8)   // 40 480 B: four workgroups per CU
 
+// The IMU factors of the inverse-depth windows: one wave per keyframe pair, in its own launch right behind k_lin2 (same stream)
+// -- inlined into k_lin2 its ~60 live doubles of Lie algebra set the register budget of the 130x more numerous edge workgroups.
+__global__ void __launch_bounds__(64) k_lin_imu(Batch B, int mode) {
+    __shared__ double sm[672];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;
+    const int k = blockIdx.x;
+    if (k >= d.n_imu) return;
+    lin_imu(B, d, k, mode, sm);
+}
+
 __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode) {
     extern __shared__ double lsm[];
     double* ER = lsm;                       // 256 x LIN2_ES
@@ -374,13 +387,6 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
     const WinCtrl& c = B.ctrl[w];
     if (!c.active) return;
     const int t = threadIdx.x;
-    if ((int)blockIdx.x >= nblk_lin) {
-        const int k = blockIdx.x - nblk_lin;
-        if (k >= d.n_imu) return;
-        if (t >= 64) return;  // one wave per IMU pair; the barriers inside lin_imu then only see this wave
-        lin_imu(B, d, k, mode, lsm);
-        return;
-    }
     const int lb = blockIdx.x;
     if (lb >= d.n_part_lin) return;
     const int4 run = reinterpret_cast<const int4*>(B.lin_blk)[d.lb0 + lb];  // one load instead of the chain table -> CSR

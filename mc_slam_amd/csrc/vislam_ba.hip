@@ -928,7 +928,8 @@ void enqueue_lin(Handle* h, int mode) {
     ProfScope ps(h, VBA_PROF_LINEARIZE);
     if (h->variant == VBA_VARIANT_PRV_IDP) {
         const size_t shm = LIN2_LDS;
-        hipLaunchKernelGGL(k_lin2, dim3(h->max_lin_blk + h->max_imu, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
+        hipLaunchKernelGGL(k_lin2, dim3(h->max_lin_blk, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
+        if (h->max_imu > 0) hipLaunchKernelGGL(k_lin_imu, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, mode);
     }
     else
         hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk + h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
@@ -1435,8 +1436,10 @@ int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile 
 // Fresh windows in, solved windows out: the batch is cut into chunks and several chunks are in flight at once, each on its
 // own lane (a sub-handle with its own streams, device buffers and pinned staging), so that the host-side packing, the H2D
 // transfer and the structure build of chunk k+1 and the D2H + scatter of chunk k-1 run while chunk k is being solved.
-// Windows are independent (one function-local optimiser per call in the reference, src/Optimizer.cpp:130): results do not
-// depend on the chunking (same kernels, same summation orders).
+// Windows are independent (one function-local optimiser per call in the reference, src/Optimizer.cpp:130).  A chunk runs the
+// kernels a batch of its size runs (the choice depends on the window count: thresholds 8 / 64 / 256), so chunks of the
+// default size give bit for bit what one big upload + run + download gives; across a threshold the sums run in another
+// fixed order and the results agree to rounding.
 int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_result* const* out, const volatile int* stop_flag) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;

@@ -502,6 +502,121 @@ void vbo_edge_bias_error(const double *biasi, const double *biasj, double *err) 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * A6  EdgeNavState (15-D, two VertexNavState), src/IMU/g2otypes.cpp:989-1168, and VertexNavState::oplusImpl
+ *     (:961-966 -> NavState::IncSmall, src/IMU/NavState.cpp:31-59).  The reference no longer instantiates this
+ *     edge (LocalMapping calls the PR/V/Bias-split optimisers); it is restated so that the split factor the backend
+ *     fuses (A2 EdgeNavStatePRV + A3 EdgeNavStateBias) can be checked against the 15-D factor it was derived from
+ *     (SURVEY 8c item 5).  Written from the cited lines, sharing no code with A2/A3 above.
+ *   nav (22): P(3) q(4, xyzw) V(3) bg(3) ba(3) dbg(3) dba(3)        src/IMU/NavState.h:124-138
+ *   err (15): rP, rV, rPhi, rBiasG, rBiasA                          :1040-1046
+ *   Ji, Jj (15x15 row-major), columns P V Phi dBg dBa               :1085-1166
+ * ---------------------------------------------------------------------------------------------- */
+void vbo_edge_navstate_error(const double *navi, const double *navj, const double *meas, const double *g, double *err) {
+    const double *Pi = navi, *Vi = navi + 7, *dBgi = navi + 16, *dBai = navi + 19;   /* :995-1000 */
+    const double *Pj = navj, *Vj = navj + 7;                                        /* :1003-1006 */
+    const double dTij = meas[0], dT2 = dTij * dTij;                                 /* :1010-1011 */
+    const double *dPij = meas + 1, *dVij = meas + 4;
+    double dRij[4];
+    R_to_quat(meas + 7, dRij);   /* Sophus::SO3(M.getDeltaR()), :1014 */
+    quat_normalize(dRij);
+    double RiT[4];
+    so3_inv(navi + 3, RiT);      /* :1016 */
+    double a[3], ra[3], t1[3], t2[3];
+    for (int k = 0; k < 3; k++) a[k] = Pj[k] - Pi[k] - Vi[k] * dTij - 0.5 * g[k] * dT2;
+    quat_rot(RiT, a, ra);
+    m3_vec(meas + 16, dBgi, t1);   /* JPBiasg */
+    m3_vec(meas + 25, dBai, t2);   /* JPBiasa */
+    for (int k = 0; k < 3; k++) err[k] = ra[k] - (dPij[k] + t1[k] + t2[k]);       /* rPij :1020-1021 */
+    for (int k = 0; k < 3; k++) a[k] = Vj[k] - Vi[k] - g[k] * dTij;
+    quat_rot(RiT, a, ra);
+    m3_vec(meas + 34, dBgi, t1);   /* JVBiasg */
+    m3_vec(meas + 43, dBai, t2);   /* JVBiasa */
+    for (int k = 0; k < 3; k++) err[3 + k] = ra[k] - (dVij[k] + t1[k] + t2[k]);   /* rVij :1024-1025 */
+    double w[3], dR_dbg[4], prod[4], inv[4], u[4], rR[4];
+    m3_vec(meas + 52, dBgi, w);    /* JRBiasg dBgi */
+    vbo_so3_exp(w, dR_dbg);        /* :1028 */
+    so3_mul(dRij, dR_dbg, prod);
+    so3_inv(prod, inv);
+    so3_mul(inv, RiT, u);
+    so3_mul(u, navj + 3, rR);      /* :1029 */
+    vbo_so3_log(rR, err + 6);      /* :1030 */
+    for (int k = 0; k < 3; k++) {
+        err[9 + k] = (navj[10 + k] + navj[16 + k]) - (navi[10 + k] + navi[16 + k]);    /* rBiasG :1033-1034 */
+        err[12 + k] = (navj[13 + k] + navj[19 + k]) - (navi[13 + k] + navi[19 + k]);   /* rBiasA :1037-1038 */
+    }
+}
+
+void vbo_edge_navstate_jac(const double *navi, const double *navj, const double *meas, const double *g, const double *err,
+                           double *Ji, double *Jj) {
+    const double *Pi = navi, *Vi = navi + 7, *dBgi = navi + 16;   /* :1062-1066 */
+    const double *Pj = navj, *Vj = navj + 7;                      /* :1069-1072 */
+    double Ri[9], Rj[9], RiT[9], RjT[9];
+    quat_to_R(navi + 3, Ri);
+    quat_to_R(navj + 3, Rj);
+    m3_T(Ri, RiT);
+    m3_T(Rj, RjT);
+    const double dTij = meas[0], dT2 = dTij * dTij;   /* :1076-1077 */
+    const double *rPhiij = err + 6;                   /* :1083 */
+    double JrInv_rPhi[9];
+    vbo_so3_jrinv(rPhiij, JrInv_rPhi);                /* :1084 */
+    const double *J_rPhi_dbg = meas + 52;             /* :1085 */
+    memset(Ji, 0, 225 * sizeof(double));
+    memset(Jj, 0, 225 * sizeof(double));
+#define BLK(J, r0, c0, M, sgn)                                                          \
+    for (int _r = 0; _r < 3; _r++)                                                      \
+        for (int _c = 0; _c < 3; _c++) (J)[((r0) + _r) * 15 + (c0) + _c] = (sgn) * (M)[3 * _r + _c];
+    double a[3], ra[3], H[9], T1[9], T2[9];
+    /* vertex 0: rows rP :1091-1096 */
+    BLK(Ji, 0, 0, RiT, -1.0);
+    BLK(Ji, 0, 3, RiT, -dTij);
+    for (int k = 0; k < 3; k++) a[k] = Pj[k] - Pi[k] - Vi[k] * dTij - 0.5 * g[k] * dT2;
+    m3_vec(RiT, a, ra);
+    hat(ra, H);
+    BLK(Ji, 0, 6, H, 1.0);
+    BLK(Ji, 0, 9, meas + 16, -1.0);
+    BLK(Ji, 0, 12, meas + 25, -1.0);
+    /* rows rV :1099-1103 */
+    BLK(Ji, 3, 3, RiT, -1.0);
+    for (int k = 0; k < 3; k++) a[k] = Vj[k] - Vi[k] - g[k] * dTij;
+    m3_vec(RiT, a, ra);
+    hat(ra, H);
+    BLK(Ji, 3, 6, H, 1.0);
+    BLK(Ji, 3, 9, meas + 34, -1.0);
+    BLK(Ji, 3, 12, meas + 43, -1.0);
+    /* rows rPhi :1106-1112 */
+    double qe[4], qei[4], ExprPhiijTrans[9], w[3], JrBiasGCorr[9];
+    vbo_so3_exp(rPhiij, qe);
+    so3_inv(qe, qei);
+    quat_to_R(qei, ExprPhiijTrans);
+    m3_vec(J_rPhi_dbg, dBgi, w);
+    vbo_so3_jr(w, JrBiasGCorr);
+    m3_mul(JrInv_rPhi, RjT, T1);
+    m3_mul(T1, Ri, T2);
+    BLK(Ji, 6, 6, T2, -1.0);
+    m3_mul(JrInv_rPhi, ExprPhiijTrans, T1);
+    m3_mul(T1, JrBiasGCorr, T2);
+    m3_mul(T2, J_rPhi_dbg, T1);
+    BLK(Ji, 6, 9, T1, -1.0);
+    /* rows rBiasG, rBiasA :1115-1126 */
+    for (int k = 0; k < 3; k++) { Ji[(9 + k) * 15 + 9 + k] = -1.0; Ji[(12 + k) * 15 + 12 + k] = -1.0; }
+    /* vertex 1 :1131-1166 */
+    BLK(Jj, 0, 0, RiT, 1.0);
+    BLK(Jj, 3, 3, RiT, 1.0);
+    BLK(Jj, 6, 6, JrInv_rPhi, 1.0);
+    for (int k = 0; k < 3; k++) { Jj[(9 + k) * 15 + 9 + k] = 1.0; Jj[(12 + k) * 15 + 12 + k] = 1.0; }
+#undef BLK
+}
+
+/* VertexNavState::oplusImpl, g2otypes.cpp:961-966 -> NavState::IncSmall, NavState.cpp:31-59 (update order P V Phi dBg dBa) */
+void vbo_oplus_navstate(double *nav, const double *upd) {
+    for (int k = 0; k < 3; k++) { nav[k] += upd[k]; nav[7 + k] += upd[3 + k]; }
+    double dR[4];
+    vbo_so3_exp(upd + 6, dR);
+    so3_mul(nav + 3, dR, nav + 3);   /* _R = Get_R() * dR */
+    for (int k = 0; k < 3; k++) { nav[16 + k] += upd[9 + k]; nav[19 + k] += upd[12 + k]; }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * A15  IMUPreintegrator::update, src/IMU/IMUPreintegrator.cpp:63-112
  *   state: meas[VBA_IMU_MEAS_STRIDE] (dt,dP,dV,dR,JPg,JPa,JVg,JVa,JRg) + cov[81] in P,V,phi order
  *   gyr_cov / acc_cov: scalar diagonal of IMUData::_gyrMeasCov / _accMeasCov (imudata.cpp:28-31)

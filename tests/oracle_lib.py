@@ -182,6 +182,22 @@ def edge_bias_error(bi, bj):
     e = _v(6); call("vbo_edge_bias_error", _a(bi), _a(bj), e); return e
 
 
+def edge_navstate_error(navi, navj, meas, g):
+    """A6 EdgeNavState::computeError: 15 (rP rV rPhi rBg rBa)"""
+    e = _v(15); call("vbo_edge_navstate_error", _a(navi), _a(navj), _a(meas), _a(g), e); return e
+
+
+def edge_navstate_jac(navi, navj, meas, g, err):
+    """A6 EdgeNavState::linearizeOplus: two 15x15, columns P V Phi dBg dBa"""
+    Ji, Jj = _v(225), _v(225)
+    call("vbo_edge_navstate_jac", _a(navi), _a(navj), _a(meas), _a(g), _a(err), Ji, Jj)
+    return Ji.reshape(15, 15), Jj.reshape(15, 15)
+
+
+def oplus_navstate(nav, upd15):
+    out = np.array(nav, dtype=np.float64).copy(); call("vbo_oplus_navstate", out, _a(upd15)); return out
+
+
 def preint(omega, acc, dts, gyr_cov=abi.GYR_MEAS_COV, acc_cov=abi.ACC_MEAS_COV):
     meas, cov = _v(abi.IMU_MEAS_STRIDE), _v(81)
     call("vbo_preint_reset", meas, cov)

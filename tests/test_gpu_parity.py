@@ -226,13 +226,20 @@ def test_batch_solve_streams_fresh_windows_like_upload_run_download(ba, oracle, 
     ba.upload(ps); ba.run(); q0, r0 = ba.download()
     q0 = [x.copy() for x in q0]
     try:
-        for chunk, lanes in ((1000, 1), (10, 3), (4, 2), (7, 1)):
+        # chunks of >= 8 windows run the same kernels as the 29-window batch (the kernel choice depends on the number of windows
+        # in a call: thresholds 8 / 64 / 256): bit-identical.  Smaller chunks take the few-window kernels, whose sums run in
+        # another (fixed) order: equal to rounding.
+        for chunk, lanes, exact in ((1000, 1, True), (10, 3, True), (15, 2, True), (4, 2, False), (7, 1, False)):
             ba.lib.vba_debug_set_chunking(ba.h, chunk, lanes)
             q, r = ba.solve_batch(ps)
             for a, b, ra, rb in zip(q0, q, r0, r):
-                assert ra.status == rb.status == 0 and ra.its_done == rb.its_done and ra.chi2_vis == rb.chi2_vis
-                assert (a.kf_pose == b.kf_pose).all() and (a.pt == b.pt).all() and (a.kf_vel == b.kf_vel).all()
-                assert (ra.obs_outlier == rb.obs_outlier).all() and (ra.obs_chi2 == rb.obs_chi2).all()
+                assert ra.status == rb.status == 0 and ra.its_done == rb.its_done and (ra.obs_outlier == rb.obs_outlier).all()
+                if exact:
+                    assert ra.chi2_vis == rb.chi2_vis and (ra.obs_chi2 == rb.obs_chi2).all()
+                    assert (a.kf_pose == b.kf_pose).all() and (a.pt == b.pt).all() and (a.kf_vel == b.kf_vel).all()
+                else:
+                    assert abs(ra.chi2_vis - rb.chi2_vis) <= 1e-10 * ra.chi2_vis
+                    assert np.abs(a.kf_pose - b.kf_pose).max() < 1e-9 and np.abs(a.pt - b.pt).max() < 1e-9
     finally:
         ba.lib.vba_debug_set_chunking(ba.h, 0, 0)
     for i in range(6):
@@ -246,6 +253,41 @@ def test_batch_solve_streams_fresh_windows_like_upload_run_download(ba, oracle, 
             ba.solve_batch(ps[:9] + [bad] + ps[:3])
     finally:
         ba.lib.vba_debug_set_chunking(ba.h, 0, 0)
+
+
+def test_fused_imu_factor_hessian_equals_edge_navstate(ba, oracle):
+    """A6 on the GPU: the 30x30 local Hessian + rhs the linearisation kernel builds for one keyframe pair
+    (EdgeNavStatePRV + EdgeNavStateBias fused, Huber weights applied) equals J^T (rho' Omega) J / -J^T (rho' Omega) e of the
+    oracle's 15-D EdgeNavState (g2otypes.cpp:989-1168) after the P,Phi,V -> P,V,Phi permutation"""
+    from test_oracle_units import split_factor, A6_FROM_SPLIT_COLS, A6_FROM_SPLIT_ROWS, _nav
+    p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=7, n_fixed=1, n_pt=120, n_obs=600, seed=61)
+    p.kf_bias = p.kf_bias.copy()
+    p.kf_bias[:, 6:] = np.random.default_rng(5).normal(0, 1e-3, (p.n_kf, 6))   # non-zero delta biases
+    p.its_stage1, p.its_stage2 = 1, 0          # one linearisation at the uploaded state; IMUH then holds its products
+    ba.upload([p]); ba.run()
+    buf = ba.lib.vba_debug_buf_id(b"IMUH")
+    H = np.zeros((p.n_imu, 960))
+    assert ba.lib.vba_debug_copy(ba.h, buf, C.c_uint64(0), H.ctypes.data_as(C.c_void_p), C.c_uint64(H.nbytes)) == 0
+    pr, pc = np.array(A6_FROM_SPLIT_ROWS), np.array(A6_FROM_SPLIT_COLS)
+    pc2 = np.concatenate([pc, 15 + pc])
+    checked = 0
+    for k in range(p.n_imu):
+        i, j = p.imu_kf_i[k], p.imu_kf_j[k]
+        # the A6 factor with the split edges' robust weights: rho'(chi2_prv) on the PVR rows, rho'(chi2_bias) on the bias rows
+        e_s, Ji_s, Jj_s, Om_s = split_factor(oracle, p, k)
+        w_prv = oracle.huber(e_s[:9] @ Om_s[:9, :9] @ e_s[:9], p.huber_prv)[1]
+        w_b = oracle.huber(e_s[9:] @ Om_s[9:, 9:] @ e_s[9:], p.huber_bias)[1]
+        W6 = (np.diag([w_prv] * 9 + [w_b] * 6) @ Om_s)[pr][:, pr]
+        ni, nj = _nav(p, i), _nav(p, j)
+        e6 = oracle.edge_navstate_error(ni, nj, p.imu_meas[k], p.g_w)
+        J6 = np.hstack(oracle.edge_navstate_jac(ni, nj, p.imu_meas[k], p.g_w, e6))
+        H6, b6 = J6.T @ W6 @ J6, -J6.T @ W6 @ e6
+        Hg, bg = H[k, :900].reshape(30, 30), H[k, 900:930]
+        # GPU local order per keyframe: P Phi V dbg dba (the split order) -> A6 order through the column permutation
+        np.testing.assert_allclose(Hg[pc2][:, pc2], H6, rtol=1e-9, atol=1e-9 * np.abs(H6).max())
+        np.testing.assert_allclose(bg[pc2], b6, rtol=1e-9, atol=1e-9 * np.abs(b6).max())
+        checked += 1
+    assert checked == p.n_imu >= 6
 
 
 def test_rerun_is_bit_reproducible(ba):

@@ -188,6 +188,84 @@ def test_edge_prv_jacobians(oracle):
             np.testing.assert_allclose(N, Jk, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(Jk).max()))
 
 
+# ---- A6: the 15-D EdgeNavState (g2otypes.cpp:989-1168) and what the backend fuses instead (A2 + A3) ----
+A6_FROM_SPLIT_ROWS = [0, 1, 2, 6, 7, 8, 3, 4, 5, 9, 10, 11, 12, 13, 14]   # A6 row r (P V Phi bg ba) <- [A2 (P Phi V) ; A3 (bg ba)] row
+A6_FROM_SPLIT_COLS = [0, 1, 2, 6, 7, 8, 3, 4, 5, 9, 10, 11, 12, 13, 14]   # A6 column (P V Phi dbg dba) <- split column (P Phi | V | dbg dba)
+
+
+def _nav(p, kf, bias=None):
+    return np.concatenate([p.kf_pose[kf], p.kf_vel[kf], p.kf_bias[kf] if bias is None else bias])
+
+
+def split_factor(oracle, p, k, bi=None):
+    """A2 + A3 of IMU edge k stacked in the split order: error 15 = [rP rPhi rV | rBg rBa], Jacobians 15x15 per keyframe with
+    columns [P Phi | V | dbg dba], information blkdiag(info_prv(P,Phi,V), inv_bg/dT I3, inv_ba/dT I3)  (src/Optimizer.cpp:273-302)"""
+    i, j = p.imu_kf_i[k], p.imu_kf_j[k]
+    bi = p.kf_bias[i] if bi is None else bi
+    pi, pj, vi, vj, meas, g = p.kf_pose[i], p.kf_pose[j], p.kf_vel[i], p.kf_vel[j], p.imu_meas[k], p.g_w
+    e9 = oracle.edge_prv_error(pi, pj, vi, vj, bi, meas, g)
+    JPRi, JPRj, JVi, JVj, JBi = oracle.edge_prv_jac(pi, pj, vi, vj, bi, meas, g, e9)
+    e6 = oracle.edge_bias_error(bi, p.kf_bias[j])
+    Ji = np.zeros((15, 15)); Jj = np.zeros((15, 15))
+    Ji[:9, 0:6], Ji[:9, 6:9], Ji[:9, 9:15] = JPRi, JVi, JBi
+    Jj[:9, 0:6], Jj[:9, 6:9] = JPRj, JVj
+    Ji[9:, 9:] = -np.eye(6); Jj[9:, 9:] = np.eye(6)                      # EdgeNavStateBias::linearizeOplus, g2otypes.cpp:728-741
+    dT = meas[0]
+    Om = np.zeros((15, 15))
+    Om[:9, :9] = p.imu_info_prv[k].reshape(9, 9)
+    Om[9:12, 9:12] = np.eye(3) / abi.GYR_BIAS_RW2 / dT
+    Om[12:, 12:] = np.eye(3) / abi.ACC_BIAS_RW2 / dT
+    return np.concatenate([e9, e6]), Ji, Jj, Om
+
+
+def test_edge_navstate_jacobians_fd(oracle):
+    """A6 analytic Jacobians vs central differences through VertexNavState::oplusImpl (NavState::IncSmall)"""
+    for seed in (21, 22, 23):
+        p, k, i, j, bi = _prv_setup(seed)
+        ni, nj, meas, g = _nav(p, i, bi), _nav(p, j), p.imu_meas[k], p.g_w
+        err = oracle.edge_navstate_error(ni, nj, meas, g)
+        Ji, Jj = oracle.edge_navstate_jac(ni, nj, meas, g, err)
+        Ni = _numdiff(lambda d: oracle.edge_navstate_error(oracle.oplus_navstate(ni, d), nj, meas, g), 15, 1e-6)
+        Nj = _numdiff(lambda d: oracle.edge_navstate_error(ni, oracle.oplus_navstate(nj, d), meas, g), 15, 1e-6)
+        # first-order-in-the-residual Jacobians, as for A2: 2e-3 relative
+        np.testing.assert_allclose(Ni, Ji, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(Ji).max()))
+        np.testing.assert_allclose(Nj, Jj, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(Jj).max()))
+        # the oplus itself: P, V, dbg, dba additive, R right-multiplied
+        d = np.random.default_rng(seed).normal(0, 1e-2, 15)
+        n2 = oracle.oplus_navstate(ni, d)
+        np.testing.assert_allclose(n2[:3], ni[:3] + d[:3]); np.testing.assert_allclose(n2[7:10], ni[7:10] + d[3:6])
+        np.testing.assert_allclose(n2[16:], ni[16:] + d[9:]); assert (n2[10:16] == ni[10:16]).all()
+        np.testing.assert_allclose(oracle.quat_to_R(n2[3:7]), oracle.quat_to_R(ni[3:7]) @ synth.so3_exp(d[6:9]), atol=1e-12)
+
+
+def test_split_prv_plus_bias_factor_equals_edge_navstate_after_permutation(oracle):
+    """residual, Jacobians and the quadratic form of A2 + A3 (what the backend fuses per keyframe pair)
+    equal those of the 15-D A6 edge after the P,Phi,V -> P,V,Phi permutation"""
+    perm_r, perm_c = np.array(A6_FROM_SPLIT_ROWS), np.array(A6_FROM_SPLIT_COLS)
+    for seed in (21, 22, 23, 24):
+        p, k, i, j, bi = _prv_setup(seed)
+        e_s, Ji_s, Jj_s, Om_s = split_factor(oracle, p, k, bi)
+        ni, nj = _nav(p, i, bi), _nav(p, j)
+        e6 = oracle.edge_navstate_error(ni, nj, p.imu_meas[k], p.g_w)
+        Ji6, Jj6 = oracle.edge_navstate_jac(ni, nj, p.imu_meas[k], p.g_w, e6)
+        np.testing.assert_allclose(e6, e_s[perm_r], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(Ji6, Ji_s[perm_r][:, perm_c], rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(Jj6, Jj_s[perm_r][:, perm_c], rtol=1e-13, atol=1e-15)
+        # information of the 15-D edge in ITS order = the permuted block-diagonal; then chi2, H and b agree
+        Om6 = Om_s[perm_r][:, perm_r]
+        assert abs(e6 @ Om6 @ e6 - e_s @ Om_s @ e_s) <= 1e-12 * abs(e_s @ Om_s @ e_s)
+        J6 = np.hstack([Ji6, Jj6]); Js = np.hstack([Ji_s, Jj_s])
+        pc2 = np.concatenate([perm_c, 15 + perm_c])
+        H6, Hs = J6.T @ Om6 @ J6, Js.T @ Om_s @ Js
+        np.testing.assert_allclose(H6, Hs[pc2][:, pc2], rtol=1e-10, atol=1e-10 * np.abs(Hs).max())
+        np.testing.assert_allclose(J6.T @ Om6 @ e6, (Js.T @ Om_s @ e_s)[pc2], rtol=1e-10, atol=1e-10 * np.abs(Js.T @ Om_s @ e_s).max())
+        # one IncSmall step == IncSmallPR + IncSmallV + IncSmallBias of the split vertices
+        d = np.random.default_rng(seed).normal(0, 1e-2, 15)
+        n2 = oracle.oplus_navstate(ni, d)
+        np.testing.assert_allclose(n2[:7], oracle.oplus_pr(ni[:7], np.concatenate([d[:3], d[6:9]])), atol=1e-15)
+        np.testing.assert_allclose(n2[7:10], ni[7:10] + d[3:6], atol=0)
+
+
 def test_prv_and_bias_zero_at_noise_free_truth(oracle):
     p = synth.make_window(n_kf=6, n_pt=40, n_obs=160, noise=False, seed=12)
     for k in range(p.n_imu):
