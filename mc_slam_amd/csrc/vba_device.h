@@ -48,6 +48,9 @@ struct WinDesc {
     int order;      // elimination order: 0 = V/Bias blocks first, 1 = keyframe by keyframe
     int vp_pr0, vp_prs, vp_vb0, vp_vbs;  // position of dof r of free keyframe a: r < 6 ? pr0 + prs a + r : vb0 + vbs a + r - 6
     long long S0;   // offset (doubles) into S
+    long long mask0; // offset (64-bit words) of the window's landmark masks (n_pt x mwords)
+    int mwords;      // 64-bit words per landmark mask = ceil(n_kf / 64)
+    int pad_;
     double K[4];
     double Rcb[9], tcb[3], g[3];
     double inv_bg, inv_ba;
@@ -65,7 +68,6 @@ struct WinCtrl {
     int its_done[2];
     int robust_vis;   // Huber on vision edges (stage 1)
     int chol_fail;    // set by the factorisation of the current iteration
-    int step_ok;      // (unused, kept for layout stability of the debug tools)
     int aborted;      // stop flag seen
     int n_trace;
     int n_outliers;

@@ -39,6 +39,10 @@ struct Batch {
     int* var_act;
     // structure (g2o buildStructure analogue, built on the host at upload)
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
+    const int* item_mid;                // per pair: its first item that involves the landmark's reference keyframe
+    const unsigned long long* lmask;    // [n_pt x mwords] observing keyframes of every landmark (host-built while validating)
+    const int *kf_seg, *ref_seg;        // [n_kf + 1] per window: record range of every keyframe -- slot / edge records by observing
+                                        // keyframe, landmark records by reference keyframe (the items of the diagonal pair (a,a))
     const int *off_pair, *pair_mask;  // off-diagonal pair indices; per pair: which sub-blocks of S are ever read
     const int* lin_blk;  // k_lin2: per workgroup its run of landmarks and edges (p0, p1, e0, e1), n_part_lin records per window
     // tile structure of the factor (symbolic factorisation on 32x32 tiles, built at upload)
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(64) k_reset(Batch B) {
         c.stage = 0; c.it = 0; c.active = 0; c.status = 0;
         c.its_done[0] = c.its_done[1] = 0;
         c.robust_vis = (d.protocol == 1) ? (d.robust != 0) : 1;
-        c.chol_fail = 0; c.step_ok = 0; c.aborted = 0;
+        c.chol_fail = 0; c.aborted = 0;
         c.n_trace = 0; c.n_outliers = 0;
         c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0;
         c.lambda = 0; c.ni = 2; c.chi_prev = 0; c.chi_ini = 0;
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(64) k_stage_clear(Batch B, int stage) {
             c.robust_vis = 0;  // e->setRobustKernel(0) on every vision edge, :489
         }
         if (d.its[stage] <= 0) c.active = 0;  // optimize(0) runs nothing
-        c.stage = stage; c.it = 0; c.chol_fail = 0; c.step_ok = 0;
+        c.stage = stage; c.it = 0; c.chol_fail = 0;
         c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0; c.ni = 2;
     }
 }
@@ -668,7 +672,6 @@ __global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval) {
     }
     c.active = active;
     c.chol_fail = 0;
-    c.step_ok = active;
     c.it = it + 1;
     if (active && B.alive_cnt && it < 32)  // lets the host skip dead iterations; a posted store, not a PCIe atomic
         __hip_atomic_store(B.alive_cnt + st * 32 + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -912,20 +915,20 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
     for (int i = 0; i < 21; i++) acc[i] = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) rhs[i] = bp[i] = hd[i] = 0;
-    const int ib = B.item_begin[d.pair0 + d.win + pr], ie = B.item_begin[d.pair0 + d.win + pr + 1];
+    // the items of the diagonal pair are the records of keyframe a: its slot records (observer) and, for inverse-depth
+    // landmarks, the landmark records it is the reference keyframe of -- two index ranges, no list
+    const int* kseg = B.kf_seg + d.kf0 + d.win;
+    const int s0 = kseg[a], n_o = kseg[a + 1] - s0;
+    const int r0s = (LD == 1) ? B.ref_seg[d.kf0 + d.win + a] : 0, n_r = (LD == 1) ? B.ref_seg[d.kf0 + d.win + a + 1] - r0s : 0;
     const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
-    const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
     double Ra[9];  // rotation of keyframe a (the observer of every non-reference item of its diagonal pair)
     {
         const double* Ca = B.kfR + 12 * (size_t)(d.kf0 + a);
 #pragma unroll
         for (int i = 0; i < 9; i++) Ra[i] = Ca[i];
     }
-    int nxt = 0;
-    if (ib + t < ie) nxt = items[ib + t].x;
-    for (int it = ib + t; it < ie; it += 64) {
-        const int sa = nxt;
-        if (it + 64 < ie) nxt = items[it + 64].x;
+    for (int it = t; it < n_o + n_r; it += 64) {
+        const int sa = (it < n_o) ? s0 + it : d.n_obs + r0s + (it - n_o);
         const double* qa = slots + SS * (size_t)sa;
         double UA[6 * LD], beta[LD];
 #pragma unroll

@@ -9,6 +9,7 @@
 #include "vba_kernels_lm.h"
 #include "vba_preint.h"
 #include "vba_pose.h"
+#include "vba_structure.h"
 
 #include <algorithm>
 #include <chrono>
@@ -119,14 +120,15 @@ struct PinVec {
 struct Staging {
     PinVec<double> pose, vel, bias, pt, uv, ow, meas, info;
     PinVec<unsigned char> kffix;
-    PinVec<int> ptref, ptobs, obskf, obspt, imui, imuj, pair_a, pair_b, item_begin, items, pimu_begin, pimu;
-    PinVec<int> offpair, pairmask, slotperm, ptperm;
+    PinVec<int> ptref, ptobs, obskf, imui, imuj, pair_a, pair_b, pimu_begin, pimu;
+    PinVec<int> offpair, pairmask;
+    PinVec<unsigned long long> lmask;
     PinVec<double> dl_pose, dl_vel, dl_bias, dl_pt, dl_chi2;
     PinVec<unsigned char> dl_outl;
     template <typename F> void each(F f) {
         f(pose); f(vel); f(bias); f(pt); f(uv); f(ow); f(meas); f(info); f(kffix);
-        f(ptref); f(ptobs); f(obskf); f(obspt); f(imui); f(imuj); f(pair_a); f(pair_b); f(item_begin); f(items); f(pimu_begin); f(pimu);
-        f(offpair); f(pairmask); f(slotperm); f(ptperm);
+        f(ptref); f(ptobs); f(obskf); f(imui); f(imuj); f(pair_a); f(pair_b); f(pimu_begin); f(pimu);
+        f(offpair); f(pairmask); f(lmask);
         f(dl_pose); f(dl_vel); f(dl_bias); f(dl_pt); f(dl_chi2); f(dl_outl);
     }
     bool ok() { bool r = true; each([&](auto& v) { r = r && v.ok; }); return r; }
@@ -138,7 +140,8 @@ enum {
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
-    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM, BUF_N
+    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_N
 };
 
 struct ProfEvt {
@@ -162,6 +165,8 @@ struct Handle {
     std::vector<WinDesc> desc;
     std::vector<WinCtrl> hctrl;
     int n_win = 0;
+    int regime_n = 0;  // windows of the uploaded batch: decides WHICH kernels run (few-window / many-window variants), so that
+                       // cutting the batch into window groups never changes a summation order
     // launch geometry (maxima over the batch)
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
     int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0, max_quads = 1, max_offp = 1;
@@ -235,14 +240,20 @@ struct ProfScope {
 };
 
 // ---- structure build (g2o BlockSolver::buildStructure analogue, block_solver.hpp:143-295) -------------
+// Host half: ONE walk over a window's index arrays validates them and leaves, per landmark, the bitmask of its observing
+// keyframes; from the masks come the keyframe-pair occupancy and with it the symbolic tile factorisation, the IMU lists and
+// the write masks.  Everything that needs a sort or a per-pair item list is built on the device from the raw arrays
+// (vba_structure.h).
 struct Structure {
-    std::vector<int> pair_a, pair_b, item_begin, items, pimu_begin, pimu, obs_pt;
+    std::vector<int> pair_a, pair_b, pimu_begin, pimu;
     std::vector<int> step_begin, tpairs, pan_begin, pan;  // tile lists of the factorisation
     std::vector<int> step_npairs;
     std::vector<int> off_pair, pair_mask;
-    std::vector<int> slot_perm;        // record position of every observation edge (see build_structure)
-    std::vector<int> pt_perm;          // record position of every landmark (reference slot, point record, N0)
-    int order = 0;                     // elimination order of the reduced system (see build_structure)
+    std::vector<unsigned long long> lmask;  // [n_pt][mwords] observing keyframes of every landmark
+    std::vector<int> linblk;                // k_lin2 work split (inverse-depth windows): (p0, p1, e0, e1) per workgroup
+    int mwords = 1;
+    long long item_cap = 0;            // upper bound of the off-diagonal items (exact when every keyframe is free)
+    int order = 0;                     // elimination order of the reduced system (see below)
     std::vector<int> kl_begin, klist;  // left-looking factorisation: per column entry the steps k < J that update it
 };
 
@@ -255,154 +266,105 @@ double now_ms();
 int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     static const bool timing = getenv("VBA_TIMING") != nullptr;
     const double t_b0 = timing ? now_ms() : 0.0;
-    const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2;
+    const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2, nkf = P->n_kf;
     auto pidx = [nf](int a, int b) { return a * nf - a * (a - 1) / 2 + (b - a); };
     st.pair_a.resize(npairs);
     st.pair_b.resize(npairs);
+    st.off_pair.clear();
+    st.off_pair.reserve(npairs);
     for (int a = 0; a < nf; a++)
         for (int b = a; b < nf; b++) {
             st.pair_a[pidx(a, b)] = a;
             st.pair_b[pidx(a, b)] = b;
+            if (a != b) st.off_pair.push_back(pidx(a, b));
         }
-    st.obs_pt.resize(P->n_obs);
-    // Where the slot / edge records of observation o live.  Inverse-depth windows keep them KEYFRAME-major (all records of
-    // one observing keyframe contiguous, landmark order inside): the Schur gather of a keyframe pair (a,b) then stays
-    // inside two ~45-KB segments instead of wandering over the whole 2-MB array, and the diagonal pair streams its
-    // segment.  (The observation arrays themselves stay landmark-major, as the caller hands them over.)
-    st.slot_perm.resize(P->n_obs);
-    st.pt_perm.resize(P->n_pt);
-    static const bool no_perm = getenv("VBA_NO_SLOT_PERM") != nullptr;
-    static const bool no_track_order = getenv("VBA_NO_TRACK_ORDER") != nullptr;
-    // Landmark order used for the records inside a keyframe's segment AND for the items inside a pair's list: by the first
-    // keyframe (lowest index) of the landmark's track, then by landmark.  Tracks cover runs of consecutive keyframes, so the
-    // records pair (a,b) needs are then a contiguous suffix of a's segment and a contiguous prefix of b's, visited in
-    // ascending order: the gather touches every fetched line completely instead of one 64-B record per 128-B line.
-    std::vector<int> lm_order(P->n_pt);
-    {
-        std::vector<int> key(P->n_pt), start(P->n_kf + 1, 0);
-        for (int p = 0; p < P->n_pt; p++) {
-            const int o0 = P->pt_obs_begin[p], o1 = P->pt_obs_begin[p + 1];
-            if (o0 > o1 || o0 < 0 || o1 > P->n_obs) return fail(h, "pt_obs_begin is not a valid CSR");
-            int k = P->n_kf - 1;
-            if (P->variant == VBA_VARIANT_PRV_IDP) {
-                const int rf = P->pt_ref_kf[p];
-                if (rf < 0 || rf >= P->n_kf) return fail(h, "pt_ref_kf out of range");
-                k = rf;
-            }
-            for (int o = o0; o < o1; o++) {
-                const int kf = P->obs_kf[o];
-                if (kf < 0 || kf >= P->n_kf) return fail(h, "obs_kf out of range");
-                k = std::min(k, kf);
-            }
-            key[p] = (!no_perm && !no_track_order) ? k : 0;
-            start[key[p] + 1]++;
-        }
-        for (int k = 0; k < P->n_kf; k++) start[k + 1] += start[k];
-        for (int p = 0; p < P->n_pt; p++) lm_order[start[key[p]]++] = p;
-    }
-    if (!no_perm) {
-        // counting sort by observing / reference keyframe (stable: lm_order inside a keyframe)
-        std::vector<int> start(P->n_kf + 1, 0);
-        for (int o = 0; o < P->n_obs; o++) start[P->obs_kf[o] + 1]++;
-        for (int k = 0; k < P->n_kf; k++) start[k + 1] += start[k];
-        for (int q = 0; q < P->n_pt; q++) {
-            const int p = lm_order[q];
-            for (int o = P->pt_obs_begin[p]; o < P->pt_obs_begin[p + 1]; o++) st.slot_perm[o] = start[P->obs_kf[o]]++;
-        }
-    } else {
-        for (int o = 0; o < P->n_obs; o++) st.slot_perm[o] = o;
-    }
-    if (P->variant == VBA_VARIANT_PRV_IDP && !no_perm) {   // landmark records (reference slot, point record, N0) by reference keyframe
-        std::vector<int> start(P->n_kf + 1, 0);
-        for (int p = 0; p < P->n_pt; p++) start[P->pt_ref_kf[p] + 1]++;
-        for (int k = 0; k < P->n_kf; k++) start[k + 1] += start[k];
-        for (int q = 0; q < P->n_pt; q++) st.pt_perm[lm_order[q]] = start[P->pt_ref_kf[lm_order[q]]]++;
-    } else {   // XYZ landmarks have no reference keyframe: their point records stay in landmark order
-        for (int p = 0; p < P->n_pt; p++) st.pt_perm[p] = p;
-    }
-    std::vector<int> cnt(npairs + 1, 0);
-    std::vector<std::pair<int, int>> sl;  // (kf, slot) of one landmark, free keyframes only
     const bool idp = P->variant == VBA_VARIANT_PRV_IDP;
-    // per pair the items are ordered: first the pairs of two observation slots, then the pairs that involve the
-    // landmark's reference keyframe (these also carry a direct H_pp term; grouping them keeps waves uniform)
-    std::vector<int> cnt2(npairs + 1, 0);
-    // one walk over the landmarks records every item (pair index, kind, slot ids) and counts per pair; a second, linear
-    // pass scatters the recorded items to their places (the walk -- sorting, pair indices -- is not repeated)
-    size_t rec_max = 0;
+    const int mw = (nkf + 63) / 64;
+    st.mwords = mw;
+    st.lmask.assign((size_t)P->n_pt * mw, 0ull);
+    // occ[a] = the keyframes that share a landmark with free keyframe a (observer or reference), as a bitmask
+    std::vector<unsigned long long> occ((size_t)nf * mw, 0ull), tmp(mw);
+    st.item_cap = 0;
+    if (P->n_pt > 0 && P->pt_obs_begin[0] != 0) return fail(h, "pt_obs_begin is not a valid CSR");
     for (int p = 0; p < P->n_pt; p++) {
-        const size_t m = (size_t)(P->pt_obs_begin[p + 1] - P->pt_obs_begin[p]) + (idp ? 1 : 0);
-        rec_max += m * (m + 1) / 2;
-    }
-    std::unique_ptr<int[]> rec(new int[3 * rec_max + 3]);   // uninitialised on purpose
-    size_t nrec = 0;
-    for (int q = 0; q < P->n_pt; q++) {
-        const int p = lm_order[q];
-        sl.clear();
         const int o0 = P->pt_obs_begin[p], o1 = P->pt_obs_begin[p + 1];
-        bool sorted = true;
+        if (o0 > o1 || o0 < 0 || o1 > P->n_obs) return fail(h, "pt_obs_begin is not a valid CSR");
+        unsigned long long* M = &st.lmask[(size_t)p * mw];
+        int rf = -1;
         if (idp) {
-            const int rf = P->pt_ref_kf[p];
-            if (rf < nf) sl.push_back({rf, -1});
+            rf = P->pt_ref_kf[p];
+            if (rf < 0 || rf >= nkf) return fail(h, "pt_ref_kf out of range");
         }
         for (int o = o0; o < o1; o++) {
             const int kf = P->obs_kf[o];
-            if (idp && kf == P->pt_ref_kf[p]) return fail(h, "observation from the reference keyframe is not an edge");
-            st.obs_pt[o] = p;
-            if (kf < nf) {
-                if (!sl.empty() && kf <= sl.back().first) sorted = false;
-                sl.push_back({kf, o});
-            }
+            if (kf < 0 || kf >= nkf) return fail(h, "obs_kf out of range");
+            if (kf == rf) return fail(h, "observation from the reference keyframe is not an edge");
+            const unsigned long long bit = 1ull << (kf & 63);
+            if (M[kf >> 6] & bit) return fail(h, "a landmark is observed twice from one keyframe");
+            M[kf >> 6] |= bit;
         }
-        if (!sorted) std::sort(sl.begin(), sl.end());
-        for (size_t i = 1; i < sl.size(); i++)
-            if (sl[i].first == sl[i - 1].first) return fail(h, "a landmark is observed twice from one keyframe");
-        const int ref_slot = P->n_obs + st.pt_perm[p];   // slot ids: observation o -> its record position; reference keyframe -> n_obs + landmark record
-        for (size_t i1 = 0; i1 < sl.size(); i1++) {
-            const int a = sl[i1].first, sa = sl[i1].second >= 0 ? st.slot_perm[sl[i1].second] : ref_slot;
-            const int row = a * nf - a * (a - 1) / 2 - a;   // pidx(a, b) = row + b
-            for (size_t i2 = i1; i2 < sl.size(); i2++) {
-                const int pi = row + sl[i2].first;
-                const bool refpair = (i1 != i2) && (sl[i1].second < 0 || sl[i2].second < 0);
-                if (refpair) cnt2[pi]++; else cnt[pi]++;
-                rec[nrec] = 2 * pi + (refpair ? 1 : 0);
-                rec[nrec + 1] = sa;
-                rec[nrec + 2] = sl[i2].second >= 0 ? st.slot_perm[sl[i2].second] : ref_slot;
-                nrec += 3;
+        const long long m = o1 - o0;
+        st.item_cap += idp ? m * (m + 1) / 2 : m * (m - 1) / 2;
+        // every free keyframe of the track (reference included) shares this landmark with every other one
+        for (int wd = 0; wd < mw; wd++) tmp[wd] = M[wd];
+        if (rf >= 0) tmp[rf >> 6] |= 1ull << (rf & 63);
+        for (int wd = 0; wd < mw; wd++) {
+            unsigned long long bits = tmp[wd];
+            while (bits) {
+                const int a = 64 * wd + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (a >= nf) break;
+                for (int w2 = 0; w2 < mw; w2++) occ[(size_t)a * mw + w2] |= tmp[w2];
             }
         }
     }
-    {
-        st.item_begin.assign(npairs + 1, 0);
-        for (int i = 0; i < npairs; i++) st.item_begin[i + 1] = st.item_begin[i] + cnt[i] + cnt2[i];
-        st.items.resize(2 * (size_t)st.item_begin[npairs]);
-        // per pair the items are ordered: first the pairs of two observation slots, then the ones with the reference keyframe
-        std::vector<int> fill(st.item_begin.begin(), st.item_begin.end() - 1), fill2(npairs);
-        for (int i = 0; i < npairs; i++) fill2[i] = st.item_begin[i] + cnt[i];
-        for (size_t r = 0; r < nrec; r += 3) {
-            const int pi = rec[r] >> 1;
-            int* it = &st.items[2 * (size_t)((rec[r] & 1) ? fill2[pi]++ : fill[pi]++)];
-            it[0] = rec[r + 1];
-            it[1] = rec[r + 2];
+    if (P->pt_obs_begin[P->n_pt] != P->n_obs) return fail(h, "pt_obs_begin does not cover the observations");
+    auto pair_vis = [&](int a, int b) { return (occ[(size_t)a * mw + (b >> 6)] >> (b & 63)) & 1ull; };
+    if (idp) {
+        // k_lin2 work split: runs of consecutive landmarks with <= 256 edges and <= 64 landmarks per workgroup
+        // (one 16-B record per workgroup: first / end landmark, first / end edge)
+        st.linblk.clear();
+        int p = 0;
+        while (p < P->n_pt) {
+            const int p_first = p;
+            int ne = 0, np2 = 0;
+            while (p < P->n_pt && np2 < 64) {
+                const int k = P->pt_obs_begin[p + 1] - P->pt_obs_begin[p];
+                if (k > 256) return fail(h, "a landmark with more than 256 observations is not supported");
+                if (ne + k > 256) break;
+                ne += k; np2++; p++;
+            }
+            st.linblk.push_back(p_first); st.linblk.push_back(p);
+            st.linblk.push_back(P->pt_obs_begin[p_first]); st.linblk.push_back(P->pt_obs_begin[p]);
         }
     }
     const double t_b1 = timing ? now_ms() : 0.0;
-    // IMU edges per block pair
-    std::vector<std::vector<std::pair<int, int>>> pl(npairs);
+    // IMU edges per block pair: (edge, role) with role bit0: a is keyframe j of the edge, bit1: b is keyframe j
     const int nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
-    for (int k = 0; k < nimu; k++) {
-        const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
-        if (i < 0 || j < 0 || i >= P->n_kf || j >= P->n_kf || i == j) return fail(h, "imu keyframe index out of range");
-        if (i < nf) pl[pidx(i, i)].push_back({k, 0});
-        if (j < nf) pl[pidx(j, j)].push_back({k, 3});
-        if (i < nf && j < nf) {
-            if (i < j) pl[pidx(i, j)].push_back({k, 2});
-            else pl[pidx(j, i)].push_back({k, 1});
-        }
-    }
     st.pimu_begin.assign(npairs + 1, 0);
-    for (int i = 0; i < npairs; i++) {
-        st.pimu_begin[i + 1] = st.pimu_begin[i] + (int)pl[i].size();
-        for (auto& e : pl[i]) { st.pimu.push_back(e.first); st.pimu.push_back(e.second); }
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<int> fill;
+        if (pass) {
+            for (int i = 0; i < npairs; i++) st.pimu_begin[i + 1] += st.pimu_begin[i];
+            st.pimu.assign(2 * (size_t)st.pimu_begin[npairs], 0);
+            fill.assign(st.pimu_begin.begin(), st.pimu_begin.end() - 1);
+        }
+        auto put = [&](int pi, int k, int role) {
+            if (!pass) { st.pimu_begin[pi + 1]++; return; }
+            st.pimu[2 * (size_t)fill[pi]] = k;
+            st.pimu[2 * (size_t)fill[pi] + 1] = role;
+            fill[pi]++;
+        };
+        for (int k = 0; k < nimu; k++) {
+            const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
+            if (i < 0 || j < 0 || i >= nkf || j >= nkf || i == j) return fail(h, "imu keyframe index out of range");
+            if (i < nf) put(pidx(i, i), k, 0);
+            if (j < nf) put(pidx(j, j), k, 3);
+            if (i < nf && j < nf) {
+                if (i < j) put(pidx(i, j), k, 2);
+                else put(pidx(j, i), k, 1);
+            }
+        }
     }
     // symbolic factorisation on 32x32 tiles (the tile-level analogue of SimplicialLDLT::analyzePattern,
     // linear_solver_eigen.h:147-152): which tiles of L can be nonzero.  Two elimination orders are tried and the cheaper
@@ -413,13 +375,13 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     //            for long, thin windows and for maps
     const int pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
     const int np = pdim * nf, nS = ((np + VBA_NB - 1) / VBA_NB) * VBA_NB, nb = nS / VBA_NB;
-    auto symbolic = [&](int order) -> long long {
+    auto symbolic = [&](int order, bool lists) -> long long {
     st.tpairs.clear(); st.pan.clear();
     std::vector<unsigned char> T((size_t)nb * nb, 0);
     for (int i = 0; i < nb; i++) T[(size_t)i * nb + i] = 1;
     for (int pi = 0; pi < npairs; pi++) {
         const int a = st.pair_a[pi], b = st.pair_b[pi];
-        const bool vis = st.item_begin[pi + 1] > st.item_begin[pi];
+        const bool vis = pair_vis(a, b);
         const bool imu = st.pimu_begin[pi + 1] > st.pimu_begin[pi];
         if (!vis && !imu && a != b) continue;
         // a keyframe's PR dofs (0..5) and V/Bias dofs (6..14) are two contiguous runs: each touches at most two tiles
@@ -437,6 +399,7 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     st.pan_begin.assign(nb + 1, 0);
     st.step_npairs.assign(nb, 0);
     std::vector<int> pk;
+    long long cost = 0;
     for (int k = 0; k < nb; k++) {
         pk.clear();
         for (int I = k + 1; I < nb; I++)
@@ -452,6 +415,8 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
         st.pan_begin[k + 1] = (int)st.pan.size();
         st.step_npairs[k] = st.step_begin[k + 1] - st.step_begin[k];
     }
+    cost = (long long)st.tpairs.size();   // one tile product per update pair (= the k-list entries of the left-looking form)
+    if (!lists) return cost;
     // left-looking lists: column entries in the order (J,J), then (I,J) for I in the panel of J; K(I,J) = {k < J : L_Ik, L_Jk != 0}
     st.kl_begin.clear();
     st.klist.clear();
@@ -466,10 +431,8 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     st.kl_begin.push_back((int)st.klist.size());
     // which sub-blocks of a keyframe pair's block can land in a tile the factorisation reads (T now holds L's pattern)
     st.pair_mask.assign(npairs, 0);
-    st.off_pair.clear();
     for (int pi = 0; pi < npairs; pi++) {
         const int a = st.pair_a[pi], b = st.pair_b[pi];
-        if (a != b) st.off_pair.push_back(pi);
         int mask = 0;
         const int nsub = (pdim == 15) ? 2 : 1;
         for (int sr = 0; sr < nsub; sr++)
@@ -484,7 +447,6 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
             }
         st.pair_mask[pi] = mask;
     }
-    long long cost = (long long)st.klist.size();
     return cost;
     };
     static const int env_order = getenv("VBA_ORDER") ? atoi(getenv("VBA_ORDER")) : -1;
@@ -492,14 +454,14 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     if (pdim == 15) {
         if (env_order >= 0) st.order = env_order ? 1 : 0;
         else {
-            const long long c0 = symbolic(0), c1 = symbolic(1);
+            const long long c0 = symbolic(0, false), c1 = symbolic(1, false);
             st.order = (10 * c1 < 7 * c0) ? 1 : 0;  // only a clear win: a batch that mixes both orders pays for both patterns
-            if (getenv("VBA_TIMING")) fprintf(stderr, "[vba] tile products of the factorisation: V/Bias-first %lld, keyframe order %lld (nb %d)\n", c0, c1, nb);
+            if (timing) fprintf(stderr, "[vba] tile products of the factorisation: V/Bias-first %lld, keyframe order %lld (nb %d)\n", c0, c1, nb);
         }
     }
-    symbolic(st.order);
+    symbolic(st.order, true);
     st.off_pair.resize(npairs, 0);  // padded to the pair stride
-    if (timing) fprintf(stderr, "[vba] structure: orders + item lists %.3f ms, IMU lists + symbolic factorisation %.3f ms\n", t_b1 - t_b0, now_ms() - t_b1);
+    if (timing) fprintf(stderr, "[vba] structure (host): validation + masks %.3f ms, IMU lists + symbolic factorisation %.3f ms\n", t_b1 - t_b0, now_ms() - t_b1);
     return 0;
 }
 
@@ -542,14 +504,16 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     HIPCHK(h, hipSetDevice(h->device));
     h->uploaded = false;
     h->n_win = n;
+    h->regime_n = n;
     h->desc.assign(n, WinDesc());
     h->win_tiles.assign(n, 0);
     Staging& G = h->stg;
     auto &pose = G.pose, &vel = G.vel, &bias = G.bias, &pt = G.pt, &uv = G.uv, &ow = G.ow, &meas = G.meas, &info = G.info;
     auto& kffix = G.kffix;
-    auto &ptref = G.ptref, &ptobs = G.ptobs, &obskf = G.obskf, &obspt = G.obspt, &imui = G.imui, &imuj = G.imuj, &pair_a = G.pair_a, &pair_b = G.pair_b;
-    auto &item_begin = G.item_begin, &items = G.items, &pimu_begin = G.pimu_begin, &pimu = G.pimu;
-    auto &offpair = G.offpair, &pairmask = G.pairmask, &slotperm = G.slotperm, &ptperm = G.ptperm;
+    auto &ptref = G.ptref, &ptobs = G.ptobs, &obskf = G.obskf, &imui = G.imui, &imuj = G.imuj, &pair_a = G.pair_a, &pair_b = G.pair_b;
+    auto &pimu_begin = G.pimu_begin, &pimu = G.pimu;
+    auto &offpair = G.offpair, &pairmask = G.pairmask;
+    auto& lmask = G.lmask;
     G.each([](auto& v) { v.clear(); });
     std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, tlkb, tlk;
     h->step_grid.clear();
@@ -557,7 +521,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->step_npair_max.clear();
     h->tile_updates = 0;
     size_t S_tot = 0;
-    int kf0 = 0, pt0 = 0, obs0 = 0, imu0 = 0, pair0 = 0, item0 = 0, pimu0 = 0, vec0 = 0, part0 = 0;
+    int kf0 = 0, pt0 = 0, obs0 = 0, imu0 = 0, pair0 = 0, pimu0 = 0, vec0 = 0, part0 = 0;
+    long long item0 = 0, mask0 = 0;
+    int max_kf = 0;
     h->max_free = 0;
     h->max_lin_blk = 0;
     h->max_quads = 1;
@@ -579,11 +545,11 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             spair += (size_t)P->n_kf_free * (P->n_kf_free + 1) / 2;
         }
         pose.reserve(7 * skf); vel.reserve(3 * skf); bias.reserve(12 * skf); kffix.reserve(skf);
-        pt.reserve(3 * spt); ptref.reserve(spt); ptobs.reserve(spt + n); ptperm.reserve(spt);
-        obskf.reserve(sobs); obspt.reserve(sobs); slotperm.reserve(sobs); uv.reserve(2 * sobs); ow.reserve(sobs);
+        pt.reserve(3 * spt); ptref.reserve(spt); ptobs.reserve(spt + n); lmask.reserve(spt);
+        obskf.reserve(sobs); uv.reserve(2 * sobs); ow.reserve(sobs);
         imui.reserve(simu); imuj.reserve(simu); meas.reserve(61 * simu); info.reserve(81 * simu);
         pair_a.reserve(spair); pair_b.reserve(spair); offpair.reserve(spair); pairmask.reserve(spair);
-        item_begin.reserve(spair + n); pimu_begin.reserve(spair + n);
+        pimu_begin.reserve(spair + n);
     }
     const bool pristine = use_left_looking(n);
     h->ll_mode = pristine;
@@ -613,10 +579,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         });
         t_struct += now_ms() - ts0;
         if (bad.load()) return -1;
-        if (chunk0 == 0) {   // items: extrapolate from the first chunk
-            size_t it = 0, tp = 0;
-            for (auto& x : sts) { it += x.items.size(); tp += x.tpairs.size() + x.klist.size(); }
-            items.reserve((size_t)(1.1 * it / cn * n) + 1024);
+        if (chunk0 == 0) {   // tile lists: extrapolate from the first chunk
+            size_t tp = 0;
+            for (auto& x : sts) tp += x.tpairs.size() + x.klist.size();
             tlpair.reserve((size_t)(1.1 * tp / cn * n) + 1024); tlk.reserve((size_t)(1.1 * tp / cn * n) + 1024);
         }
         // (2)
@@ -645,27 +610,14 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             d.its[0] = P->its_stage1; d.its[1] = P->its_stage2;
             d.kf0 = kf0; d.pt0 = pt0; d.obs0 = obs0; d.imu0 = imu0;
             d.pair0 = pair0; d.n_pairs = d.n_free * (d.n_free + 1) / 2;
-            d.item0 = item0; d.pimu0 = pimu0; d.vec0 = vec0; d.part0 = part0;
+            Structure& st = sts[w - chunk0];
+            d.item0 = (int)item0; d.pimu0 = pimu0; d.vec0 = vec0; d.part0 = part0;
+            d.mask0 = mask0; d.mwords = st.mwords;
             d.n_part_lin = (d.n_pt + 63) / 64;
             if (P->variant == VBA_VARIANT_PRV_IDP) {
-                // k_lin2 work split: runs of consecutive landmarks with <= 256 edges and <= 64 landmarks per workgroup
-                // (one 16-B record per workgroup: first / end landmark, first / end edge)
                 d.lb0 = (int)(linblk.size() / 4);
-                int nb2 = 0, p = 0;
-                while (p < d.n_pt) {
-                    const int p_first = p;
-                    nb2++;
-                    int ne = 0, np2 = 0;
-                    while (p < d.n_pt && np2 < 64) {
-                        const int k = P->pt_obs_begin[p + 1] - P->pt_obs_begin[p];
-                        if (k > 256) return fail(h, "a landmark with more than 256 observations is not supported");
-                        if (ne + k > 256) break;
-                        ne += k; np2++; p++;
-                    }
-                    linblk.push_back(p_first); linblk.push_back(p);
-                    linblk.push_back(P->pt_obs_begin[p_first]); linblk.push_back(P->pt_obs_begin[p]);
-                }
-                d.n_part_lin = nb2;
+                linblk.insert(linblk.end(), st.linblk.begin(), st.linblk.end());
+                d.n_part_lin = (int)(st.linblk.size() / 4);
             }
             d.S0 = (long long)S_tot;
             for (int i = 0; i < 4; i++) d.K[i] = P->K[i];
@@ -674,7 +626,6 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             d.inv_bg = P->inv_bg_rw2; d.inv_ba = P->inv_ba_rw2;
             d.hub_vis = P->huber_vis; d.hub_prv = P->huber_prv; d.hub_bias = P->huber_bias;
             d.chi2_th = P->chi2_th; d.depth_min = P->depth_min; d.rho_min = P->rho_min;
-            Structure& st = sts[w - chunk0];
             d.tl_step0 = (int)tlstep.size(); d.tl_pair0 = (int)tlpair.size(); d.tl_pan0 = (int)tlpan.size();
             tlstep.insert(tlstep.end(), st.step_begin.begin(), st.step_begin.end());
             tlpanb.insert(tlpanb.end(), st.pan_begin.begin(), st.pan_begin.end());
@@ -696,17 +647,18 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             h->tile_updates += (double)st.tpairs.size();
             h->win_tiles[w] = (int)st.tpairs.size();
             if ((int)st.pair_a.size() != d.n_pairs || (int)st.off_pair.size() != d.n_pairs || (int)st.pair_mask.size() != d.n_pairs ||
-                (int)st.item_begin.size() != d.n_pairs + 1 || (int)st.pimu_begin.size() != d.n_pairs + 1 ||
-                (int)st.obs_pt.size() != d.n_obs || (int)st.slot_perm.size() != d.n_obs || (int)st.pt_perm.size() != d.n_pt)
+                (int)st.pimu_begin.size() != d.n_pairs + 1 || st.lmask.size() != (size_t)d.n_pt * st.mwords)
                 return fail(h, "internal: structure sizes");
             {   // the per-window offsets are 32-bit: refuse a batch that would overflow them instead of wrapping
                 const long long lim = 2147483647LL - 64;
-                if ((long long)obs0 + d.n_obs > lim || (long long)item0 + (long long)(st.items.size() / 2) > lim ||
+                if ((long long)obs0 + d.n_obs > lim || item0 + st.item_cap > lim ||
                     (long long)tlpair.size() > lim || (long long)tlk.size() > lim || (long long)vec0 + d.nS > lim)
                     return fail(h, "batch too large for 32-bit offsets: split it into several calls");
             }
             kf0 += d.n_kf; pt0 += d.n_pt; obs0 += d.n_obs; imu0 += d.n_imu;
-            pair0 += d.n_pairs; item0 += (int)(st.items.size() / 2); pimu0 += (int)(st.pimu.size() / 2);
+            pair0 += d.n_pairs; item0 += st.item_cap; pimu0 += (int)(st.pimu.size() / 2);
+            mask0 += (long long)d.n_pt * st.mwords;
+            max_kf = std::max(max_kf, d.n_kf);
             vec0 += d.nS;
             const int obs_blk = (d.n_obs + 63) / 64;
             part0 += std::max(3 * std::max(d.n_part_lin, (d.n_pt + 63) / 64), 2 * obs_blk) + 2;
@@ -729,12 +681,12 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         // (3)
         const int nw = chunk0 + cn;   // windows packed so far
         pose.resize(7 * (size_t)kf0); vel.resize(3 * (size_t)kf0); bias.resize(12 * (size_t)kf0); kffix.resize(kf0);
-        pt.resize(3 * (size_t)pt0); ptref.resize(pt0); ptperm.resize(pt0); ptobs.resize((size_t)pt0 + nw);
-        obskf.resize(obs0); obspt.resize(obs0); slotperm.resize(obs0); uv.resize(2 * (size_t)obs0); ow.resize(obs0);
+        pt.resize(3 * (size_t)pt0); ptref.resize(pt0); lmask.resize((size_t)mask0); ptobs.resize((size_t)pt0 + nw);
+        obskf.resize(obs0); uv.resize(2 * (size_t)obs0); ow.resize(obs0);
         imui.resize(imu0); imuj.resize(imu0); meas.resize(61 * (size_t)imu0); info.resize(81 * (size_t)imu0);
         pair_a.resize(pair0); pair_b.resize(pair0); offpair.resize(pair0); pairmask.resize(pair0);
-        item_begin.resize((size_t)pair0 + nw); pimu_begin.resize((size_t)pair0 + nw);
-        items.resize(2 * (size_t)item0); pimu.resize(2 * (size_t)pimu0);
+        pimu_begin.resize((size_t)pair0 + nw);
+        pimu.resize(2 * (size_t)pimu0);
         if (!G.ok()) return fail(h, "out of pinned host memory (upload staging)");
         // (4)
         run_pool(cn, [&](int q) {
@@ -754,9 +706,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             else std::fill_n(ptref.data() + d.pt0, d.n_pt, 0);
             put(ptobs.data() + d.pt0 + w, P->pt_obs_begin, (size_t)d.n_pt + 1);
             put(obskf.data() + d.obs0, P->obs_kf, d.n_obs);
-            put(obspt.data() + d.obs0, st.obs_pt.data(), d.n_obs);
-            put(slotperm.data() + d.obs0, st.slot_perm.data(), d.n_obs);
-            put(ptperm.data() + d.pt0, st.pt_perm.data(), d.n_pt);
+            put(lmask.data() + d.mask0, st.lmask.data(), st.lmask.size());
             put(uv.data() + 2 * (size_t)d.obs0, P->obs_uv, 2 * (size_t)d.n_obs);
             put(ow.data() + d.obs0, P->obs_w, d.n_obs);
             if (d.n_imu) {
@@ -772,8 +722,6 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
                 for (int pi = 0; pi < d.n_pairs; pi++)
                     if (st.pair_a[pi] != st.pair_b[pi] && st.pimu_begin[pi + 1] == st.pimu_begin[pi]) st.pair_mask[pi] &= 1;
             put(pairmask.data() + d.pair0, st.pair_mask.data(), d.n_pairs);
-            put(item_begin.data() + d.pair0 + w, st.item_begin.data(), (size_t)d.n_pairs + 1);
-            put(items.data() + 2 * (size_t)d.item0, st.items.data(), st.items.size());
             put(pimu_begin.data() + d.pair0 + w, st.pimu_begin.data(), (size_t)d.n_pairs + 1);
             put(pimu.data() + 2 * (size_t)d.pimu0, st.pimu.data(), st.pimu.size());
         });
@@ -789,7 +737,12 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_POSE, pose.size() * 8) || dalloc(h, BUF_VEL, vel.size() * 8) || dalloc(h, BUF_BIAS, bias.size() * 8)) return -1;
     if (dalloc(h, BUF_POSEBK, pose.size() * 8) || dalloc(h, BUF_VELBK, vel.size() * 8) || dalloc(h, BUF_BIASBK, bias.size() * 8)) return -1;
     if (dalloc(h, BUF_KFR, (size_t)kf0 * 12 * 8) || dalloc(h, BUF_PT, pt.size() * 8) || dalloc(h, BUF_PTBK, pt.size() * 8)) return -1;
-    if (h2d(h, BUF_PTREF, ptref) || h2d(h, BUF_PTOBS, ptobs) || h2d(h, BUF_OBSKF, obskf) || h2d(h, BUF_OBSPT, obspt)) return -1;
+    if (h2d(h, BUF_PTREF, ptref) || h2d(h, BUF_PTOBS, ptobs) || h2d(h, BUF_OBSKF, obskf) || h2d(h, BUF_LMASK, lmask)) return -1;
+    // built on the device (vba_structure.h): record orders, keyframe segments, item lists; + the scratch of the build
+    if (dalloc(h, BUF_OBSPT, (size_t)obs0 * 4) || dalloc(h, BUF_SLOTPERM, (size_t)obs0 * 4) || dalloc(h, BUF_PTPERM, (size_t)pt0 * 4)) return -1;
+    if (dalloc(h, BUF_KFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_REFSEG, ((size_t)kf0 + n) * 4)) return -1;
+    if (dalloc(h, BUF_ITEMBEG, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMMID, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMS, (size_t)item0 * 8)) return -1;
+    if (dalloc(h, BUF_STKEY, (size_t)pt0 * 4) || dalloc(h, BUF_LMORDER, (size_t)pt0 * 4) || dalloc(h, BUF_SLOTOBS, (size_t)obs0 * 4) || dalloc(h, BUF_PTINV, (size_t)pt0 * 4)) return -1;
     if (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow)) return -1;
     if (dalloc(h, BUF_LVL, (size_t)obs0) || dalloc(h, BUF_CHI2E, (size_t)obs0 * 8) || dalloc(h, BUF_DEPTH, (size_t)obs0 * 8)) return -1;
     const bool idp = probs[0]->variant == VBA_VARIANT_PRV_IDP;
@@ -802,10 +755,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
     if (dalloc(h, BUF_LF, S_tot * 8) || dalloc(h, BUF_YV, (size_t)vec0 * 8)) return -1;
     if (h2d(h, BUF_TLSTEP, tlstep) || h2d(h, BUF_TLPAIR, tlpair) || h2d(h, BUF_TLPANB, tlpanb) || h2d(h, BUF_TLPAN, tlpan)) return -1;
-    if (h2d(h, BUF_TLKB, tlkb) || h2d(h, BUF_TLK, tlk) || h2d(h, BUF_SLOTPERM, slotperm) || h2d(h, BUF_PTPERM, ptperm)) return -1;
+    if (h2d(h, BUF_TLKB, tlkb) || h2d(h, BUF_TLK, tlk)) return -1;
     if (dalloc(h, BUF_DVEC, (size_t)vec0 * 8) || dalloc(h, BUF_WINV, (size_t)n * 1024 * 8)) return -1;
     if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
-    if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b) || h2d(h, BUF_ITEMBEG, item_begin) || h2d(h, BUF_ITEMS, items)) return -1;
+    if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b)) return -1;
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d(h, BUF_LINBLK, linblk)) return -1;
     if (h2d(h, BUF_OFFPAIR, offpair) || h2d(h, BUF_PAIRMASK, pairmask)) return -1;
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
@@ -843,7 +796,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.slot_perm = dp<int>(h, BUF_SLOTPERM); B.pt_perm = dp<int>(h, BUF_PTPERM);
     B.var_act = dp<int>(h, BUF_VARACT);
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
-    B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS);
+    B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS); B.item_mid = dp<int>(h, BUF_ITEMMID);
+    B.lmask = dp<unsigned long long>(h, BUF_LMASK); B.kf_seg = dp<int>(h, BUF_KFSEG); B.ref_seg = dp<int>(h, BUF_REFSEG);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
     B.lin_blk = dp<int>(h, BUF_LINBLK);
     B.off_pair = dp<int>(h, BUF_OFFPAIR); B.pair_mask = dp<int>(h, BUF_PAIRMASK);
@@ -855,6 +809,20 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.dbg = dp<double>(h, BUF_DBG);
     static_assert(VBA_NB <= 64, "k_init_pads covers the pads with one wave");
     hipLaunchKernelGGL(k_init_pads, dim3(n), dim3(64), 0, h->stream, B);
+    {   // the device half of the structure build
+        StBuild T;
+        T.obs_pt = dp<int>(h, BUF_OBSPT); T.slot_perm = dp<int>(h, BUF_SLOTPERM); T.pt_perm = dp<int>(h, BUF_PTPERM);
+        T.kf_seg = dp<int>(h, BUF_KFSEG); T.ref_seg = dp<int>(h, BUF_REFSEG);
+        T.item_begin = dp<int>(h, BUF_ITEMBEG); T.item_mid = dp<int>(h, BUF_ITEMMID); T.items = dp<int>(h, BUF_ITEMS);
+        T.st_key = dp<int>(h, BUF_STKEY); T.lm_order = dp<int>(h, BUF_LMORDER); T.slot_obs = dp<int>(h, BUF_SLOTOBS); T.pt_inv = dp<int>(h, BUF_PTINV);
+        const size_t sh_order = 3 * ((size_t)max_kf + 1) * sizeof(int), sh_row = 2 * (size_t)std::max(1, h->max_free) * sizeof(int);
+        if (sh_order > 60000 || sh_row > 60000) return fail(h, "window with too many keyframes for the structure build");
+        hipLaunchKernelGGL(k_st_order, dim3(n), dim3(256), sh_order, h->stream, B, T);
+        hipLaunchKernelGGL(k_st_count, dim3(h->max_free, n), dim3(64), sh_row, h->stream, B, T, h->max_free);
+        hipLaunchKernelGGL(k_st_scan, dim3(n), dim3(256), 0, h->stream, B, T);
+        hipLaunchKernelGGL(k_st_fill, dim3(h->max_free, n), dim3(64), sh_row, h->stream, B, T, h->max_free);
+        HIPCHK(h, hipGetLastError());
+    }
     const double t_enq = now_ms();
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (timing) fprintf(stderr, "[vba] upload %d windows: total %.3f ms (structure %.3f, pack %.3f, alloc+H2D enqueue %.3f, sync %.3f)\n", n,
@@ -867,28 +835,29 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
 // ---- the launch schedule ------------------------------------------------------------------------------
 void enqueue_solve_iteration(Handle* h) {
     const Batch& B = h->B;
-    const int n = h->n_win;
+    const int n = h->n_win;         // windows of this group: grid sizes
+    const int rn = h->regime_n;     // windows of the batch: kernel choice
     const bool idp = h->variant == VBA_VARIANT_PRV_IDP;
     {
         ProfScope ps(h, VBA_PROF_SCHUR);
         const int ngrp = (n >= 8) ? 8 * ((n + 7) / 8) : n;
         if (idp) {
             static const int fused_schur = getenv("VBA_SCHUR_SPLIT") ? 0 : 1;
-            if (n >= 8 && fused_schur) {
+            if (rn >= 8 && fused_schur) {
                 hipLaunchKernelGGL(k_schur_all, dim3((h->max_free + h->max_quads) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_quads);
             } else {
             hipLaunchKernelGGL(k_schur_diag, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free);
-            if (n >= 8) hipLaunchKernelGGL(k_schur_off, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
+            if (rn >= 8) hipLaunchKernelGGL(k_schur_off, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
             else hipLaunchKernelGGL(k_schur_off_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
             }
         } else {
             hipLaunchKernelGGL(k_dinv, dim3(h->max_pt_blk, n), dim3(64), 0, h->stream, B);
             static const int fused_schur3 = getenv("VBA_SCHUR_FUSE3") ? 1 : 0;  // measured on C2: no gain for the 192-B XYZ records
-            if (n >= 8 && fused_schur3) {
+            if (rn >= 8 && fused_schur3) {
                 hipLaunchKernelGGL(k_schur_all3, dim3((h->max_free + h->max_quads) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_quads);
             } else {
                 hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 0);
-                if (n >= 8) hipLaunchKernelGGL(k_schur_off3, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
+                if (rn >= 8) hipLaunchKernelGGL(k_schur_off3, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
                 else hipLaunchKernelGGL(k_schur_off3_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
             }
         }
@@ -897,7 +866,7 @@ void enqueue_solve_iteration(Handle* h) {
         ProfScope ps(h, VBA_PROF_FACTOR);
         static const int split_min = getenv("VBA_SPLIT_MIN") ? atoi(getenv("VBA_SPLIT_MIN")) : 64;
         const bool ll = h->ll_mode;  // decided for the whole batch at upload (S stays pristine, pair masks), also for its window groups
-        if (n >= split_min || ll) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
+        if (rn >= split_min || ll) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
             for (int k = 0; k < h->max_nb && ll; k++) {  // every tile read once, updated in registers, written once
                 hipLaunchKernelGGL(k_chol_diag_ll, dim3(n), dim3(64), 0, h->stream, B, k);
                 if (h->pan_grid[k] > 0) hipLaunchKernelGGL(k_chol_panel_ll, dim3(h->pan_grid[k], n), dim3(64), 0, h->stream, B, k);
@@ -1175,7 +1144,7 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     const int max_streams = std::min(14, want);
     int ngroups = 1;
     if (!h->profile && max_streams > 1 && n >= 8)
-        ngroups = std::max(1, std::min(max_streams, n / 4));
+        ngroups = std::max(1, std::min(max_streams, n / 8));   // a group never falls below the 8 windows of the XCD-aware mapping
     while ((int)h->xstreams.size() < ngroups - 1) {
         hipStream_t st;
         HIPCHK(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1504,7 +1473,8 @@ int vba_debug_buf_id(const char* name) {
     static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
-        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM"};
+        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
@@ -1552,7 +1522,7 @@ int vba_preintegrate(void* handle, int32_t n_edges, const int32_t* sample_begin,
 
 namespace {
 // Matrix::inverse() of the small dense matrices of the set-up code (Gauss-Jordan, partial pivoting)
-void inverse_host(int n, const double* A, double* Ai) {
+bool inverse_host(int n, const double* A, double* Ai) {
     double M[15][30];
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) { M[i][j] = A[i * n + j]; M[i][n + j] = (i == j) ? 1.0 : 0.0; }
@@ -1562,6 +1532,7 @@ void inverse_host(int n, const double* A, double* Ai) {
             if (std::fabs(M[r][c]) > std::fabs(M[p][c])) p = r;
         if (p != c)
             for (int j = 0; j < 2 * n; j++) std::swap(M[c][j], M[p][j]);
+        if (!(std::fabs(M[c][c]) > 0.0) || !std::isfinite(M[c][c])) return false;   // singular or non-finite: no information matrix
         const double inv = 1.0 / M[c][c];
         for (int j = 0; j < 2 * n; j++) M[c][j] *= inv;
         for (int r = 0; r < n; r++) {
@@ -1572,7 +1543,11 @@ void inverse_host(int n, const double* A, double* Ai) {
         }
     }
     for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) Ai[i * n + j] = M[i][n + j];
+        for (int j = 0; j < n; j++) {
+            Ai[i * n + j] = M[i][n + j];
+            if (!std::isfinite(Ai[i * n + j])) return false;
+        }
+    return true;
 }
 }  // namespace
 
@@ -1587,6 +1562,7 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
         if (!F || !out[f] || F->n_obs < 0 || (F->n_obs > 0 && (!F->obs_pw || !F->obs_uv || !F->obs_w || !out[f]->outlier)))
             return fail(h, "vba_pose_optimize: bad frame");
         if (F->last_is_frame < 0 || F->last_is_frame > 2) return fail(h, "vba_pose_optimize: unknown frame kind");
+        if (F->last_is_frame == VBA_FRAME_FRAME && F->n_obs_last < 0) return fail(h, "vba_pose_optimize: negative n_obs_last");
         if (F->last_is_frame == VBA_FRAME_FRAME && F->n_obs_last > 0 && (!F->last_pw || !F->last_uv || !F->last_w)) return fail(h, "vba_pose_optimize: bad last frame");
         n_tot += (size_t)F->n_obs + (F->last_is_frame == VBA_FRAME_FRAME ? (size_t)F->n_obs_last : 0);
     }
@@ -1617,6 +1593,7 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
             d.last0 = (int)o; o += d.n_last;
         }
     }
+    std::atomic<int> bad_cov(0);
     auto pack = [&](int f) {
         const vba_frame_problem* F = inout[f];
         FrameDesc& d = desc[f];
@@ -1639,7 +1616,8 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
         quat_to_R_host(F->T_cb + 3, d.Rcb);
         for (int i = 0; i < 3; i++) { d.tcb[i] = F->T_cb[i]; d.g[i] = F->g_w[i]; }
         std::memcpy(d.meas, F->imu_meas, sizeof d.meas);
-        if (F->last_is_frame != VBA_FRAME_VISION) inverse_host(9, F->imu_cov_pvphi, d.info_pvr);   // Matrix9d InvCovPVR = imupreint.getCovPVPhi().inverse(), :2103
+        if (F->last_is_frame != VBA_FRAME_VISION && !inverse_host(9, F->imu_cov_pvphi, d.info_pvr))   // Matrix9d InvCovPVR = imupreint.getCovPVPhi().inverse(), :2103
+            bad_cov.store(1);
         d.inv_bg = F->inv_bg_rw2; d.inv_ba = F->inv_ba_rw2;
         d.hub_prior = (double)(float)std::sqrt(30.5779); d.hub_pvr = (double)(float)std::sqrt(21.666);
         d.hub_bias = (double)(float)std::sqrt(16.812); d.hub_mono = (double)(float)std::sqrt(5.991);
@@ -1653,6 +1631,7 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
         work();
         for (auto& t : pool) t.join();
     }
+    if (bad_cov.load()) return fail(h, "vba_pose_optimize: imu_cov_pvphi is singular or not finite");
     char* base = reinterpret_cast<char*>(h->pose_arena.p);
     PoseBatch B;
     B.desc = reinterpret_cast<const FrameDesc*>(base);

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <iostream>
+#include <chrono>
 #include <thread>
 
 namespace ORB_SLAM2 {
@@ -107,9 +108,11 @@ struct StopMirror {
         if (!src) return;
         flag = *src ? 1 : 0;
         th = std::thread([this, src] {
+            // the device looks at the flag between outer iterations (~0.25 ms apart for a local window): polling a few
+            // times per iteration is as prompt as g2o's own check and leaves the core to the Tracking thread
             while (!done.load()) {
-                if (*reinterpret_cast<volatile bool*>(src)) flag = 1;
-                std::this_thread::yield();
+                if (*reinterpret_cast<volatile bool*>(src)) { flag = 1; break; }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
         });
     }

@@ -78,3 +78,22 @@ def test_c1_vision_only_pose_optimization_matches_oracle(ba, oracle):
         assert rr.its_done == rq.its_done and (rr.outlier == rq.outlier).all()
         assert np.abs(rr.nav[:7] - rq.nav[:7]).max() <= 1e-6
     assert (rs[-1].nav == r.nav).all()
+
+
+def test_bad_frames_are_refused_with_a_message(ba):
+    """negative n_obs_last and a singular / non-finite preintegration covariance fail the call instead of corrupting memory or
+    returning NaN information with VBA_OK"""
+    import ctypes as C
+    from mc_slam_amd import abi
+    f = synth.make_frame(seed=45, n_obs=60, last_is_frame=True)
+    packed = ba.pose_pack([f])
+    packed[1][0].n_obs_last = -5
+    assert ba.lib.vba_pose_optimize(ba.h, 1, packed[3], packed[4]) != 0
+    assert b"n_obs_last" in ba.lib.vba_last_error(ba.h)
+    for bad in (np.zeros((9, 9)), np.full((9, 9), np.nan)):
+        g = synth.make_frame(seed=46, n_obs=60)
+        g.imu_cov_pvphi = bad
+        with pytest.raises(RuntimeError, match="singular or not finite"):
+            ba.pose_optimize([g])
+    r = ba.pose_optimize([synth.make_frame(seed=46, n_obs=60)])[0]       # the handle is still usable
+    assert r.status == 0 and r.n_inliers > 0
