@@ -17,7 +17,8 @@
 
 struct StBuild {   // what the build writes (the solve reads the same arrays through Batch, as const)
     int *obs_pt, *slot_perm, *pt_perm, *kf_seg, *ref_seg, *item_begin, *item_mid, *items;
-    int *st_key, *lm_order, *slot_obs, *pt_inv;   // scratch: first keyframe of a track, landmark at rank q, observation in slot s, landmark in record r
+    int *st_key, *lm_order, *slot_obs, *pt_inv;   // scratch: first keyframe of a track, landmark at rank q, landmark of the record in slot s, landmark in record r
+    int *key_seg, *tslot;                         // scratch: landmarks per first keyframe (starts); per landmark its slots in keyframe order
 };
 
 typedef unsigned long long u64_t;
@@ -29,15 +30,39 @@ DEVI u64_t wave_or64(u64_t v) {
 }
 DEVI u64_t lanes_below() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
-// record position of landmark p's observation from keyframe b (the host has checked that there is exactly one)
-DEVI int st_slot_of(const Batch& B, const StBuild& T, const WinDesc& d, const int* ob, int p, int b) {
-    for (int o = ob[p]; o < ob[p + 1]; o++)
-        if (B.obs_kf[d.obs0 + o] == b) return T.slot_perm[d.obs0 + o];
-    return 0;
+// record position of landmark p's observation from keyframe b: the landmark's slots are kept in KEYFRAME order behind its
+// CSR row (tslot), so the position inside the row is the number of observing keyframes below b
+DEVI int st_slot_of(const StBuild& T, const WinDesc& d, const u64_t* LM, const int* ob, int p, int b) {
+    const u64_t* M = LM + (size_t)p * d.mwords;
+    int r = __popcll(M[b >> 6] & ((1ull << (b & 63)) - 1ull));
+    for (int wd = 0; wd < (b >> 6); wd++) r += __popcll(M[wd]);
+    return T.tslot[d.obs0 + ob[p] + r];
 }
 
-// One workgroup per window: histograms -> segment starts, then the two ranked walks.
-__global__ void __launch_bounds__(256) k_st_order(Batch B, StBuild T) {
+// The first eight slots of a landmark's row, fetched together BEFORE the walk over the partner keyframes: the lookups inside
+// that walk then cost no memory round trip (tracks longer than eight fall back to the table)
+struct SlotRow {
+    int v[8];
+    DEVI void load(const StBuild& T, const WinDesc& d, const int* ob, int p, bool valid) {
+        const int o0 = valid ? ob[p] : 0, n = valid ? ob[p + 1] - o0 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (i < n) ? T.tslot[d.obs0 + o0 + i] : 0;
+    }
+    DEVI int at(const StBuild& T, const WinDesc& d, const u64_t* LM, const int* ob, int p, int b) const {
+        const u64_t* M = LM + (size_t)p * d.mwords;
+        int r = __popcll(M[b >> 6] & ((1ull << (b & 63)) - 1ull));
+        for (int wd = 0; wd < (b >> 6); wd++) r += __popcll(M[wd]);
+        if (r >= 8) return T.tslot[d.obs0 + ob[p] + r];
+        int x = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) x = (r == i) ? v[i] : x;
+        return x;
+    }
+};
+
+// 1. One workgroup per window: first keyframe of every track, observation -> landmark, and the three histograms with their
+//    prefix sums = the segment starts (landmarks per first keyframe, observations per observer, landmarks per reference).
+__global__ void __launch_bounds__(256) k_st_hist(Batch B, StBuild T) {
     extern __shared__ int sh[];
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
@@ -61,6 +86,7 @@ __global__ void __launch_bounds__(256) k_st_order(Batch B, StBuild T) {
         atomicAdd(&hk[key + 1], 1);   // integer counts: the result does not depend on the order of the adds
         if (idp) atomicAdd(&hr[ref + 1], 1);
         for (int o = ob[p]; o < ob[p + 1]; o++) T.obs_pt[d.obs0 + o] = p;
+        if (!idp) T.pt_perm[d.pt0 + p] = p;   // XYZ landmarks have no reference keyframe: point records stay in landmark order
     }
     for (int o = t; o < d.n_obs; o += 256) atomicAdd(&ho[B.obs_kf[d.obs0 + o] + 1], 1);
     __syncthreads();
@@ -70,56 +96,73 @@ __global__ void __launch_bounds__(256) k_st_order(Batch B, StBuild T) {
     }
     __syncthreads();
     for (int i = t; i <= nk; i += 256) {
+        T.key_seg[d.kf0 + d.win + i] = hk[i];
         T.kf_seg[d.kf0 + d.win + i] = ho[i];
         T.ref_seg[d.kf0 + d.win + i] = idp ? hr[i] : 0;
     }
-    const int wave = t >> 6, lane = t & 63;
+}
+
+// 2. landmarks by (first keyframe, index): one wave per (window, bucket) walks the landmarks in index order
+__global__ void __launch_bounds__(64) k_st_rank_lm(Batch B, StBuild T) {
+    const int w = blockIdx.y, k = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    if (k >= d.n_kf) return;
+    const int npt = d.n_pt, lane = threadIdx.x;
+    int base = T.key_seg[d.kf0 + d.win + k];
+    const int end = T.key_seg[d.kf0 + d.win + k + 1];
     const u64_t lt = lanes_below();
-    // A. landmarks by (first keyframe, index): one wave per bucket walks the landmarks in index order
-    for (int k = wave; k < nk; k += 4) {
-        int base = hk[k];
-        const int end = hk[k + 1];
-        for (int c = 0; c < npt && base < end; c += 64) {
-            const int p = c + lane;
-            const bool has = p < npt && T.st_key[d.pt0 + p] == k;
-            const u64_t m = __ballot(has);
-            if (has) T.lm_order[d.pt0 + base + __popcll(m & lt)] = p;
-            base += __popcll(m);
-        }
+    for (int c = 0; c < npt && base < end; c += 64) {
+        const int p = c + lane;
+        const bool has = p < npt && T.st_key[d.pt0 + p] == k;
+        const u64_t m = __ballot(has);
+        if (has) T.lm_order[d.pt0 + base + __popcll(m & lt)] = p;
+        base += __popcll(m);
     }
-    __syncthreads();
-    // B. observation records by (observing keyframe, lm_order) and landmark records by (reference keyframe, lm_order): one
-    //    wave per keyframe walks the landmarks in lm_order
-    for (int k = wave; k < nk; k += 4) {
-        int bo = ho[k], br = hr[k];
-        const int eo = ho[k + 1], er = hr[k + 1];
-        const int kw = k >> 6, kb = k & 63;
-        for (int c = 0; c < npt && (bo < eo || br < er); c += 64) {
-            const int q = c + lane;
-            const bool valid = q < npt;
-            const int p = valid ? T.lm_order[d.pt0 + q] : 0;
-            const bool haso = valid && ((LM[(size_t)p * mw + kw] >> kb) & 1ull);
-            const u64_t mo = __ballot(haso);
-            if (haso) {
-                const int slot = bo + __popcll(mo & lt);
-                int o = ob[p];
-                while (B.obs_kf[d.obs0 + o] != k) o++;
-                T.slot_perm[d.obs0 + o] = slot;
-                T.slot_obs[d.obs0 + slot] = o;
-            }
-            bo += __popcll(mo);
-            const bool hasr = valid && idp && B.pt_ref[d.pt0 + p] == k;
-            const u64_t mr = __ballot(hasr);
-            if (hasr) {
-                const int r = br + __popcll(mr & lt);
-                T.pt_perm[d.pt0 + p] = r;
-                T.pt_inv[d.pt0 + r] = p;
-            }
-            br += __popcll(mr);
+}
+
+// 3. observation records by (observing keyframe, lm_order) and landmark records by (reference keyframe, lm_order): one wave
+//    per (window, keyframe) walks the landmarks in lm_order
+__global__ void __launch_bounds__(64) k_st_rank_rec(Batch B, StBuild T) {
+    const int w = blockIdx.y, k = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    if (k >= d.n_kf) return;
+    const int npt = d.n_pt, lane = threadIdx.x, mw = d.mwords;
+    const bool idp = d.variant == 2;
+    const int* ob = B.pt_obs_begin + d.pt0 + d.win;
+    const u64_t* LM = B.lmask + d.mask0;
+    int bo = T.kf_seg[d.kf0 + d.win + k], br = T.ref_seg[d.kf0 + d.win + k];
+    const int eo = T.kf_seg[d.kf0 + d.win + k + 1], er = T.ref_seg[d.kf0 + d.win + k + 1];
+    const int kw = k >> 6, kb = k & 63;
+    const u64_t lt = lanes_below();
+    // a track that contains k starts at k or before: only the landmarks of the first k + 1 buckets of lm_order can be members
+    const int q_end = min(npt, T.key_seg[d.kf0 + d.win + k + 1]);
+    for (int c = 0; c < q_end && (bo < eo || br < er); c += 64) {
+        const int q = c + lane;
+        const bool valid = q < q_end;
+        const int p = valid ? T.lm_order[d.pt0 + q] : 0;
+        const u64_t* M = LM + (size_t)p * mw;
+        const bool haso = valid && ((M[kw] >> kb) & 1ull);
+        const u64_t mo = __ballot(haso);
+        if (haso) {
+            const int slot = bo + __popcll(mo & lt);
+            int o = ob[p];
+            while (B.obs_kf[d.obs0 + o] != k) o++;
+            T.slot_perm[d.obs0 + o] = slot;
+            T.slot_obs[d.obs0 + slot] = p;   // the landmark of the record in this slot
+            int r = __popcll(M[kw] & ((1ull << kb) - 1ull));
+            for (int wd = 0; wd < kw; wd++) r += __popcll(M[wd]);
+            T.tslot[d.obs0 + ob[p] + r] = slot;   // the landmark's slots in keyframe order (st_slot_of)
         }
+        bo += __popcll(mo);
+        const bool hasr = valid && idp && B.pt_ref[d.pt0 + p] == k;
+        const u64_t mr = __ballot(hasr);
+        if (hasr) {
+            const int r = br + __popcll(mr & lt);
+            T.pt_perm[d.pt0 + p] = r;
+            T.pt_inv[d.pt0 + r] = p;
+        }
+        br += __popcll(mr);
     }
-    if (!idp)   // XYZ landmarks have no reference keyframe: their point records stay in landmark order
-        for (int p = t; p < npt; p += 256) T.pt_perm[d.pt0 + p] = p;
 }
 
 // One wave per (window, free keyframe a): walks the records of a -- its observation records in slot order, then the landmark
@@ -159,9 +202,10 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
     for (int c = kseg[a]; c < kseg[a + 1]; c += 64) {
         const int slot = c + lane;
         const bool valid = slot < kseg[a + 1];
-        const int o = valid ? T.slot_obs[d.obs0 + slot] : 0;
-        const int p = valid ? T.obs_pt[d.obs0 + o] : 0;
+        const int p = valid ? T.slot_obs[d.obs0 + slot] : 0;
         const int r = (valid && idp) ? B.pt_ref[d.pt0 + p] : -1;
+        SlotRow sr;
+        if (FILL) sr.load(T, d, ob, p, valid);
         for (int wd = a >> 6; wd < mw; wd++) {
             const u64_t rg = range(wd);
             if (!rg) continue;
@@ -175,7 +219,7 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
                 const bool h0 = (Mr >> bb) & 1ull, h1 = (rb >> bb) & 1ull;
                 const u64_t m0 = __ballot(h0), m1 = __ballot(h1);
                 if (FILL) {
-                    if (h0) items[c0[b] + __popcll(m0 & lt)] = make_int2(slot, st_slot_of(B, T, d, ob, p, b));
+                    if (h0) items[c0[b] + __popcll(m0 & lt)] = make_int2(slot, sr.at(T, d, LM, ob, p, b));
                     if (h1) items[c1[b] + __popcll(m1 & lt)] = make_int2(slot, d.n_obs + T.pt_perm[d.pt0 + p]);
                 }
                 __syncthreads();   // one wave: orders the LDS reads above before lane 0's update
@@ -190,6 +234,8 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
             const int rec = c + lane;
             const bool valid = rec < rseg[a + 1];
             const int p = valid ? T.pt_inv[d.pt0 + rec] : 0;
+            SlotRow sr;
+            if (FILL) sr.load(T, d, ob, p, valid);
             for (int wd = a >> 6; wd < mw; wd++) {
                 const u64_t rg = range(wd);
                 if (!rg) continue;
@@ -201,7 +247,7 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
                     const int b = 64 * wd + bb;
                     const bool h1 = (Mr >> bb) & 1ull;
                     const u64_t m1 = __ballot(h1);
-                    if (FILL && h1) items[c1[b] + __popcll(m1 & lt)] = make_int2(d.n_obs + rec, st_slot_of(B, T, d, ob, p, b));
+                    if (FILL && h1) items[c1[b] + __popcll(m1 & lt)] = make_int2(d.n_obs + rec, sr.at(T, d, LM, ob, p, b));
                     __syncthreads();
                     if (lane == 0) c1[b] += __popcll(m1);
                     __syncthreads();

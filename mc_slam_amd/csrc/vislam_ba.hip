@@ -21,6 +21,7 @@
 #include <string>
 #include <atomic>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -123,12 +124,15 @@ struct Staging {
     PinVec<int> ptref, ptobs, obskf, imui, imuj, pair_a, pair_b, pimu_begin, pimu;
     PinVec<int> offpair, pairmask;
     PinVec<unsigned long long> lmask;
+    PinVec<int> s_int[7];        // pinned copies of the small host-built lists (tile lists, k_lin2 runs)
+    PinVec<WinDesc> s_desc;
     PinVec<double> dl_pose, dl_vel, dl_bias, dl_pt, dl_chi2;
     PinVec<unsigned char> dl_outl;
     template <typename F> void each(F f) {
         f(pose); f(vel); f(bias); f(pt); f(uv); f(ow); f(meas); f(info); f(kffix);
         f(ptref); f(ptobs); f(obskf); f(imui); f(imuj); f(pair_a); f(pair_b); f(pimu_begin); f(pimu);
-        f(offpair); f(pairmask); f(lmask);
+        f(offpair); f(pairmask); f(lmask); f(s_desc);
+        for (auto& v : s_int) f(v);
         f(dl_pose); f(dl_vel); f(dl_bias); f(dl_pt); f(dl_chi2); f(dl_outl);
     }
     bool ok() { bool r = true; each([&](auto& v) { r = r && v.ok; }); return r; }
@@ -141,7 +145,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_N
 };
 
 struct ProfEvt {
@@ -153,6 +157,10 @@ struct Handle {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<hipStream_t> xstreams;  // extra streams: one per window group of a large batch
+    // upload (H2D + structure build) and download (D2H) streams: the run stream itself, except for the lanes of
+    // vba_batch_solve, which share the parent's four streams -- run x 2, upload, download -- one per hardware queue
+    hipStream_t up_stream = nullptr, dl_stream = nullptr;
+    bool owns_streams = true;
     std::string err;
     DevBuf buf[BUF_N];
     DevBuf preint;  // arena of vba_preintegrate
@@ -465,11 +473,23 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     return 0;
 }
 
+// a pageable std::vector goes through a pinned copy first: a pageable hipMemcpyAsync is a synchronous, staged transfer
+template <typename T>
+int h2d_vec(Handle* h, int id, const std::vector<T>& v, PinVec<T>& pin) {
+    pin.clear();
+    pin.resize(v.size());
+    if (!pin.ok) return fail(h, "out of pinned host memory (upload staging)");
+    if (!v.empty()) memcpy(pin.data(), v.data(), v.size() * sizeof(T));
+    HIPCHK(h, h->buf[id].ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
+    if (!v.empty()) HIPCHK(h, hipMemcpyAsync(h->buf[id].p, pin.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->up_stream));
+    return 0;
+}
+
 template <typename V>
 int h2d(Handle* h, int id, const V& v) {
     typedef typename V::value_type T;
     HIPCHK(h, h->buf[id].ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
-    if (!v.empty()) HIPCHK(h, hipMemcpyAsync(h->buf[id].p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    if (!v.empty()) HIPCHK(h, hipMemcpyAsync(h->buf[id].p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->up_stream));
     return 0;
 }
 int dalloc(Handle* h, int id, size_t bytes) {
@@ -730,7 +750,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->variant = probs[0]->variant;
     const double t_pack = now_ms();
     // pads of S: identity on the padded diagonal, written once (the solve never touches them)
-    if (h2d(h, BUF_DESC, h->desc)) return -1;
+    if (h2d_vec(h, BUF_DESC, h->desc, G.s_desc)) return -1;
     if (dalloc(h, BUF_CTRL, sizeof(WinCtrl) * n)) return -1;
     if (h2d(h, BUF_POSE0, pose) || h2d(h, BUF_VEL0, vel) || h2d(h, BUF_BIAS0, bias) || h2d(h, BUF_PT0, pt)) return -1;
     if (h2d(h, BUF_KFFIX, kffix)) return -1;
@@ -740,7 +760,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (h2d(h, BUF_PTREF, ptref) || h2d(h, BUF_PTOBS, ptobs) || h2d(h, BUF_OBSKF, obskf) || h2d(h, BUF_LMASK, lmask)) return -1;
     // built on the device (vba_structure.h): record orders, keyframe segments, item lists; + the scratch of the build
     if (dalloc(h, BUF_OBSPT, (size_t)obs0 * 4) || dalloc(h, BUF_SLOTPERM, (size_t)obs0 * 4) || dalloc(h, BUF_PTPERM, (size_t)pt0 * 4)) return -1;
-    if (dalloc(h, BUF_KFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_REFSEG, ((size_t)kf0 + n) * 4)) return -1;
+    if (dalloc(h, BUF_KFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_REFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_KEYSEG, ((size_t)kf0 + n) * 4)) return -1;
+    if (dalloc(h, BUF_TSLOT, (size_t)obs0 * 4)) return -1;
     if (dalloc(h, BUF_ITEMBEG, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMMID, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMS, (size_t)item0 * 8)) return -1;
     if (dalloc(h, BUF_STKEY, (size_t)pt0 * 4) || dalloc(h, BUF_LMORDER, (size_t)pt0 * 4) || dalloc(h, BUF_SLOTOBS, (size_t)obs0 * 4) || dalloc(h, BUF_PTINV, (size_t)pt0 * 4)) return -1;
     if (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow)) return -1;
@@ -754,24 +775,24 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_IMUH, (size_t)imu0 * VBA_IMUH * 8) || dalloc(h, BUF_IMUCHI, (size_t)imu0 * 4 * 8)) return -1;
     if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
     if (dalloc(h, BUF_LF, S_tot * 8) || dalloc(h, BUF_YV, (size_t)vec0 * 8)) return -1;
-    if (h2d(h, BUF_TLSTEP, tlstep) || h2d(h, BUF_TLPAIR, tlpair) || h2d(h, BUF_TLPANB, tlpanb) || h2d(h, BUF_TLPAN, tlpan)) return -1;
-    if (h2d(h, BUF_TLKB, tlkb) || h2d(h, BUF_TLK, tlk)) return -1;
+    if (h2d_vec(h, BUF_TLSTEP, tlstep, G.s_int[0]) || h2d_vec(h, BUF_TLPAIR, tlpair, G.s_int[1]) || h2d_vec(h, BUF_TLPANB, tlpanb, G.s_int[2]) ||
+        h2d_vec(h, BUF_TLPAN, tlpan, G.s_int[3]) || h2d_vec(h, BUF_TLKB, tlkb, G.s_int[4]) || h2d_vec(h, BUF_TLK, tlk, G.s_int[5])) return -1;
     if (dalloc(h, BUF_DVEC, (size_t)vec0 * 8) || dalloc(h, BUF_WINV, (size_t)n * 1024 * 8)) return -1;
     if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
     if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b)) return -1;
-    if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d(h, BUF_LINBLK, linblk)) return -1;
+    if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d_vec(h, BUF_LINBLK, linblk, G.s_int[6])) return -1;
     if (h2d(h, BUF_OFFPAIR, offpair) || h2d(h, BUF_PAIRMASK, pairmask)) return -1;
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
     // S: zero everything once, identity on the pads
-    if (use_left_looking(n)) HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->stream));
+    if (use_left_looking(n)) HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->up_stream));
     for (int w = 0; w < n && !use_left_looking(n); w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
         const WinDesc& d = h->desc[w];
         if (d.nS > d.np)
-            HIPCHK(h, hipMemsetAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)d.np * d.nS, 0, (size_t)(d.nS - d.np) * d.nS * 8, h->stream));
+            HIPCHK(h, hipMemsetAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)d.np * d.nS, 0, (size_t)(d.nS - d.np) * d.nS * 8, h->up_stream));
     }
-    HIPCHK(h, hipMemsetAsync(h->buf[BUF_VEC].p, 0, (size_t)vec0 * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf[BUF_YV].p, 0, (size_t)vec0 * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->buf[BUF_BPOSE].p, 0, (size_t)vec0 * 16, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->buf[BUF_VEC].p, 0, (size_t)vec0 * 8, h->up_stream));
+    HIPCHK(h, hipMemsetAsync(h->buf[BUF_YV].p, 0, (size_t)vec0 * 8, h->up_stream));
+    HIPCHK(h, hipMemsetAsync(h->buf[BUF_BPOSE].p, 0, (size_t)vec0 * 16, h->up_stream));
     Batch& B = h->B;
     B.desc = dp<WinDesc>(h, BUF_DESC); B.ctrl = dp<WinCtrl>(h, BUF_CTRL); B.n_win = n;
     B.pose = dp<double>(h, BUF_POSE); B.vel = dp<double>(h, BUF_VEL); B.bias = dp<double>(h, BUF_BIAS); B.kfR = dp<double>(h, BUF_KFR);
@@ -808,7 +829,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_DBG, 4096)) return -1;
     B.dbg = dp<double>(h, BUF_DBG);
     static_assert(VBA_NB <= 64, "k_init_pads covers the pads with one wave");
-    hipLaunchKernelGGL(k_init_pads, dim3(n), dim3(64), 0, h->stream, B);
+    hipLaunchKernelGGL(k_init_pads, dim3(n), dim3(64), 0, h->up_stream, B);
     {   // the device half of the structure build
         StBuild T;
         T.obs_pt = dp<int>(h, BUF_OBSPT); T.slot_perm = dp<int>(h, BUF_SLOTPERM); T.pt_perm = dp<int>(h, BUF_PTPERM);
@@ -817,15 +838,18 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         T.st_key = dp<int>(h, BUF_STKEY); T.lm_order = dp<int>(h, BUF_LMORDER); T.slot_obs = dp<int>(h, BUF_SLOTOBS); T.pt_inv = dp<int>(h, BUF_PTINV);
         const size_t sh_order = 3 * ((size_t)max_kf + 1) * sizeof(int), sh_row = 2 * (size_t)std::max(1, h->max_free) * sizeof(int);
         if (sh_order > 60000 || sh_row > 60000) return fail(h, "window with too many keyframes for the structure build");
-        hipLaunchKernelGGL(k_st_order, dim3(n), dim3(256), sh_order, h->stream, B, T);
-        hipLaunchKernelGGL(k_st_count, dim3(h->max_free, n), dim3(64), sh_row, h->stream, B, T, h->max_free);
-        hipLaunchKernelGGL(k_st_scan, dim3(n), dim3(256), 0, h->stream, B, T);
-        hipLaunchKernelGGL(k_st_fill, dim3(h->max_free, n), dim3(64), sh_row, h->stream, B, T, h->max_free);
+        T.key_seg = dp<int>(h, BUF_KEYSEG); T.tslot = dp<int>(h, BUF_TSLOT);
+        hipLaunchKernelGGL(k_st_hist, dim3(n), dim3(256), sh_order, h->up_stream, B, T);
+        hipLaunchKernelGGL(k_st_rank_lm, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
+        hipLaunchKernelGGL(k_st_rank_rec, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
+        hipLaunchKernelGGL(k_st_count, dim3(h->max_free, n), dim3(64), sh_row, h->up_stream, B, T, h->max_free);
+        hipLaunchKernelGGL(k_st_scan, dim3(n), dim3(256), 0, h->up_stream, B, T);
+        hipLaunchKernelGGL(k_st_fill, dim3(h->max_free, n), dim3(64), sh_row, h->up_stream, B, T, h->max_free);
         HIPCHK(h, hipGetLastError());
     }
     const double t_enq = now_ms();
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (timing) fprintf(stderr, "[vba] upload %d windows: total %.3f ms (structure %.3f, pack %.3f, alloc+H2D enqueue %.3f, sync %.3f)\n", n,
+    HIPCHK(h, hipStreamSynchronize(h->up_stream));
+    if (timing) fprintf(stderr, "[vba] %p t=%.1f upload %d windows: total %.3f ms (structure %.3f, pack %.3f, alloc+H2D enqueue %.3f, sync %.3f)\n", (void*)h, now_ms(), n,
                         now_ms() - t_begin, t_struct, t_pack - t_begin - t_struct, t_enq - t_pack, now_ms() - t_enq);
     h->uploaded = true;
     h->ran = false;
@@ -1117,6 +1141,8 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
 }
 
 int do_run(Handle* h, const volatile int* stop_flag) {
+    static const bool timing = getenv("VBA_TIMING") != nullptr;
+    const double t_run0 = timing ? now_ms() : 0.0;
     if (!h->uploaded) return fail(h, "vba_batch_run before vba_batch_upload");
     HIPCHK(h, hipSetDevice(h->device));
     const Batch B = h->B;
@@ -1141,7 +1167,7 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     static const int lane_streams = getenv("VBA_LANE_STREAMS") ? atoi(getenv("VBA_LANE_STREAMS")) : 2;
     if (want <= 0 && h->is_lane) want = lane_streams;   // several lanes share the chip: fewer window groups each
     if (want <= 0) want = (n >= 2048 && h->algo == VBA_ALGO_GN) ? 2 : (n >= 64) ? 4 : (n >= 16) ? 2 : 1;   // default policy (16..48 windows: 2 groups +5..10 %, 4 groups -40 %)
-    const int max_streams = std::min(14, want);
+    const int max_streams = std::min(std::min(14, want), (int)h->xstreams.size() + (h->owns_streams ? 11 : 1));
     int ngroups = 1;
     if (!h->profile && max_streams > 1 && n >= 8)
         ngroups = std::max(1, std::min(max_streams, n / 8));   // a group never falls below the 8 windows of the XCD-aware mapping
@@ -1221,10 +1247,13 @@ int do_run(Handle* h, const volatile int* stop_flag) {
         }
     }
     h->ran = true;
+    if (timing) fprintf(stderr, "[vba] %p t=%.1f run %d windows: %.3f ms\n", (void*)h, now_ms(), n, now_ms() - t_run0);
     return 0;
 }
 
 int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* out) {
+    static const bool timing = getenv("VBA_TIMING") != nullptr;
+    const double t_dl0 = timing ? now_ms() : 0.0;
     if (!h->ran) return fail(h, "vba_batch_download before vba_batch_run");
     if (n != h->n_win) return fail(h, "window count mismatch");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1249,16 +1278,16 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
         if (want_chi2) G.dl_chi2.resize(nobs);
         if (!G.ok()) return fail(h, "out of pinned host memory (download staging)");
         if (want_state) {
-            HIPCHK(h, hipMemcpyAsync(G.dl_pose.data(), B.pose, 56 * nkf, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(G.dl_pt.data(), B.pt, 24 * npt, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(G.dl_pose.data(), B.pose, 56 * nkf, hipMemcpyDeviceToHost, h->dl_stream));
+            HIPCHK(h, hipMemcpyAsync(G.dl_pt.data(), B.pt, 24 * npt, hipMemcpyDeviceToHost, h->dl_stream));
             if (vi) {
-                HIPCHK(h, hipMemcpyAsync(G.dl_vel.data(), B.vel, 24 * nkf, hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(h, hipMemcpyAsync(G.dl_bias.data(), B.bias, 96 * nkf, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipMemcpyAsync(G.dl_vel.data(), B.vel, 24 * nkf, hipMemcpyDeviceToHost, h->dl_stream));
+                HIPCHK(h, hipMemcpyAsync(G.dl_bias.data(), B.bias, 96 * nkf, hipMemcpyDeviceToHost, h->dl_stream));
             }
         }
-        if (want_outl) HIPCHK(h, hipMemcpyAsync(G.dl_outl.data(), B.out_outlier, nobs, hipMemcpyDeviceToHost, h->stream));
-        if (want_chi2) HIPCHK(h, hipMemcpyAsync(G.dl_chi2.data(), B.out_chi2, 8 * nobs, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (want_outl) HIPCHK(h, hipMemcpyAsync(G.dl_outl.data(), B.out_outlier, nobs, hipMemcpyDeviceToHost, h->dl_stream));
+        if (want_chi2) HIPCHK(h, hipMemcpyAsync(G.dl_chi2.data(), B.out_chi2, 8 * nobs, hipMemcpyDeviceToHost, h->dl_stream));
+        HIPCHK(h, hipStreamSynchronize(h->dl_stream));
     }
     std::atomic<int> next(0), bad(0);
     auto work = [&]() {
@@ -1302,6 +1331,7 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
         for (auto& t : pool) t.join();
     }
     if (bad.load()) return fail(h, "hipMemcpy (download) failed");
+    if (timing) fprintf(stderr, "[vba] %p t=%.1f download %d windows: %.3f ms\n", (void*)h, now_ms(), n, now_ms() - t_dl0);
     return 0;
 }
 
@@ -1309,24 +1339,37 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
 
 extern "C" {
 
-int vba_create(int device, void** handle) {
-    if (!handle) return -1;
-    *handle = nullptr;
+// parent == nullptr: a handle of its own (four streams, created NOW, before anything ran: created after a first solve they do
+// not run concurrently with it -- measured: 64 windows in 4 groups 16.4 ms instead of 11.3 ms when a one-window solve came
+// first; the runtime binds streams to its hardware queues when they are created).
+// parent != nullptr: a lane of vba_batch_solve.  It owns device buffers, pinned staging and control words, but SHARES the
+// parent's four streams, one role each: [0] run, [1] run (second window group), [2] upload (H2D + structure build), [3]
+// download (D2H).  The runtime multiplexes streams onto four hardware queues; with streams of their own the lanes' uploads
+// landed in the queue of another lane's solve and stalled it behind their transfers (head-of-line blocking: 512 windows
+// solved in 70 ms instead of 52).  Only one lane solves at a time (run token), so the run streams are never contended.
+static int make_handle(int device, Handle* parent, Handle** out) {
+    *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return -2;  // no CPU fallback
     Handle* h = new Handle();
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete h;
-        return -3;
-    }
-    // The streams of the window groups are created NOW, before anything ran on the main stream: created after a first solve
-    // they do not run concurrently with it (measured: 64 windows in 4 groups 16.4 ms instead of 11.3 ms when a one-window
-    // solve came first) -- the runtime binds streams to its hardware queues when they are created.
-    for (int i = 0; i < 3; i++) {
-        hipStream_t st;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
-        h->xstreams.push_back(st);
+    if (hipSetDevice(device) != hipSuccess) { delete h; return -3; }
+    if (parent) {
+        if (parent->xstreams.size() < 3) { delete h; return -3; }
+        h->owns_streams = false;
+        h->is_lane = true;
+        h->stream = parent->stream;
+        h->xstreams.push_back(parent->xstreams[0]);
+        h->up_stream = parent->xstreams[1];
+        h->dl_stream = parent->xstreams[2];
+    } else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return -3; }
+        for (int i = 0; i < 3; i++) {
+            hipStream_t st;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+            h->xstreams.push_back(st);
+        }
+        h->up_stream = h->dl_stream = h->stream;
     }
     void* hp = nullptr;
     if (hipHostMalloc(&hp, 4096, hipHostMallocMapped) != hipSuccess) { delete h; return -4; }
@@ -1339,8 +1382,17 @@ int vba_create(int device, void** handle) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lin2), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)LIN2_LDS);
     memset(&h->prof, 0, sizeof h->prof);
-    *handle = h;
+    *out = h;
     return 0;
+}
+
+int vba_create(int device, void** handle) {
+    if (!handle) return -1;
+    *handle = nullptr;
+    Handle* h = nullptr;
+    const int rc = make_handle(device, nullptr, &h);
+    if (rc == 0) *handle = h;
+    return rc;
 }
 
 int vba_destroy(void* handle) {
@@ -1350,6 +1402,8 @@ int vba_destroy(void* handle) {
     h->lanes.clear();
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->up_stream);
+    (void)hipStreamSynchronize(h->dl_stream);
     h->stg.release();
     for (auto& b : h->buf) b.release();
     h->preint.release();
@@ -1357,9 +1411,10 @@ int vba_destroy(void* handle) {
     h->pose_host_in.release();
     h->pose_host_out.release();
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
-    for (auto st : h->xstreams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (h->owns_streams)
+        for (auto st : h->xstreams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (h->stop_host) (void)hipHostFree((void*)h->stop_host);
-    (void)hipStreamDestroy(h->stream);
+    if (h->owns_streams) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
 }
@@ -1413,8 +1468,10 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
     if (n <= 0 || !inout) return fail(h, "vba_batch_solve: bad arguments");
-    static const int env_lanes = getenv("VBA_LANES") ? atoi(getenv("VBA_LANES")) : 3;
-    static const int env_chunk = getenv("VBA_CHUNK") ? atoi(getenv("VBA_CHUNK")) : 512;
+    // measured on MI355X, 4096 fresh C3 windows (scripts/e2e_sweep.py): chunk x lanes 512x3 7.7k windows/s, 768x3 8.0k, 1024x3 8.1k,
+    // 1024x2 8.2k (resident: 10.8k) -- one lane solves while the other packs / transfers / builds its structure / scatters
+    static const int env_lanes = getenv("VBA_LANES") ? atoi(getenv("VBA_LANES")) : 2;
+    static const int env_chunk = getenv("VBA_CHUNK") ? atoi(getenv("VBA_CHUNK")) : 1024;
     const int chunk_max = std::max(1, h->opt_chunk > 0 ? h->opt_chunk : env_chunk);
     const int n_chunks = (n + chunk_max - 1) / chunk_max;
     const int n_lanes = std::max(1, std::min(h->opt_lanes > 0 ? h->opt_lanes : env_lanes, n_chunks));
@@ -1423,19 +1480,48 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
         return do_download(h, n, inout, out);
     }
     while ((int)h->lanes.size() < n_lanes) {
-        void* l = nullptr;
-        if (vba_create(h->device, &l) != 0) return fail(h, "vba_batch_solve: could not create a lane");
-        reinterpret_cast<Handle*>(l)->is_lane = true;
-        h->lanes.push_back(reinterpret_cast<Handle*>(l));
+        Handle* l = nullptr;
+        if (make_handle(h->device, h, &l) != 0) return fail(h, "vba_batch_solve: could not create a lane");
+        h->lanes.push_back(l);
     }
-    const int chunk = (n + n_chunks - 1) / n_chunks;   // balanced: no tiny tail chunk
+    // balanced chunks (no tiny tail); with three or more of them the first is half a chunk, so that the device starts after half
+    // the packing / transfer time of a full one (the other chunks share the remainder evenly)
+    std::vector<int> cbeg(n_chunks + 1, 0);
+    {
+        const int even = (n + n_chunks - 1) / n_chunks;
+        const int first = (n_chunks >= 3 && even >= 512) ? even / 2 : even;
+        cbeg[1] = std::min(n, first);
+        for (int c = 1; c < n_chunks; c++) cbeg[c + 1] = cbeg[1] + (int)((long long)(n - cbeg[1]) * c / (n_chunks - 1));
+        cbeg[n_chunks] = n;
+    }
     std::atomic<int> next(0), bad(0);
     std::mutex mu;
+    // Lanes that start together stay in step (all pack, then all solve, then all scatter: the GPU idles while the hosts pack).
+    // A run token breaks the symmetry: only `run_slots` lanes may be inside the solve at a time, the others pack / transfer /
+    // build the structure of their next chunk or scatter their last one meanwhile.
+    static const int env_slots = getenv("VBA_RUN_SLOTS") ? atoi(getenv("VBA_RUN_SLOTS")) : 1;
+    int run_free = std::max(1, std::min(env_slots, n_lanes));
+    std::mutex run_mu;
+    std::condition_variable run_cv;
+    auto run_gated = [&](Handle* lane) -> int {
+        {
+            std::unique_lock<std::mutex> lk(run_mu);
+            run_cv.wait(lk, [&] { return run_free > 0; });
+            run_free--;
+        }
+        const int rc = do_run(lane, stop_flag);
+        {
+            std::lock_guard<std::mutex> lk(run_mu);
+            run_free++;
+        }
+        run_cv.notify_one();
+        return rc;
+    };
     auto work = [&](Handle* lane) {
         for (int c = next.fetch_add(1); c < n_chunks && !bad.load(); c = next.fetch_add(1)) {
-            const int w0 = c * chunk, cn = std::min(chunk, n - w0);
-            if (cn <= 0) break;
-            if (do_upload(lane, cn, inout + w0) || do_run(lane, stop_flag) || do_download(lane, cn, inout + w0, out ? out + w0 : nullptr)) {
+            const int w0 = cbeg[c], cn = cbeg[c + 1] - w0;
+            if (cn <= 0) continue;
+            if (do_upload(lane, cn, inout + w0) || run_gated(lane) || do_download(lane, cn, inout + w0, out ? out + w0 : nullptr)) {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!bad.exchange(1)) h->err = "vba_batch_solve, windows " + std::to_string(w0) + ".." + std::to_string(w0 + cn - 1) + ": " + lane->err;
                 return;
@@ -1474,7 +1560,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
