@@ -797,13 +797,14 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
     const int n_off = d.n_pairs - d.n_free;
     const int oi = quad * NG + g;
     const bool have = oi < n_off;
-    int pr = 0, a = 0, b = 0, ib = 0, ie = 0;
+    int pr = 0, a = 0, b = 0, ib = 0, im = 0, ie = 0;
     if (have) {
         pr = B.off_pair[d.pair0 + oi];
         a = B.pair_a[d.pair0 + pr];
         b = B.pair_b[d.pair0 + pr];
         ib = B.item_begin[d.pair0 + d.win + pr];
         ie = B.item_begin[d.pair0 + d.win + pr + 1];
+        im = (LD == 1) ? B.item_mid[d.pair0 + d.win + pr] : ie;
     }
     double acc[36];
 #pragma unroll
@@ -812,12 +813,12 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
     int2 nxt = make_int2(0, 0);
     if (ib + l16 < ie) nxt = items[ib + l16];
+    // every item: the Schur term -U_a U_b^T of one landmark seen from both keyframes
     for (int it = ib + l16; it < ie; it += LP) {
         const int2 itm = nxt;  // indices were fetched one trip ahead: one dependent round trip per item, not two
         if (it + LP < ie) nxt = items[it + LP];
-        const int sa = itm.x, sb = itm.y;
-        const double* qa = slots + SS * (size_t)sa;
-        const double* qb = slots + SS * (size_t)sb;
+        const double* qa = slots + SS * (size_t)itm.x;
+        const double* qb = slots + SS * (size_t)itm.y;
         double UA[6 * LD], UB[6 * LD];
 #pragma unroll
         for (int i = 0; i < 6 * LD; i++) { UA[i] = qa[i]; UB[i] = qb[i]; }
@@ -827,38 +828,39 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
             for (int j = 0; j < 6; j++)
 #pragma unroll
                 for (int l = 0; l < LD; l++) acc[6 * i + j] -= UA[LD * i + l] * UB[LD * j + l];
-        if (LD == 1) {
-            // direct H_pp terms of the pairs that involve the landmark's reference keyframe (sorted to the end
-            // of a pair's list)
-            if (sa >= d.n_obs || sb >= d.n_obs) {
-                // one of the two is the landmark's reference keyframe: the edge of the other one adds Br^T Bi (a = ref)
-                // or Bi^T Br (b = ref), with Br = [-A | A N0] rebuilt from the record's A = Bi[:, 0:3]
-                const bool a_ref = sa >= d.n_obs;
-                const double* re = B.erec + VBA_EREC1 * (size_t)(d.obs0 + (a_ref ? sb : sa));
-                const double* n0 = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + (a_ref ? sa : sb) - d.n_obs);
-                const double* Ro = B.kfR + 12 * (size_t)(d.kf0 + (a_ref ? b : a));  // the observer's rotation
-                double N0[9], Rm[9], rec[6], bi0[6], bi1[6], rr0, rr1;
+    }
+    if (LD == 1) {
+        // the items [im, ie) involve the landmark's reference keyframe and also carry a direct H_pp term: the edge of the
+        // other keyframe adds Br^T Bi (a = ref) or Bi^T Br (b = ref), with Br = [-A | A N0] rebuilt from the record's
+        // A = Bi[:, 0:3].  Their own loop: the walk above stays free of this branch and of its loads.
+        for (int it = im + l16; it < ie; it += LP) {
+            const int2 itm = items[it];
+            const int sa = itm.x, sb = itm.y;
+            const bool a_ref = sa >= d.n_obs;
+            const double* re = B.erec + VBA_EREC1 * (size_t)(d.obs0 + (a_ref ? sb : sa));
+            const double* n0 = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + (a_ref ? sa : sb) - d.n_obs);
+            const double* Ro = B.kfR + 12 * (size_t)(d.kf0 + (a_ref ? b : a));  // the observer's rotation
+            double N0[9], Rm[9], rec[6], bi0[6], bi1[6], rr0, rr1;
 #pragma unroll
-                for (int i = 0; i < 9; i++) { N0[i] = n0[i]; Rm[i] = Ro[i]; }
+            for (int i = 0; i < 9; i++) { N0[i] = n0[i]; Rm[i] = Ro[i]; }
 #pragma unroll
-                for (int i = 0; i < 4; i++) rec[i] = re[i];
-                rec[4] = rec[5] = 0.0;
-                rebuild_edge(d, Rm, rec, bi0, bi1, rr0, rr1);
+            for (int i = 0; i < 4; i++) rec[i] = re[i];
+            rec[4] = rec[5] = 0.0;
+            rebuild_edge(d, Rm, rec, bi0, bi1, rr0, rr1);
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const double* bi = h ? bi1 : bi0;
-                    double br[6];
+            for (int h = 0; h < 2; h++) {
+                const double* bi = h ? bi1 : bi0;
+                double br[6];
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        br[k] = -bi[k];
-                        br[3 + k] = bi[0] * N0[k] + bi[1] * N0[3 + k] + bi[2] * N0[6 + k];
-                    }
+                for (int k = 0; k < 3; k++) {
+                    br[k] = -bi[k];
+                    br[3 + k] = bi[0] * N0[k] + bi[1] * N0[3 + k] + bi[2] * N0[6 + k];
+                }
 #pragma unroll
-                    for (int i = 0; i < 6; i++) {
-                        const double x = a_ref ? br[i] : bi[i];
+                for (int i = 0; i < 6; i++) {
+                    const double x = a_ref ? br[i] : bi[i];
 #pragma unroll
-                        for (int j = 0; j < 6; j++) acc[6 * i + j] += x * (a_ref ? bi[j] : br[j]);
-                    }
+                    for (int j = 0; j < 6; j++) acc[6 * i + j] += x * (a_ref ? bi[j] : br[j]);
                 }
             }
         }
@@ -939,7 +941,7 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
             const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + sa - d.n_obs);
 #pragma unroll
             for (int g = 0; g < 21; g++) acc[g] += pr_[g];
-            hd[0] += pr_[0]; hd[1] += pr_[6]; hd[2] += pr_[11]; hd[3] += pr_[15]; hd[4] += pr_[18]; hd[5] += pr_[20];
+            // (no H_pp diagonal here: it feeds Levenberg-Marquardt's lambda init, and inverse-depth windows run Gauss-Newton)
 #pragma unroll
             for (int i = 0; i < 6; i++) bp[i] += pr_[21 + i];
         } else {
@@ -960,7 +962,7 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
             for (int i = 0; i < 6; i++) {
 #pragma unroll
                 for (int j = i; j < 6; j++) acc[gi++] += b0[i] * b0[j] + b1[i] * b1[j];
-                hd[i] += b0[i] * b0[i] + b1[i] * b1[i];
+                if (LD != 1) hd[i] += b0[i] * b0[i] + b1[i] * b1[i];
                 bp[i] += (LD == 1) ? -(b0[i] * r0 + b1[i] * r1) : ra[24 + i];
             }
         }
@@ -980,7 +982,7 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
 #pragma unroll
     for (int i = 0; i < 21; i++) acc[i] = wave_sum(acc[i]);
 #pragma unroll
-    for (int i = 0; i < 6; i++) { rhs[i] = wave_sum(rhs[i]); bp[i] = wave_sum(bp[i]); hd[i] = wave_sum(hd[i]); }
+    for (int i = 0; i < 6; i++) { rhs[i] = wave_sum(rhs[i]); bp[i] = wave_sum(bp[i]); if (LD != 1) hd[i] = wave_sum(hd[i]); }
     const int P = d.pdim;
     for (int q = t; q < P * P; q += 64) blk[q] = 0.0;
     __syncthreads();
