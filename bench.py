@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose"],
                     help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, pose = IMU-aided per-frame pose optimisation: extra measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcg", action="store_true", help="c4 / gba: skip the second run of the batch with the PCG solver")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-steps", type=int, default=4, help="timed vba_batch_solve calls over fresh copies of the batch (0: skip)")
     ap.add_argument("--single-reps", type=int, default=21, help="vba_solve repetitions behind single_window_ms (0: skip)")
@@ -371,6 +372,31 @@ def main():
                 t_all = time.perf_counter() - t1
                 cpu["all_cores"] = {"value": per * ncores / t_all, "unit": "windows/s", "cores": ncores,
                                     "sample": "%d solves, %d threads, one window per thread" % (per * ncores, ncores)}
+        # BASELINE configs[3] says "Schur + PCG": the same batch with vba_problem.solver = VBA_SOLVER_PCG beside the LDL^T figure
+        pcg = None
+        if args.workload in ("c4", "gba") and not args.no_pcg:
+            from mc_slam_amd import abi
+            pw = []
+            for w_ in wins:
+                q_ = w_.copy(); q_.solver = abi.SOLVER_PCG; pw.append(q_)
+            bp = backend.LocalBA(local_rank)
+            bp.upload([pw[i % len(pw)] for i in range(args.batch)])
+            bp.run()
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(2):
+                bp.run()
+            torch.cuda.synchronize(); tp = (time.perf_counter() - t1) / 2
+            solp, resp = bp.download()
+            for i in range(len(wins)):
+                if resp[i].its_done != res[i].its_done or abs(resp[i].chi2_vis - res[i].chi2_vis) > 1e-4 * res[i].chi2_vis \
+                        or np.abs(solp[i].kf_pose[:, :3] - sol[i].kf_pose[:, :3]).max() > 1e-6:
+                    raise SystemExit("bench: the PCG path does not land where the LDL^T path lands (window %d)" % i)
+            n_p = (6 if batch[0].variant == 0 else 15) * batch[0].n_kf_free
+            pcg = {"value": args.batch / tp, "unit": "windows/s", "ms_per_step": tp * 1e3, "vs_ldlt": (args.batch / tp) / value,
+                   "cg_iterations_per_solve": float(np.mean([r.lin_iterations / max(1, sum(r.its_done)) for r in resp])), "n_p": n_p,
+                   "what": "same batch, vba_problem.solver = VBA_SOLVER_PCG (block-Jacobi PCG on the reduced system, tolerance 1e-10); "
+                           "iteration counts, chi2 (1e-4) and translations (1e-6 m) equal to the LDL^T run"}
+            bp.close()
         rng = lambda f: [int(min(f(w) for w in wins)), int(max(f(w) for w in wins))]
         out = {
             "metric": {"c3": "LocalBA windows/sec (50 KF, 5k pts, 30k obs, IMU edges)",
@@ -398,7 +424,7 @@ def main():
                        "its_done_histogram": its_hist,
                        "parallelism": "independent windows sharded %d per GPU, no data-path collective" % args.batch,
                        "mean_outer_iterations": float(np.mean(its))},
-            "end_to_end": e2e, "single_window": single,
+            "end_to_end": e2e, "single_window": single, "pcg": pcg,
             "roofline": roofline, "cpu_baseline": cpu, "verified": verified,
         }
     if dist is not None:

@@ -36,6 +36,10 @@ extern "C" {
 #define VBA_PROTO_SINGLE 1 /* one optimize(its_stage1), no outlier pass: BundleAdjustment / GlobalBundleAdjustmentNavStatePRV
                             * (src/Optimizer.cpp:3377-3607, 629-933) */
 
+#define VBA_SOLVER_LDLT 0 /* dense LDL^T on 32x32 tiles of the reduced system: what LinearSolverEigen does (linear_solver_eigen.h:94-124) */
+#define VBA_SOLVER_PCG 1  /* block-Jacobi preconditioned conjugate gradients on the reduced system (not in the reference: BASELINE
+                           * north_star / configs[3] "Schur + PCG"); tolerance 1e-10, so the outer iterations follow the direct path */
+
 #define VBA_IMU_MEAS_STRIDE 61 /* dt, dP(3), dV(3), dR(9 row-major), JPg, JPa, JVg, JVa, JRg (9 each, row-major) */
 #define VBA_TRACE_MAX 64
 
@@ -84,6 +88,7 @@ typedef struct vba_problem {
     const uint8_t *kf_fix;    /* NULL or [n_kf]: per-vertex setFixed() of the keyframes listed as free: bit0 PR, bit1 V,
                                * bit2 Bias (GlobalBundleAdjustmentNavStatePRV fixes PR and Bias of keyframe 0 but not
                                * its V: src/Optimizer.cpp:667-685) */
+    int32_t solver;           /* VBA_SOLVER_*: how the reduced system is solved (0 = LDL^T, the reference's choice) */
 } vba_problem;
 
 typedef struct vba_result {
@@ -98,6 +103,7 @@ typedef struct vba_result {
     int32_t n_trace;      /* entries of chi2_trace */
     double chi2_trace[VBA_TRACE_MAX]; /* activeRobustChi2 after every accepted/terminating evaluation (diagnostic) */
     double lambda_final;  /* LM only */
+    int32_t lin_iterations; /* VBA_SOLVER_PCG: conjugate-gradient iterations summed over all solves of the window (0 for LDL^T) */
 } vba_result;
 
 /* Per-kernel-class device time of the last vba_batch_run, measured with HIP events on the backend's

@@ -12,6 +12,7 @@ import numpy as np
 
 VARIANT_SE3_XYZ, VARIANT_PRV_XYZ, VARIANT_PRV_IDP = 0, 1, 2
 PROTO_LOCAL, PROTO_SINGLE = 0, 1
+SOLVER_LDLT, SOLVER_PCG = 0, 1
 ALGO_GN, ALGO_LM = 0, 1
 IMU_MEAS_STRIDE = 61
 TRACE_MAX = 64
@@ -47,7 +48,7 @@ class vba_problem(C.Structure):
         ("huber_vis", C.c_double), ("huber_prv", C.c_double), ("huber_bias", C.c_double),
         ("algo", C.c_int32), ("its_stage1", C.c_int32), ("its_stage2", C.c_int32),
         ("chi2_th", C.c_double), ("depth_min", C.c_double), ("rho_min", C.c_double),
-        ("protocol", C.c_int32), ("robust", C.c_int32), ("kf_fix", _pu8),
+        ("protocol", C.c_int32), ("robust", C.c_int32), ("kf_fix", _pu8), ("solver", C.c_int32),
     ]
 
 
@@ -57,7 +58,7 @@ class vba_result(C.Structure):
         ("its_done", C.c_int32 * 2), ("n_outliers", C.c_int32), ("status", C.c_int32),
         ("obs_outlier", _pu8), ("obs_chi2", _pd),
         ("n_trace", C.c_int32), ("chi2_trace", C.c_double * TRACE_MAX),
-        ("lambda_final", C.c_double),
+        ("lambda_final", C.c_double), ("lin_iterations", C.c_int32),
     ]
 
 
@@ -112,6 +113,7 @@ class Problem:
     protocol: int = 0                          # PROTO_LOCAL / PROTO_SINGLE
     robust: int = 1
     kf_fix: Optional[np.ndarray] = None        # [n_kf] uint8: bit0 PR, bit1 V, bit2 Bias fixed
+    solver: int = 0                            # SOLVER_LDLT / SOLVER_PCG
     truth: dict = field(default_factory=dict)  # generator ground truth (not part of the ABI)
 
     def __post_init__(self):
@@ -165,6 +167,7 @@ class Problem:
         s.algo, s.its_stage1, s.its_stage2 = self.algo, self.its_stage1, self.its_stage2
         s.chi2_th, s.depth_min, s.rho_min = self.chi2_th, self.depth_min, self.rho_min
         s.protocol, s.robust = self.protocol, self.robust
+        s.solver = self.solver
         if self.kf_fix is not None:
             self.kf_fix = np.ascontiguousarray(self.kf_fix, dtype=np.uint8)
             assert self.kf_fix.shape == (self.n_kf,)
@@ -184,6 +187,7 @@ class Result:
     obs_chi2: np.ndarray
     chi2_trace: np.ndarray
     lambda_final: float
+    lin_iterations: int = 0
 
 
 class ResultBuf:
@@ -201,7 +205,7 @@ class ResultBuf:
         s = self.s
         return Result(s.chi2_vis, s.chi2_prv, s.chi2_bias, (s.its_done[0], s.its_done[1]), s.n_outliers, s.status,
                       self.outlier[:self.n_obs].copy(), self.chi2[:self.n_obs].copy(),
-                      np.array(s.chi2_trace[:s.n_trace]), s.lambda_final)
+                      np.array(s.chi2_trace[:s.n_trace]), s.lambda_final, s.lin_iterations)
 
 
 # ---- IMU-aided per-frame pose optimisation (include/vislam_ba.h: vba_frame_problem / vba_frame_result) ----

@@ -50,7 +50,7 @@ struct WinDesc {
     long long S0;   // offset (doubles) into S
     long long mask0; // offset (64-bit words) of the window's landmark masks (n_pt x mwords)
     int mwords;      // 64-bit words per landmark mask = ceil(n_kf / 64)
-    int pad_;
+    int adj0;        // offset into the keyframe adjacency list (PCG)
     double K[4];
     double Rcb[9], tcb[3], g[3];
     double inv_bg, inv_ba;
@@ -76,6 +76,8 @@ struct WinCtrl {
     int lm_need_trial;// 1: another trial must run in this outer iteration
     int lm_restore;   // 1: the last trial was rejected, k_restore must pop the state
     int nbad;
+    int lin_its;      // PCG iterations of all solves so far
+    int pad_;
     double lambda, ni;
     double chi_prev;  // GN: preChi2 of the last started iteration.  LM: currentChi
     double chi_ini;   // LM: iniChi

@@ -39,6 +39,8 @@ struct Batch {
     int* var_act;
     // structure (g2o buildStructure analogue, built on the host at upload)
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
+    const int *adj_begin, *adj;         // PCG: per free keyframe the other free keyframes it shares a landmark or an IMU edge with
+    double *pcg_v, *pcg_m;              // PCG: x r z p q (5 nS per window); inverted diagonal blocks (225 per keyframe)
     const int* item_mid;                // per pair: its first item that involves the landmark's reference keyframe
     const unsigned long long* lmask;    // [n_pt x mwords] observing keyframes of every landmark (host-built while validating)
     const int *kf_seg, *ref_seg;        // [n_kf + 1] per window: record range of every keyframe -- slot / edge records by observing
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(64) k_reset(Batch B) {
         c.robust_vis = (d.protocol == 1) ? (d.robust != 0) : 1;
         c.chol_fail = 0; c.aborted = 0;
         c.n_trace = 0; c.n_outliers = 0;
-        c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0;
+        c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0; c.lin_its = 0;
         c.lambda = 0; c.ni = 2; c.chi_prev = 0; c.chi_ini = 0;
         c.chi2_vis = c.chi2_prv = c.chi2_bias = 0;
     }

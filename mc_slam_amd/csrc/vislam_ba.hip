@@ -10,6 +10,7 @@
 #include "vba_preint.h"
 #include "vba_pose.h"
 #include "vba_structure.h"
+#include "vba_pcg.h"
 
 #include <algorithm>
 #include <chrono>
@@ -124,7 +125,7 @@ struct Staging {
     PinVec<int> ptref, ptobs, obskf, imui, imuj, pair_a, pair_b, pimu_begin, pimu;
     PinVec<int> offpair, pairmask;
     PinVec<unsigned long long> lmask;
-    PinVec<int> s_int[7];        // pinned copies of the small host-built lists (tile lists, k_lin2 runs)
+    PinVec<int> s_int[9];        // pinned copies of the small host-built lists (tile lists, k_lin2 runs)
     PinVec<WinDesc> s_desc;
     PinVec<double> dl_pose, dl_vel, dl_bias, dl_pt, dl_chi2;
     PinVec<unsigned char> dl_outl;
@@ -145,7 +146,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_N
 };
 
 struct ProfEvt {
@@ -182,7 +183,7 @@ struct Handle {
     std::vector<int> pan_grid, step_npair_max;  // panel tiles / tile pairs per step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
     std::vector<int> win_tiles;  // tile products of one factorisation of window w
-    int algo = 0, variant = 2;
+    int algo = 0, variant = 2, solver = 0;
     volatile int* stop_host = nullptr;  // pinned, device-visible
     int* stop_dev = nullptr;
     bool profile = false;
@@ -258,6 +259,7 @@ struct Structure {
     std::vector<int> step_npairs;
     std::vector<int> off_pair, pair_mask;
     std::vector<unsigned long long> lmask;  // [n_pt][mwords] observing keyframes of every landmark
+    std::vector<int> adj_begin, adj;        // PCG: per free keyframe the other free keyframes its block row of S is non-zero for
     std::vector<int> linblk;                // k_lin2 work split (inverse-depth windows): (p0, p1, e0, e1) per workgroup
     int mwords = 1;
     long long item_cap = 0;            // upper bound of the off-diagonal items (exact when every keyframe is free)
@@ -372,6 +374,18 @@ int build_structure(Handle* h, const vba_problem* P, Structure& st) {
                 if (i < j) put(pidx(i, j), k, 2);
                 else put(pidx(j, i), k, 1);
             }
+        }
+    }
+    if (P->solver == VBA_SOLVER_PCG) {   // block rows of S: a shares a landmark or an IMU edge with b
+        st.adj_begin.assign(nf + 1, 0);
+        st.adj.clear();
+        for (int a = 0; a < nf; a++) {
+            for (int b = 0; b < nf; b++) {
+                if (b == a) continue;
+                const int pi = (a < b) ? pidx(a, b) : pidx(b, a);
+                if (pair_vis(a, b) || st.pimu_begin[pi + 1] > st.pimu_begin[pi]) st.adj.push_back(b);
+            }
+            st.adj_begin[a + 1] = (int)st.adj.size();
         }
     }
     // symbolic factorisation on 32x32 tiles (the tile-level analogue of SimplicialLDLT::analyzePattern,
@@ -535,7 +549,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     auto &offpair = G.offpair, &pairmask = G.pairmask;
     auto& lmask = G.lmask;
     G.each([](auto& v) { v.clear(); });
-    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, tlkb, tlk;
+    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, tlkb, tlk, adjbeg, adj;
+    const bool pcg = probs[0] && probs[0]->solver == VBA_SOLVER_PCG;
     h->step_grid.clear();
     h->pan_grid.clear();
     h->step_npair_max.clear();
@@ -614,7 +629,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
                 return fail(h, "XYZ landmarks are solved with Levenberg-Marquardt only (as the reference does, src/Optimizer.cpp:1028,3928)");
             if (P->n_kf_free <= 0 || P->n_kf_free > P->n_kf || P->n_pt < 0 || P->n_obs < 0) return fail(h, "bad sizes");
             if (P->n_pt == 0 || P->n_obs == 0) return fail(h, "a window without landmarks or observations has nothing to optimise");
-            if (w > 0 && (P->variant != probs[0]->variant || P->algo != probs[0]->algo)) return fail(h, "mixed batch");
+            if (w > 0 && (P->variant != probs[0]->variant || P->algo != probs[0]->algo || P->solver != probs[0]->solver)) return fail(h, "mixed batch");
+            if (P->solver != VBA_SOLVER_LDLT && P->solver != VBA_SOLVER_PCG) return fail(h, "unknown solver");
             if (P->its_stage1 > 30 || P->its_stage2 > 30 || P->its_stage1 < 0 || P->its_stage2 < 0) return fail(h, "its out of range");
             if (P->protocol != VBA_PROTO_LOCAL && P->protocol != VBA_PROTO_SINGLE) return fail(h, "unknown protocol");
             WinDesc& d = h->desc[w];
@@ -633,6 +649,12 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             Structure& st = sts[w - chunk0];
             d.item0 = (int)item0; d.pimu0 = pimu0; d.vec0 = vec0; d.part0 = part0;
             d.mask0 = mask0; d.mwords = st.mwords;
+            d.adj0 = (int)adj.size();
+            if (pcg) {
+                adjbeg.resize((size_t)kf0 + w, 0);   // rows of adj_begin start at kf0 + win, like the keyframe segments
+                adjbeg.insert(adjbeg.end(), st.adj_begin.begin(), st.adj_begin.end());
+                adj.insert(adj.end(), st.adj.begin(), st.adj.end());
+            }
             d.n_part_lin = (d.n_pt + 63) / 64;
             if (P->variant == VBA_VARIANT_PRV_IDP) {
                 d.lb0 = (int)(linblk.size() / 4);
@@ -780,12 +802,19 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_DVEC, (size_t)vec0 * 8) || dalloc(h, BUF_WINV, (size_t)n * 1024 * 8)) return -1;
     if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
     if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b)) return -1;
+    h->solver = probs[0]->solver;
+    if (pcg) {
+        adjbeg.resize((size_t)kf0 + n, 0);
+        if (h2d_vec(h, BUF_ADJBEG, adjbeg, G.s_int[7]) || h2d_vec(h, BUF_ADJ, adj, G.s_int[8])) return -1;
+        if (dalloc(h, BUF_PCGV, (size_t)vec0 * 5 * 8) || dalloc(h, BUF_PCGM, (size_t)kf0 * 225 * 8)) return -1;
+    }
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d_vec(h, BUF_LINBLK, linblk, G.s_int[6])) return -1;
     if (h2d(h, BUF_OFFPAIR, offpair) || h2d(h, BUF_PAIRMASK, pairmask)) return -1;
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
     // S: zero everything once, identity on the pads
-    if (use_left_looking(n)) HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->up_stream));
-    for (int w = 0; w < n && !use_left_looking(n); w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
+    // (PCG reads whole keyframe-pair blocks, also the sub-blocks no factor tile covers and no Schur kernel writes: zero them once)
+    if (use_left_looking(n) || pcg) HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->up_stream));
+    for (int w = 0; w < n && !(use_left_looking(n) || pcg); w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
         const WinDesc& d = h->desc[w];
         if (d.nS > d.np)
             HIPCHK(h, hipMemsetAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)d.np * d.nS, 0, (size_t)(d.nS - d.np) * d.nS * 8, h->up_stream));
@@ -818,6 +847,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.var_act = dp<int>(h, BUF_VARACT);
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS); B.item_mid = dp<int>(h, BUF_ITEMMID);
+    B.adj_begin = dp<int>(h, BUF_ADJBEG); B.adj = dp<int>(h, BUF_ADJ); B.pcg_v = dp<double>(h, BUF_PCGV); B.pcg_m = dp<double>(h, BUF_PCGM);
     B.lmask = dp<unsigned long long>(h, BUF_LMASK); B.kf_seg = dp<int>(h, BUF_KFSEG); B.ref_seg = dp<int>(h, BUF_REFSEG);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
     B.lin_blk = dp<int>(h, BUF_LINBLK);
@@ -886,6 +916,10 @@ void enqueue_solve_iteration(Handle* h) {
             }
         }
     }
+    if (h->solver == VBA_SOLVER_PCG) {   // the whole linear solve in one launch: a workgroup per window iterates alone
+        ProfScope ps(h, VBA_PROF_FACTOR);
+        hipLaunchKernelGGL(k_pcg, dim3(n), dim3(256), 0, h->stream, B);
+    } else {
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
         static const int split_min = getenv("VBA_SPLIT_MIN") ? atoi(getenv("VBA_SPLIT_MIN")) : 64;
@@ -909,6 +943,7 @@ void enqueue_solve_iteration(Handle* h) {
         ProfScope ps(h, VBA_PROF_TRSV);
         const size_t shm = ((size_t)h->max_nS + 256 + 32 * 33) * sizeof(double);
         hipLaunchKernelGGL(k_trsv, dim3(n), dim3(256), shm, h->stream, B);
+    }
     }
     {
         ProfScope ps(h, VBA_PROF_UPDATE);
@@ -1316,6 +1351,7 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
                 R->n_trace = c.n_trace;
                 for (int i = 0; i < c.n_trace && i < VBA_TRACE_MAX; i++) R->chi2_trace[i] = c.trace[i];
                 R->lambda_final = c.lambda;
+                R->lin_iterations = c.lin_its;
                 if (c.status != VBA_ABORTED_BEFORE && d.n_obs) {
                     if (R->obs_outlier) get(R->obs_outlier, B.out_outlier + d.obs0, h->stg.dl_outl.data() + d.obs0, (size_t)d.n_obs);
                     if (R->obs_chi2) get(R->obs_chi2, B.out_chi2 + d.obs0, h->stg.dl_chi2.data() + d.obs0, 8 * (size_t)d.n_obs);
@@ -1446,7 +1482,7 @@ int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile 
     if (stop_flag && *stop_flag) {  // src/Optimizer.cpp:453-455: return before anything is built
         out->status = VBA_ABORTED_BEFORE;
         out->its_done[0] = out->its_done[1] = 0;
-        out->n_outliers = 0; out->n_trace = 0;
+        out->n_outliers = 0; out->n_trace = 0; out->lin_iterations = 0;
         out->chi2_vis = out->chi2_prv = out->chi2_bias = 0;
         return 0;
     }
@@ -1560,7 +1596,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
