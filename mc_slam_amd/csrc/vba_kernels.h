@@ -40,6 +40,7 @@ struct Batch {
     // structure (g2o buildStructure analogue, built on the host at upload)
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
     const int *adj_begin, *adj;         // PCG: per free keyframe the other free keyframes it shares a landmark or an IMU edge with
+    double* kf_dir;                     // XYZ landmarks: per keyframe the damping-independent part of its diagonal block and b_p (32 doubles)
     double *pcg_v, *pcg_m;              // PCG: x r z p q (5 nS per window); inverted diagonal blocks (225 per keyframe)
     const int* item_mid;                // per pair: its first item that involves the landmark's reference keyframe
     const unsigned long long* lmask;    // [n_pt x mwords] observing keyframes of every landmark (host-built while validating)
@@ -910,7 +911,8 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
     if (w_in < 0 && !schur_map(B, max_free, w, a)) return;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
-    if (hd_pass ? !c.active : !win_on(d, c)) return;  // hd_pass: LM's pre-trial pass for computeLambdaInit
+    // hd_pass: LM's pre-trial pass for computeLambdaInit -- part of the "outer" slot, which a window that still owes a trial skips
+    if (hd_pass ? (!c.active || c.lm_need_trial) : !win_on(d, c)) return;
     if (a >= d.n_free) return;
     const int t = threadIdx.x;
     const int pr = a * d.n_free - a * (a - 1) / 2;  // index of pair (a,a)
@@ -933,13 +935,18 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
     }
     for (int it = t; it < n_o + n_r; it += 64) {
         const int sa = (it < n_o) ? s0 + it : d.n_obs + r0s + (it - n_o);
+        // XYZ landmarks (Levenberg-Marquardt): the direct terms sum Bi^T Bi and b_p do not depend on the damping, so the pass
+        // that opens an outer iteration (hd_pass) takes them from the edge records ONCE and parks them per keyframe (kf_dir);
+        // the trials then read the slot records U(lambda) only -- 192 B instead of 384 B per record and trial
+        const bool want_u = (LD == 1) || !hd_pass, want_dir = (LD == 1) || hd_pass;
         const double* qa = slots + SS * (size_t)sa;
         double UA[6 * LD], beta[LD];
 #pragma unroll
-        for (int i = 0; i < 6 * LD; i++) UA[i] = qa[i];
+        for (int i = 0; i < 6 * LD; i++) UA[i] = want_u ? qa[i] : 0.0;
 #pragma unroll
-        for (int l = 0; l < LD; l++) beta[l] = qa[6 * LD + l];
-        if (LD == 1 && sa >= d.n_obs) {
+        for (int l = 0; l < LD; l++) beta[l] = want_u ? qa[6 * LD + l] : 0.0;
+        if (!want_dir) {
+        } else if (LD == 1 && sa >= d.n_obs) {
             const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + sa - d.n_obs);
 #pragma unroll
             for (int g = 0; g < 21; g++) acc[g] += pr_[g];
@@ -964,7 +971,6 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
             for (int i = 0; i < 6; i++) {
 #pragma unroll
                 for (int j = i; j < 6; j++) acc[gi++] += b0[i] * b0[j] + b1[i] * b1[j];
-                if (LD != 1) hd[i] += b0[i] * b0[i] + b1[i] * b1[i];
                 bp[i] += (LD == 1) ? -(b0[i] * r0 + b1[i] * r1) : ra[24 + i];
             }
         }
@@ -984,7 +990,24 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
 #pragma unroll
     for (int i = 0; i < 21; i++) acc[i] = wave_sum(acc[i]);
 #pragma unroll
-    for (int i = 0; i < 6; i++) { rhs[i] = wave_sum(rhs[i]); bp[i] = wave_sum(bp[i]); if (LD != 1) hd[i] = wave_sum(hd[i]); }
+    for (int i = 0; i < 6; i++) { rhs[i] = wave_sum(rhs[i]); bp[i] = wave_sum(bp[i]); }
+    if (LD != 1) {
+        double* kd = B.kf_dir + 32 * (size_t)(d.kf0 + a);
+        if (hd_pass) {
+            if (t == 0) {
+#pragma unroll
+                for (int g = 0; g < 21; g++) kd[g] = acc[g];
+#pragma unroll
+                for (int i = 0; i < 6; i++) kd[21 + i] = bp[i];
+            }
+            hd[0] = acc[0]; hd[1] = acc[6]; hd[2] = acc[11]; hd[3] = acc[15]; hd[4] = acc[18]; hd[5] = acc[20];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 21; g++) acc[g] += kd[g];
+#pragma unroll
+            for (int i = 0; i < 6; i++) bp[i] = kd[21 + i];
+        }
+    }
     const int P = d.pdim;
     for (int q = t; q < P * P; q += 64) blk[q] = 0.0;
     __syncthreads();
@@ -998,7 +1021,7 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
         }
     }
     __syncthreads();
-    schur_write_block(B, d, c, w, pr, a, a, blk);
+    if (!hd_pass) schur_write_block(B, d, c, w, pr, a, a, blk);   // (the hd pass only feeds lambda init and b_p)
     if (t < P) {
         double s = 0.0, sb = 0.0, h = 0.0;
         if (t < 6) { s = sh_r[t]; sb = sh_b[t]; h = sh_h[t]; }
@@ -1014,7 +1037,7 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
         const bool act = B.var_act[d.vec0 + gr] != 0;
         (B.vec + d.vec0)[gr] = act ? (sb + s) : 0.0;            // reduced rhs = b_p - sum W Dinv b_l
         (B.bpose + 2 * (size_t)d.vec0)[gr] = act ? sb : 0.0;        // unreduced b_p (LM computeScale)
-        (B.bpose + 2 * (size_t)d.vec0)[d.nS + gr] = act ? h : 0.0;  // H_pp diagonal (LM computeLambdaInit)
+        if (LD == 1 || hd_pass) (B.bpose + 2 * (size_t)d.vec0)[d.nS + gr] = act ? h : 0.0;  // H_pp diagonal (LM computeLambdaInit)
     }
 }
 __global__ void __launch_bounds__(64) k_schur_diag(Batch B, int max_free) {
@@ -1031,14 +1054,6 @@ __global__ void __launch_bounds__(64, 3) k_schur_all(Batch B, int max_free, int 
     if (!schur_map(B, max_free + max_quads, w, idx)) return;
     if (idx < max_free) schur_diag_body<1>(B, max_free, 0, blk, sh_r, sh_b, sh_h, w, idx);
     else schur_off_body<1, 16>(B, max_quads, blk, w, idx - max_free);
-}
-__global__ void __launch_bounds__(64, 3) k_schur_all3(Batch B, int max_free, int max_quads) {  // XYZ landmarks
-    __shared__ double blk[15 * 15 + 16];
-    __shared__ double sh_r[6], sh_b[6], sh_h[6];
-    int w, idx;
-    if (!schur_map(B, max_free + max_quads, w, idx)) return;
-    if (idx < max_free) schur_diag_body<3>(B, max_free, 0, blk, sh_r, sh_b, sh_h, w, idx);
-    else schur_off_body<3, 16>(B, max_quads, blk, w, idx - max_free);
 }
 __global__ void __launch_bounds__(64) k_schur_diag3(Batch B, int max_free, int hd_pass) {
     __shared__ double blk[15 * 15 + 16];

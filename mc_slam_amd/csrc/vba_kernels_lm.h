@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(64) k_lin_xyz(Batch B, int nblk_pt, int mode) 
     const WinCtrl& c = B.ctrl[w];
     if (!c.active) return;
     if (mode == LIN_ERR_TRIAL && !win_on(d, c)) return;
+    if (mode == LIN_FULL && d.algo == 1 && c.lm_need_trial) return;   // "outer" slot of the LM schedule: not for a window that still owes a trial
     const int m = (mode == LIN_FULL) ? LIN_FULL : LIN_ERR;
     if ((int)blockIdx.x < nblk_pt) {
         const int p = blockIdx.x * 64 + threadIdx.x;
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_outer(Batch B) {
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
-    if (!c.active) return;
+    if (!c.active || c.lm_need_trial) return;   // the window is still inside the trials of its current outer iteration
     const int t = threadIdx.x;
     const double cur = window_chi2(B, d, sm);
     double mx = 0.0;
@@ -443,7 +444,8 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_outer(Batch B) {
 
 // one LM trial has been solved, applied and re-evaluated: rho test, lambda update, accept / reject, and when
 // the do-while ends the per-iteration stop rules (levenberg.cpp:120-161)
-__global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* need_more) {
+// alive: pinned host word of this slot group; set when the window goes on (another trial or another outer iteration)
+__global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* alive) {
     __shared__ double sm[64];
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
@@ -483,7 +485,7 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* need_more) {
     const int stop = (B.stop_word && *B.stop_word) ? 1 : 0;
     if (rho < 0 && qmax < 10 && !stop) {
         c.lm_need_trial = 1;
-        *need_more = 1;
+        __hip_atomic_store(alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // a posted store, not a PCIe atomic
         return;
     }
     c.lm_need_trial = 0;
@@ -498,5 +500,5 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* need_more) {
         if (c.nbad >= 3) term = true;
     }
     if (term || c.it >= d.its[st]) c.active = 0;
-    else need_more[1] = 1;  // at least one window goes on to another outer iteration
+    else __hip_atomic_store(alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // goes on to another outer iteration
 }

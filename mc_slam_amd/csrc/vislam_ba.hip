@@ -146,7 +146,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_N
 };
 
 struct ProfEvt {
@@ -783,7 +783,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     // built on the device (vba_structure.h): record orders, keyframe segments, item lists; + the scratch of the build
     if (dalloc(h, BUF_OBSPT, (size_t)obs0 * 4) || dalloc(h, BUF_SLOTPERM, (size_t)obs0 * 4) || dalloc(h, BUF_PTPERM, (size_t)pt0 * 4)) return -1;
     if (dalloc(h, BUF_KFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_REFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_KEYSEG, ((size_t)kf0 + n) * 4)) return -1;
-    if (dalloc(h, BUF_TSLOT, (size_t)obs0 * 4)) return -1;
+    if (dalloc(h, BUF_TSLOT, (size_t)obs0 * 4) || dalloc(h, BUF_KFDIR, (size_t)kf0 * 32 * 8)) return -1;
     if (dalloc(h, BUF_ITEMBEG, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMMID, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMS, (size_t)item0 * 8)) return -1;
     if (dalloc(h, BUF_STKEY, (size_t)pt0 * 4) || dalloc(h, BUF_LMORDER, (size_t)pt0 * 4) || dalloc(h, BUF_SLOTOBS, (size_t)obs0 * 4) || dalloc(h, BUF_PTINV, (size_t)pt0 * 4)) return -1;
     if (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow)) return -1;
@@ -847,6 +847,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.var_act = dp<int>(h, BUF_VARACT);
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS); B.item_mid = dp<int>(h, BUF_ITEMMID);
+    B.kf_dir = dp<double>(h, BUF_KFDIR);
     B.adj_begin = dp<int>(h, BUF_ADJBEG); B.adj = dp<int>(h, BUF_ADJ); B.pcg_v = dp<double>(h, BUF_PCGV); B.pcg_m = dp<double>(h, BUF_PCGM);
     B.lmask = dp<unsigned long long>(h, BUF_LMASK); B.kf_seg = dp<int>(h, BUF_KFSEG); B.ref_seg = dp<int>(h, BUF_REFSEG);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
@@ -906,14 +907,10 @@ void enqueue_solve_iteration(Handle* h) {
             }
         } else {
             hipLaunchKernelGGL(k_dinv, dim3(h->max_pt_blk, n), dim3(64), 0, h->stream, B);
-            static const int fused_schur3 = getenv("VBA_SCHUR_FUSE3") ? 1 : 0;  // measured on C2: no gain for the 192-B XYZ records
-            if (rn >= 8 && fused_schur3) {
-                hipLaunchKernelGGL(k_schur_all3, dim3((h->max_free + h->max_quads) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_quads);
-            } else {
-                hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 0);
-                if (rn >= 8) hipLaunchKernelGGL(k_schur_off3, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
-                else hipLaunchKernelGGL(k_schur_off3_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
-            }
+            // (diagonal and off-diagonal pairs in two launches: fusing them as for the inverse-depth records gained nothing at C2)
+            hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 0);
+            if (rn >= 8) hipLaunchKernelGGL(k_schur_off3, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
+            else hipLaunchKernelGGL(k_schur_off3_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
         }
     }
     if (h->solver == VBA_SOLVER_PCG) {   // the whole linear solve in one launch: a workgroup per window iterates alone
@@ -972,11 +969,17 @@ struct Group {
     bool dead;
 };
 
-// Levenberg-Marquardt schedule (levenberg.cpp:61-164) of a batch cut into window groups.  One trial = damp, Schur, factor,
-// solve, update, re-evaluate; the device decides accept / reject.  The host learns through two pinned words per group
-// whether any of its windows needs another trial (rho < 0) or another outer iteration, and enqueues only those -- one
-// host round trip per trial.  With several groups the round trip of one group is hidden behind the kernels of the
-// others: a single host thread polls the groups' events and enqueues the next piece of whichever group is ready.
+// Levenberg-Marquardt schedule (levenberg.cpp:61-164) of a batch cut into window groups, device-resident.
+// The launch stream of a group is a sequence of SLOT GROUPS [outer, trial]:
+//   outer = linearise + computeLambdaInit + the bookkeeping that opens an outer iteration   -- for windows that owe no trial
+//   trial = damp, Schur, factor, solve, update, re-evaluate, accept / reject (+ restore)    -- for windows that owe one
+// Every kernel is gated per window on WinCtrl (active, lm_need_trial), so each window consumes the slots that apply to it:
+// the usual outer iteration takes one [outer, trial]; a window whose step is rejected skips the next group's outer slot (its
+// workgroups exit at once) and retries in that group's trial slot -- windows drift apart by whole slots, never inside one, and a
+// window that needs no retry never pays for one (a speculative second trial slot per group cost 6 % at C2: ~20 launches whose
+// 300 k workgroups only exit).  The host learns through one
+// pinned word per slot group whether any window of the group of windows is still going, and stays two slot groups ahead of
+// the device (as the Gauss-Newton schedule does): no host round trip per trial, none per outer iteration on the critical path.
 int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile int* stop_flag) {
     const int big_blk = std::max(std::max(h->max_kf_blk, h->max_pt_blk), h->max_obs_blk);
     const int kp_blk = std::max(h->max_kf_blk, h->max_pt_blk);
@@ -984,8 +987,6 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
     const int n_all = h->n_win;
     hipStream_t main_stream = h->stream;
     auto use = [&](const Group& g) { h->B = g.B; h->n_win = g.n_win; h->stream = g.stream; };
-    struct State { int stage = 0, it = 0, trial = 0; bool waiting = false, done = false; hipEvent_t ev = nullptr; };
-    std::vector<State> st(groups.size());
     auto stage_begin = [&](Group& g, int stage) {
         ProfScope ps(h, VBA_PROF_MISC);
         hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
@@ -1005,10 +1006,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, g.stream, g.B, h->max_free, 1);
         hipLaunchKernelGGL(k_ctrl_lm_outer, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
     };
-    auto trial = [&](Group& g, size_t gi, State& s) -> int {
-        volatile int* flags = h->stop_host + 4 + 2 * gi;  // [0] another trial, [1] another outer iteration
-        flags[0] = 0;
-        flags[1] = 0;
+    auto trial = [&](Group& g, int* alive_dev) {
         {
             ProfScope ps(h, VBA_PROF_MISC);
             hipLaunchKernelGGL(k_backup, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
@@ -1017,13 +1015,9 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         enqueue_lin(h, LIN_ERR_TRIAL);
         {
             ProfScope ps(h, VBA_PROF_CONTROL);
-            hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(g.n_win), dim3(64), 0, g.stream, g.B, h->stop_dev + 4 + 2 * gi);
+            hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(g.n_win), dim3(64), 0, g.stream, g.B, alive_dev);
             hipLaunchKernelGGL(k_restore, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
         }
-        if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) return -1;
-        if (hipEventRecord(s.ev, g.stream) != hipSuccess) return -1;
-        s.waiting = true;
-        return 0;
     };
     auto finish = [&](Group& g) {
         ProfScope ps(h, VBA_PROF_MISC);
@@ -1032,60 +1026,49 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         hipLaunchKernelGGL(k_final_edges, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
         hipLaunchKernelGGL(k_final_sum, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
     };
-    // a stage with zero iterations still runs its prologue / epilogue (optimize(0) is a no-op in g2o)
-    auto start_stage = [&](Group& g, size_t gi, State& s) -> int {
-        for (;;) {
-            stage_begin(g, s.stage);
-            if (h->max_its[s.stage] > 0) {
-                s.it = 0; s.trial = 0;
-                outer(g);
-                return trial(g, gi, s);
-            }
-            stage_end(g);
-            if (s.stage == 1) { finish(g); s.done = true; return 0; }
-            s.stage = 1;
-        }
-    };
-    int rc = 0;
-    for (size_t gi = 0; gi < groups.size() && rc == 0; gi++) {
-        Group& g = groups[gi];
+    for (auto& g : groups) {
         use(g);
-        {
-            ProfScope ps(h, VBA_PROF_MISC);
-            hipLaunchKernelGGL(k_reset, dim3(big_blk, g.n_win), dim3(64), 0, g.stream, g.B);
-        }
-        rc = start_stage(g, gi, st[gi]);
+        ProfScope ps(h, VBA_PROF_MISC);
+        hipLaunchKernelGGL(k_reset, dim3(big_blk, g.n_win), dim3(64), 0, g.stream, g.B);
     }
-    size_t n_done = 0;
-    for (auto& s : st) n_done += s.done ? 1 : 0;
-    while (rc == 0 && n_done < groups.size()) {
-        bool progressed = false;
-        for (size_t gi = 0; gi < groups.size() && rc == 0; gi++) {
-            State& s = st[gi];
-            if (s.done || !s.waiting) continue;
-            if (groups.size() == 1) { if (hipEventSynchronize(s.ev) != hipSuccess) { rc = -1; break; } }
-            else {
-                const hipError_t q = hipEventQuery(s.ev);
-                if (q == hipErrorNotReady) continue;
-                if (q != hipSuccess) { rc = -1; break; }
+    const int RING = 32;   // pinned alive words per window group (its 64-word block: [0, RING) used here)
+    int rc = 0;
+    for (int stage = 0; stage < 2 && rc == 0; stage++) {
+        for (auto& g : groups) { use(g); stage_begin(g, stage); }
+        if (h->max_its[stage] > 0) {
+            // upper bound of the slot groups a stage can need: every outer iteration may take up to 10 trials
+            const int max_groups = 10 * h->max_its[stage] + 2;
+            std::vector<std::vector<hipEvent_t>> ev(groups.size());
+            for (auto& g : groups) g.dead = false;
+            for (int j = 0; j < max_groups; j++) {
+                bool any = false;
+                for (size_t gi = 0; gi < groups.size(); gi++) {
+                    Group& g = groups[gi];
+                    if (g.dead) continue;
+                    if (j >= 2) {
+                        if (hipEventSynchronize(ev[gi][j - 2]) != hipSuccess) { rc = -1; break; }
+                        if (g.alive[(j - 2) % RING] == 0) { g.dead = true; continue; }   // nobody went on after slot group j-2
+                    }
+                    any = true;
+                    use(g);
+                    if (stop_flag && *stop_flag) *h->stop_host = 1;
+                    g.alive[j % RING] = 0;   // the word's previous user (group j - RING) was consumed long ago
+                    int* alive_dev = h->stop_dev + (g.alive - h->stop_host) + (j % RING);
+                    outer(g);
+                    trial(g, alive_dev);
+                    ev[gi].push_back(get_evt(h));
+                    if (hipEventRecord(ev[gi][j], g.stream) != hipSuccess) { rc = -1; break; }
+                }
+                if (!any || rc) break;
             }
-            progressed = true;
-            s.waiting = false;
-            Group& g = groups[gi];
-            use(g);
-            if (stop_flag && *stop_flag) *h->stop_host = 1;
-            volatile int* flags = h->stop_host + 4 + 2 * gi;
-            const bool more_trial = flags[0] != 0, more_outer = flags[1] != 0;
-            if (more_trial && s.trial + 1 < 10) { s.trial++; rc = trial(g, gi, s); continue; }
-            if (more_outer && s.it + 1 < h->max_its[s.stage]) { s.it++; s.trial = 0; outer(g); rc = trial(g, gi, s); continue; }
-            stage_end(g);
-            if (s.stage == 0) { s.stage = 1; rc = start_stage(g, gi, s); if (s.done) n_done++; }
-            else { finish(g); s.done = true; n_done++; }
         }
-        if (!progressed) std::this_thread::yield();
+        for (auto& g : groups) { use(g); stage_end(g); }
     }
-    for (auto& s : st)
-        if (s.ev) (void)hipEventDestroy(s.ev);
+    for (auto& g : groups) {
+        if (rc) break;
+        use(g);
+        finish(g);
+    }
     h->B = B_all; h->n_win = n_all; h->stream = main_stream;
     return rc;
 }
@@ -1596,7 +1579,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
