@@ -15,13 +15,17 @@
 #pragma once
 #include "vba_kernels.h"
 
+typedef unsigned long long u64_t;
+
 struct StBuild {   // what the build writes (the solve reads the same arrays through Batch, as const)
     int *obs_pt, *slot_perm, *pt_perm, *kf_seg, *ref_seg, *item_begin, *item_mid, *items;
     int *st_key, *lm_order, *slot_obs, *pt_inv;   // scratch: first keyframe of a track, landmark at rank q, landmark of the record in slot s, landmark in record r
     int *key_seg, *tslot;                         // scratch: landmarks per first keyframe (starts); per landmark its slots in keyframe order
+    u64_t *mask_q, *slot_mask;                    // scratch: the landmark masks in lm_order / per slot record, so that the ranked
+                                                  // walks read them in sequence instead of gathering them through an index
+    int *ref_q;                                   // scratch: reference keyframe of the landmark at rank q
+    int smw;                                      // words per slot_mask entry (the largest mwords of the batch)
 };
-
-typedef unsigned long long u64_t;
 
 DEVI u64_t wave_or64(u64_t v) {
 #pragma unroll
@@ -115,7 +119,12 @@ __global__ void __launch_bounds__(64) k_st_rank_lm(Batch B, StBuild T) {
         const int p = c + lane;
         const bool has = p < npt && T.st_key[d.pt0 + p] == k;
         const u64_t m = __ballot(has);
-        if (has) T.lm_order[d.pt0 + base + __popcll(m & lt)] = p;
+        if (has) {
+            const int q = base + __popcll(m & lt);
+            T.lm_order[d.pt0 + q] = p;
+            T.ref_q[d.pt0 + q] = B.pt_ref[d.pt0 + p];
+            for (int wd = 0; wd < d.mwords; wd++) T.mask_q[d.mask0 + (size_t)q * d.mwords + wd] = B.lmask[d.mask0 + (size_t)p * d.mwords + wd];
+        }
         base += __popcll(m);
     }
 }
@@ -139,9 +148,10 @@ __global__ void __launch_bounds__(64) k_st_rank_rec(Batch B, StBuild T) {
     for (int c = 0; c < q_end && (bo < eo || br < er); c += 64) {
         const int q = c + lane;
         const bool valid = q < q_end;
-        const int p = valid ? T.lm_order[d.pt0 + q] : 0;
-        const u64_t* M = LM + (size_t)p * mw;
+        const u64_t* M = T.mask_q + d.mask0 + (size_t)(valid ? q : 0) * mw;   // masks in lm_order: read in sequence
         const bool haso = valid && ((M[kw] >> kb) & 1ull);
+        const bool hasr = valid && idp && T.ref_q[d.pt0 + q] == k;
+        const int p = (haso || hasr) ? T.lm_order[d.pt0 + q] : 0;
         const u64_t mo = __ballot(haso);
         if (haso) {
             const int slot = bo + __popcll(mo & lt);
@@ -149,12 +159,12 @@ __global__ void __launch_bounds__(64) k_st_rank_rec(Batch B, StBuild T) {
             while (B.obs_kf[d.obs0 + o] != k) o++;
             T.slot_perm[d.obs0 + o] = slot;
             T.slot_obs[d.obs0 + slot] = p;   // the landmark of the record in this slot
+            for (int wd = 0; wd < mw; wd++) T.slot_mask[(size_t)(d.obs0 + slot) * T.smw + wd] = M[wd];
             int r = __popcll(M[kw] & ((1ull << kb) - 1ull));
             for (int wd = 0; wd < kw; wd++) r += __popcll(M[wd]);
             T.tslot[d.obs0 + ob[p] + r] = slot;   // the landmark's slots in keyframe order (st_slot_of)
         }
         bo += __popcll(mo);
-        const bool hasr = valid && idp && B.pt_ref[d.pt0 + p] == k;
         const u64_t mr = __ballot(hasr);
         if (hasr) {
             const int r = br + __popcll(mr & lt);
@@ -209,7 +219,7 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
         for (int wd = a >> 6; wd < mw; wd++) {
             const u64_t rg = range(wd);
             if (!rg) continue;
-            const u64_t Mr = valid ? (LM[(size_t)p * mw + wd] & rg) : 0ull;
+            const u64_t Mr = valid ? (T.slot_mask[(size_t)(d.obs0 + slot) * T.smw + wd] & rg) : 0ull;
             const u64_t rb = (r > a && r < nf && (r >> 6) == wd) ? (1ull << (r & 63)) : 0ull;
             u64_t U = wave_or64(Mr | rb);
             while (U) {

@@ -146,7 +146,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_N
 };
 
 struct ProfEvt {
@@ -783,6 +783,11 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     // built on the device (vba_structure.h): record orders, keyframe segments, item lists; + the scratch of the build
     if (dalloc(h, BUF_OBSPT, (size_t)obs0 * 4) || dalloc(h, BUF_SLOTPERM, (size_t)obs0 * 4) || dalloc(h, BUF_PTPERM, (size_t)pt0 * 4)) return -1;
     if (dalloc(h, BUF_KFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_REFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_KEYSEG, ((size_t)kf0 + n) * 4)) return -1;
+    size_t slotmask_words = 1;
+    {
+        for (int w = 0; w < n; w++) slotmask_words = std::max(slotmask_words, (size_t)h->desc[w].mwords);
+        if (dalloc(h, BUF_MASKQ, (size_t)mask0 * 8) || dalloc(h, BUF_SLOTMASK, (size_t)obs0 * slotmask_words * 8) || dalloc(h, BUF_REFQ, (size_t)pt0 * 4)) return -1;
+    }
     if (dalloc(h, BUF_TSLOT, (size_t)obs0 * 4) || dalloc(h, BUF_KFDIR, (size_t)kf0 * 32 * 8)) return -1;
     if (dalloc(h, BUF_ITEMBEG, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMMID, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMS, (size_t)item0 * 8)) return -1;
     if (dalloc(h, BUF_STKEY, (size_t)pt0 * 4) || dalloc(h, BUF_LMORDER, (size_t)pt0 * 4) || dalloc(h, BUF_SLOTOBS, (size_t)obs0 * 4) || dalloc(h, BUF_PTINV, (size_t)pt0 * 4)) return -1;
@@ -870,6 +875,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         const size_t sh_order = 3 * ((size_t)max_kf + 1) * sizeof(int), sh_row = 2 * (size_t)std::max(1, h->max_free) * sizeof(int);
         if (sh_order > 60000 || sh_row > 60000) return fail(h, "window with too many keyframes for the structure build");
         T.key_seg = dp<int>(h, BUF_KEYSEG); T.tslot = dp<int>(h, BUF_TSLOT);
+        T.mask_q = dp<unsigned long long>(h, BUF_MASKQ); T.slot_mask = dp<unsigned long long>(h, BUF_SLOTMASK); T.ref_q = dp<int>(h, BUF_REFQ);
+        T.smw = (int)slotmask_words;
         hipLaunchKernelGGL(k_st_hist, dim3(n), dim3(256), sh_order, h->up_stream, B, T);
         hipLaunchKernelGGL(k_st_rank_lm, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
         hipLaunchKernelGGL(k_st_rank_rec, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
@@ -1579,7 +1586,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
