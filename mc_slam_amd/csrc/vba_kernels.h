@@ -41,7 +41,7 @@ struct Batch {
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
     const int *adj_begin, *adj;         // PCG: per free keyframe the other free keyframes it shares a landmark or an IMU edge with
     double* kf_dir;                     // XYZ landmarks: per keyframe the damping-independent part of its diagonal block and b_p (32 doubles)
-    double *pcg_v, *pcg_m;              // PCG: x r z p q (5 nS per window); inverted diagonal blocks (225 per keyframe)
+    double *pcg_v, *pcg_m, *pcg_s;      // PCG: x r z p q (5 nS per window); inverted diagonal blocks (225 per keyframe); CG state (8 per window)
     const int* item_mid;                // per pair: its first item that involves the landmark's reference keyframe
     const unsigned long long* lmask;    // [n_pt x mwords] observing keyframes of every landmark (host-built while validating)
     const int *kf_seg, *ref_seg;        // [n_kf + 1] per window: record range of every keyframe -- slot / edge records by observing

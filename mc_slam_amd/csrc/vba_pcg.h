@@ -6,11 +6,17 @@
 // from the reference's copy) implements: block-Jacobi preconditioner (the pdim x pdim diagonal block of every keyframe,
 // inverted once per solve), CG on S x = b, stop at sqrt(r'M^-1 r / r0'M^-1 r0) <= 1e-10 or after 20 n_p iterations.
 //
-// S is the matrix the Schur kernels assemble (lower triangle, block-sparse by keyframe pair); one workgroup per window
-// mirrors its non-zero blocks above the diagonal once, so that every product walks rows, then iterates alone: no launch and no
-// host round trip per CG iteration, all sums in a fixed order.  On the visual-inertial systems of this backend the method is
-// slow by nature -- cond(S) ~ 1e9..1e10 (velocity / bias blocks against pose blocks) and block-Jacobi needs ~0.6 n_p
-// iterations -- which is why the reference solves directly; see DESIGN.md for the measured comparison.
+// S is the matrix the Schur kernels assemble (lower triangle, block-sparse by keyframe pair).  k_pcg_init mirrors its non-zero
+// blocks above the diagonal once per solve, so that every product walks rows, and inverts the diagonal blocks; one CG iteration
+// is two launches for the whole batch: k_pcg_matvec (q = S p, a lane per row over the row's non-zero blocks, every 64-row block
+// of every window its own workgroup, partial p.q per workgroup) and k_pcg_step (one workgroup per window: alpha, x, r,
+// z = M^-1 r, beta, p, the stop test; all sums in a fixed order).  Windows that have converged exit at once.  The host enqueues
+// iterations in batches and looks at one pinned word per batch, two batches behind the device (vislam_ba.hip).
+// (A first version iterated inside ONE workgroup per window, without launches: 3 ms per CG iteration at C4 size, a single CU
+// walking 8.6 MB of blocks -- 800x slower than the LDL^T path.)
+// On the visual-inertial systems of this backend the method is slow by nature -- cond(S) ~ 1e9..1e10 (velocity / bias blocks
+// against pose blocks) and block-Jacobi needs ~0.5 n_p iterations -- which is why the reference solves directly; see DESIGN.md
+// for the measured comparison.
 #pragma once
 #include "vba_kernels.h"
 
@@ -44,112 +50,186 @@ DEVI bool pcg_block_inverse(int P, const double* A, int lda, double* Ai) {
     return true;
 }
 
-__global__ void __launch_bounds__(256) k_pcg(Batch B) {
+// per-window CG state lives in WinCtrl-independent scratch: pcg_s[8 * win + ..] = rz, rz0, done, iterations, bad
+#define PCG_RZ 0
+#define PCG_RZ0 1
+#define PCG_DONE 2
+#define PCG_ITS 3
+#define PCG_BAD 4
+#define PCG_STATE 8
+#define PCG_ROWS 64   // rows per matvec workgroup
+
+DEVI double* pcg_vec(const Batch& B, const WinDesc& d, int which) { return B.pcg_v + 5 * (size_t)d.vec0 + (size_t)which * d.nS; }   // x r z p q
+
+// z = M^-1 r for rows [i0, i1) of the window, one thread per row
+DEVI void pcg_precond(const Batch& B, const WinDesc& d, int t, int nt) {
+    const int P = d.pdim;
+    const double* Mi = B.pcg_m + 225 * (size_t)d.kf0;
+    const double* rs = pcg_vec(B, d, 1);
+    double* zs = pcg_vec(B, d, 2);
+    for (int i = t; i < P * d.n_free; i += nt) {
+        const int a = i / P, r = i % P;
+        const double* m = Mi + 225 * (size_t)a + r * P;
+        double s = 0.0;
+        for (int q = 0; q < P; q++) s += m[q] * rs[vpos(d, a, q)];
+        zs[vpos(d, a, r)] = s;
+    }
+}
+
+// once per solve: mirror S, invert the diagonal blocks, x = 0, r = b, z = M^-1 r, p = z, rz
+__global__ void __launch_bounds__(256) k_pcg_init(Batch B) {
     __shared__ double red[4];
     __shared__ int sh_bad;
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
-    WinCtrl& c = B.ctrl[w];
-    if (!win_on(d, c)) return;
-    const int t = threadIdx.x, n = d.nS, P = d.pdim, nf = d.n_free;
+    const WinCtrl& c = B.ctrl[w];
+    double* st = B.pcg_s + PCG_STATE * (size_t)d.win;
+    const int t = threadIdx.x, n = d.nS, P = d.pdim, nf = d.n_free, np = d.np;
+    if (!win_on(d, c)) {
+        if (t == 0) st[PCG_DONE] = 1.0;   // not part of this solve
+        return;
+    }
     double* S = B.S + d.S0;
-    double* xs = B.pcg_v + 5 * (size_t)d.vec0;   // x, r, z, p, q  (nS each)
-    double *rs = xs + n, *zs = rs + n, *ps = zs + n, *qs = ps + n;
-    double* Mi = B.pcg_m + 225 * (size_t)d.kf0;  // inverted diagonal blocks
-    const double* rhs = B.vec + d.vec0;
     const int* ab = B.adj_begin + d.kf0 + d.win;
     const int* adj = B.adj + d.adj0;
     if (t == 0) sh_bad = 0;
     __syncthreads();
-    // mirror the non-zero off-diagonal blocks above the diagonal (the Schur kernels write gr >= gc only), invert the diagonal ones
-    for (int a = 0; a < nf; a++)
-        for (int e = ab[a]; e < ab[a + 1]; e++) {
-            const int b = adj[e];
+    for (int a = 0; a < nf; a++) {   // the Schur kernels write gr >= gc only
+        for (int e = ab[a]; e <= ab[a + 1]; e++) {
+            const int b = (e < ab[a + 1]) ? adj[e] : a;   // the diagonal block last
             for (int q = t; q < P * P; q += 256) {
                 const int gr = vpos(d, a, q / P), gc = vpos(d, b, q % P);
                 if (gr < gc) S[(size_t)gr * n + gc] = S[(size_t)gc * n + gr];
             }
         }
-    for (int a = 0; a < nf; a++)
-        for (int q = t; q < P * P; q += 256) {
-            const int gr = vpos(d, a, q / P), gc = vpos(d, a, q % P);
-            if (gr < gc) S[(size_t)gr * n + gc] = S[(size_t)gc * n + gr];
-        }
+    }
     __syncthreads();
+    double* Mi = B.pcg_m + 225 * (size_t)d.kf0;
     for (int a = t; a < nf; a += 256) {
         double blk[225];
         for (int i = 0; i < P; i++)
             for (int j = 0; j < P; j++) blk[i * P + j] = S[(size_t)vpos(d, a, i) * n + vpos(d, a, j)];
         if (!pcg_block_inverse(P, blk, P, Mi + 225 * (size_t)a)) sh_bad = 1;
     }
-    __syncthreads();
-    if (sh_bad) {   // a diagonal block is not positive definite: the same verdict the LDL^T path reaches (linear_solver_eigen.h:105-111)
-        if (t == 0) c.chol_fail = 1;
-        return;
-    }
-    const int np = d.np;   // rows vpos(a, r) cover [0, np) exactly once
-    auto precond = [&]() {   // z = M^-1 r, one thread per row
-        for (int i = t; i < P * nf; i += 256) {
-            const int a = i / P, r = i % P;
-            const double* m = Mi + 225 * (size_t)a + r * P;
-            double s = 0.0;
-            for (int q = 0; q < P; q++) s += m[q] * rs[vpos(d, a, q)];
-            zs[vpos(d, a, r)] = s;
-        }
-    };
-    auto matvec = [&]() {    // q = S p over the non-zero blocks of every row
-        for (int i = t; i < P * nf; i += 256) {
-            const int a = i / P, r = i % P;
-            const int gr = vpos(d, a, r);
-            const double* row = S + (size_t)gr * n;
-            double s = 0.0;
-            for (int q = 0; q < P; q++) { const int gc = vpos(d, a, q); s += row[gc] * ps[gc]; }
-            for (int e = ab[a]; e < ab[a + 1]; e++) {
-                const int b = adj[e];
-                for (int q = 0; q < P; q++) { const int gc = vpos(d, b, q); s += row[gc] * ps[gc]; }
-            }
-            qs[gr] = s;
-        }
-    };
+    double *xs = pcg_vec(B, d, 0), *rs = pcg_vec(B, d, 1), *zs = pcg_vec(B, d, 2), *ps = pcg_vec(B, d, 3);
+    const double* rhs = B.vec + d.vec0;
     for (int i = t; i < np; i += 256) { xs[i] = 0.0; rs[i] = rhs[i]; }
     __syncthreads();
-    precond();
+    if (sh_bad) {   // a diagonal block is not positive definite: the verdict the LDL^T path reaches (linear_solver_eigen.h:105-111)
+        if (t == 0) { st[PCG_DONE] = 1.0; st[PCG_BAD] = 1.0; st[PCG_ITS] = 0.0; }
+        return;
+    }
+    pcg_precond(B, d, t, 256);
     __syncthreads();
     double loc = 0.0;
     for (int i = t; i < np; i += 256) { ps[i] = zs[i]; loc += rs[i] * zs[i]; }
-    double rz = block_sum256(loc, red);
-    const double rz0 = rz;
-    int it = 0;
-    const int max_it = 20 * np + 50;
-    bool bad = false;
-    if (rz0 > 0.0)
-        for (; it < max_it; it++) {
-            __syncthreads();
-            matvec();
-            __syncthreads();
-            loc = 0.0;
-            for (int i = t; i < np; i += 256) loc += ps[i] * qs[i];
-            const double pq = block_sum256(loc, red);
-            if (!(pq > 0.0)) { bad = true; break; }   // not positive definite along p
-            const double alpha = rz / pq;
-            for (int i = t; i < np; i += 256) { xs[i] += alpha * ps[i]; rs[i] -= alpha * qs[i]; }
-            __syncthreads();
-            precond();
-            __syncthreads();
-            loc = 0.0;
-            for (int i = t; i < np; i += 256) loc += rs[i] * zs[i];
-            const double rz2 = block_sum256(loc, red);
-            if (rz2 <= PCG_TOL * PCG_TOL * rz0) { it++; break; }
-            const double beta = rz2 / rz;
-            for (int i = t; i < np; i += 256) ps[i] = zs[i] + beta * ps[i];
-            rz = rz2;
+    const double rz = block_sum256(loc, red);
+    if (t == 0) {
+        st[PCG_RZ] = rz; st[PCG_RZ0] = rz; st[PCG_ITS] = 0.0; st[PCG_BAD] = 0.0;
+        st[PCG_DONE] = (rz > 0.0) ? 0.0 : 1.0;   // zero right-hand side: x = 0
+    }
+}
+
+// q = S p for PCG_ROWS rows of one window: 16 lanes per row share the row's non-zero blocks (the diagonal block and every 16th
+// neighbour each), a fixed butterfly adds them up; partial p.q of the workgroup's rows
+__global__ void __launch_bounds__(256) k_pcg_matvec(Batch B) {
+    __shared__ double red[4];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const double* st = B.pcg_s + PCG_STATE * (size_t)d.win;
+    if (st[PCG_DONE] != 0.0) return;
+    const int P = d.pdim, n = d.nS;
+    if ((int)blockIdx.x * PCG_ROWS >= P * d.n_free) return;
+    const int t = threadIdx.x, sub = t & 15;
+    const double* S = B.S + d.S0;
+    const double* ps = pcg_vec(B, d, 3);
+    double* qs = pcg_vec(B, d, 4);
+    const int* ab = B.adj_begin + d.kf0 + d.win;
+    const int* adj = B.adj + d.adj0;
+    double pq = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < PCG_ROWS / 16; rr++) {
+        const int i = blockIdx.x * PCG_ROWS + rr * 16 + (t >> 4);
+        double s = 0.0;
+        int gr = 0;
+        if (i < P * d.n_free) {
+            const int a = i / P, r = i % P;
+            gr = vpos(d, a, r);
+            const double* row = S + (size_t)gr * n;
+            const int e0 = ab[a], ne = ab[a + 1] - e0;
+            for (int e = sub; e <= ne; e += 16) {   // e == ne: the diagonal block
+                const int b = (e < ne) ? adj[e0 + e] : a;
+                for (int q = 0; q < P; q++) { const int gc = vpos(d, b, q); s += row[gc] * ps[gc]; }
+            }
         }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (sub == 0 && i < P * d.n_free) {
+            qs[gr] = s;
+            pq += ps[gr] * s;
+        }
+    }
+    pq = block_sum256(pq, red);
+    if (t == 0) B.part[d.part0 + blockIdx.x] = pq;   // (the chi2 partial array is free during the linear solve)
+}
+
+// the rest of the iteration, one workgroup per window
+__global__ void __launch_bounds__(256) k_pcg_step(Batch B, int* alive) {
+    __shared__ double red[4];
+    const int w = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    double* st = B.pcg_s + PCG_STATE * (size_t)d.win;
+    if (st[PCG_DONE] != 0.0) return;
+    const int t = threadIdx.x, np = d.np;
+    const int nblk = (d.pdim * d.n_free + PCG_ROWS - 1) / PCG_ROWS;
+    double loc = 0.0;
+    for (int k = t; k < nblk; k += 256) loc += B.part[d.part0 + k];
+    const double pq = block_sum256(loc, red);
+    const double rz = st[PCG_RZ], rz0 = st[PCG_RZ0];
+    const int it = (int)st[PCG_ITS] + 1;
     __syncthreads();
-    if (bad || it >= max_it) {
+    if (!(pq > 0.0)) {   // not positive definite along p
+        if (t == 0) { st[PCG_DONE] = 1.0; st[PCG_BAD] = 1.0; st[PCG_ITS] = it; }
+        return;
+    }
+    const double alpha = rz / pq;
+    double *xs = pcg_vec(B, d, 0), *rs = pcg_vec(B, d, 1), *zs = pcg_vec(B, d, 2), *ps = pcg_vec(B, d, 3), *qs = pcg_vec(B, d, 4);
+    for (int i = t; i < np; i += 256) { xs[i] += alpha * ps[i]; rs[i] -= alpha * qs[i]; }
+    __syncthreads();
+    pcg_precond(B, d, t, 256);
+    __syncthreads();
+    loc = 0.0;
+    for (int i = t; i < np; i += 256) loc += rs[i] * zs[i];
+    const double rz2 = block_sum256(loc, red);
+    const bool conv = rz2 <= PCG_TOL * PCG_TOL * rz0;
+    const bool out_of_its = it >= 20 * np + 50;
+    if (!conv && !out_of_its) {
+        const double beta = rz2 / rz;
+        for (int i = t; i < np; i += 256) ps[i] = zs[i] + beta * ps[i];
+    }
+    if (t == 0) {
+        st[PCG_RZ] = rz2;
+        st[PCG_ITS] = it;
+        if (conv) st[PCG_DONE] = 1.0;
+        else if (out_of_its) { st[PCG_DONE] = 1.0; st[PCG_BAD] = 1.0; }
+        else __hip_atomic_store(alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// solution -> B.vec, verdict -> WinCtrl
+__global__ void __launch_bounds__(256) k_pcg_finish(Batch B) {
+    const int w = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    WinCtrl& c = B.ctrl[w];
+    if (!win_on(d, c)) return;
+    const double* st = B.pcg_s + PCG_STATE * (size_t)d.win;
+    const int t = threadIdx.x;
+    if (st[PCG_BAD] != 0.0 || st[PCG_DONE] == 0.0) {   // breakdown, or the host gave up enqueuing
         if (t == 0) c.chol_fail = 1;
         return;
     }
+    const double* xs = pcg_vec(B, d, 0);
     double* out = B.vec + d.vec0;
-    for (int i = t; i < np; i += 256) out[i] = xs[i];
-    if (t == 0) c.lin_its += it;
+    for (int i = t; i < d.np; i += 256) out[i] = xs[i];
+    if (t == 0) c.lin_its += (int)st[PCG_ITS];
 }

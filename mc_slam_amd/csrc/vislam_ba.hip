@@ -146,7 +146,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_N
 };
 
 struct ProfEvt {
@@ -174,6 +174,7 @@ struct Handle {
     std::vector<WinDesc> desc;
     std::vector<WinCtrl> hctrl;
     int n_win = 0;
+    int cur_group = 0; // window group being enqueued (its pinned words)
     int regime_n = 0;  // windows of the uploaded batch: decides WHICH kernels run (few-window / many-window variants), so that
                        // cutting the batch into window groups never changes a summation order
     // launch geometry (maxima over the batch)
@@ -811,7 +812,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (pcg) {
         adjbeg.resize((size_t)kf0 + n, 0);
         if (h2d_vec(h, BUF_ADJBEG, adjbeg, G.s_int[7]) || h2d_vec(h, BUF_ADJ, adj, G.s_int[8])) return -1;
-        if (dalloc(h, BUF_PCGV, (size_t)vec0 * 5 * 8) || dalloc(h, BUF_PCGM, (size_t)kf0 * 225 * 8)) return -1;
+        if (dalloc(h, BUF_PCGV, (size_t)vec0 * 5 * 8) || dalloc(h, BUF_PCGM, (size_t)kf0 * 225 * 8) || dalloc(h, BUF_PCGS, (size_t)n * 8 * 8)) return -1;
     }
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d_vec(h, BUF_LINBLK, linblk, G.s_int[6])) return -1;
     if (h2d(h, BUF_OFFPAIR, offpair) || h2d(h, BUF_PAIRMASK, pairmask)) return -1;
@@ -853,7 +854,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS); B.item_mid = dp<int>(h, BUF_ITEMMID);
     B.kf_dir = dp<double>(h, BUF_KFDIR);
-    B.adj_begin = dp<int>(h, BUF_ADJBEG); B.adj = dp<int>(h, BUF_ADJ); B.pcg_v = dp<double>(h, BUF_PCGV); B.pcg_m = dp<double>(h, BUF_PCGM);
+    B.adj_begin = dp<int>(h, BUF_ADJBEG); B.adj = dp<int>(h, BUF_ADJ); B.pcg_v = dp<double>(h, BUF_PCGV); B.pcg_m = dp<double>(h, BUF_PCGM); B.pcg_s = dp<double>(h, BUF_PCGS);
     B.lmask = dp<unsigned long long>(h, BUF_LMASK); B.kf_seg = dp<int>(h, BUF_KFSEG); B.ref_seg = dp<int>(h, BUF_REFSEG);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
     B.lin_blk = dp<int>(h, BUF_LINBLK);
@@ -920,9 +921,30 @@ void enqueue_solve_iteration(Handle* h) {
             else hipLaunchKernelGGL(k_schur_off3_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
         }
     }
-    if (h->solver == VBA_SOLVER_PCG) {   // the whole linear solve in one launch: a workgroup per window iterates alone
+    if (h->solver == VBA_SOLVER_PCG) {
+        // Two launches per CG iteration for all windows of the group; the host enqueues BATCHES of iterations and reads one pinned
+        // word per batch (did any window go on?) two batches behind the device.  Converged windows exit at the first instruction.
         ProfScope ps(h, VBA_PROF_FACTOR);
-        hipLaunchKernelGGL(k_pcg, dim3(n), dim3(256), 0, h->stream, B);
+        hipLaunchKernelGGL(k_pcg_init, dim3(n), dim3(256), 0, h->stream, B);
+        const int per_batch = 32, RING = 16, row_blocks = (h->max_nS + PCG_ROWS - 1) / PCG_ROWS;
+        volatile int* ring = h->stop_host + 1024 + 16 * h->cur_group;
+        int* ring_dev = h->stop_dev + 1024 + 16 * h->cur_group;
+        std::vector<hipEvent_t> ev;
+        const int max_batches = (20 * h->max_nS + 50) / per_batch + 2;
+        for (int b = 0; b < max_batches; b++) {
+            if (b >= 2) {
+                (void)hipEventSynchronize(ev[b - 2]);
+                if (ring[(b - 2) % RING] == 0) break;   // every window had converged (or broken down) by the end of batch b-2
+            }
+            ring[b % RING] = 0;
+            for (int it = 0; it < per_batch; it++) {
+                hipLaunchKernelGGL(k_pcg_matvec, dim3(row_blocks, n), dim3(256), 0, h->stream, B);
+                hipLaunchKernelGGL(k_pcg_step, dim3(n), dim3(256), 0, h->stream, B, ring_dev + (b % RING));
+            }
+            ev.push_back(get_evt(h));
+            (void)hipEventRecord(ev.back(), h->stream);
+        }
+        hipLaunchKernelGGL(k_pcg_finish, dim3(n), dim3(256), 0, h->stream, B);
     } else {
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
@@ -993,7 +1015,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
     const Batch B_all = h->B;
     const int n_all = h->n_win;
     hipStream_t main_stream = h->stream;
-    auto use = [&](const Group& g) { h->B = g.B; h->n_win = g.n_win; h->stream = g.stream; };
+    auto use = [&](const Group& g) { h->B = g.B; h->n_win = g.n_win; h->stream = g.stream; h->cur_group = (int)(&g - &groups[0]); };
     auto stage_begin = [&](Group& g, int stage) {
         ProfScope ps(h, VBA_PROF_MISC);
         hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
@@ -1076,7 +1098,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         use(g);
         finish(g);
     }
-    h->B = B_all; h->n_win = n_all; h->stream = main_stream;
+    h->B = B_all; h->n_win = n_all; h->stream = main_stream; h->cur_group = 0;
     return rc;
 }
 
@@ -1089,8 +1111,8 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
     const Batch B_all = h->B;
     const int n_all = h->n_win;
     hipStream_t main_stream = h->stream;
-    auto use = [&](const Group& g) { h->B = g.B; h->n_win = g.n_win; h->stream = g.stream; };
-    auto restore = [&]() { h->B = B_all; h->n_win = n_all; h->stream = main_stream; };
+    auto use = [&](const Group& g) { h->B = g.B; h->n_win = g.n_win; h->stream = g.stream; h->cur_group = (int)(&g - &groups[0]); };
+    auto restore = [&]() { h->B = B_all; h->n_win = n_all; h->stream = main_stream; h->cur_group = 0; };
     int rc = 0;
     for (auto& g : groups) {
         use(g);
@@ -1398,8 +1420,8 @@ static int make_handle(int device, Handle* parent, Handle** out) {
         h->up_stream = h->dl_stream = h->stream;
     }
     void* hp = nullptr;
-    if (hipHostMalloc(&hp, 4096, hipHostMallocMapped) != hipSuccess) { delete h; return -4; }
-    memset(hp, 0, 4096);
+    if (hipHostMalloc(&hp, 8192, hipHostMallocMapped) != hipSuccess) { delete h; return -4; }   // [0,1024) run control words, [1024,2048) PCG rings
+    memset(hp, 0, 8192);
     h->stop_host = reinterpret_cast<volatile int*>(hp);
     *h->stop_host = 0;
     void* dpw = nullptr;
@@ -1586,7 +1608,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
