@@ -50,13 +50,17 @@ def spawn_ranks(n: int, argv, env=None, out=None, err=None, poll_s: float = 0.05
                                       stderr=subprocess.PIPE, text=True))
     lock = threading.Lock()
 
-    def pump(stream, sink, prefix):
+    def pump(stream, sink, prefix, json_only=False):
         for line in stream:
             with lock:
+                if json_only and not line.lstrip().startswith("{"):   # library chatter on stdout (e.g. "[Gloo] Rank 0 is connected ...")
+                    err.write("[rank 0] " + line)
+                    err.flush()
+                    continue
                 sink.write(prefix + line)
                 sink.flush()
 
-    pumps = [threading.Thread(target=pump, args=(procs[0].stdout, out, ""), daemon=True)]
+    pumps = [threading.Thread(target=pump, args=(procs[0].stdout, out, "", True), daemon=True)]
     pumps += [threading.Thread(target=pump, args=(p.stderr, err, "[rank %d] " % r), daemon=True) for r, p in enumerate(procs)]
     for t in pumps:
         t.start()

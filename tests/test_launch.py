@@ -15,6 +15,7 @@ import json, os, sys
 r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
 sys.stderr.write("hello from %d\n" % r)
+print("[Gloo] chatter of a library on stdout")
 print(json.dumps({"rank": r, "n_gpus": w, "argv": sys.argv[1:]}))
 """
 CHILD_FAIL = r"""
@@ -49,6 +50,7 @@ def test_spawn_relays_rank0_and_forwards_stderr(tmp_path):
     assert j == {"rank": 0, "n_gpus": 3, "argv": ["--steps", "2"]}
     for r in range(3):
         assert "[rank %d] hello from %d" % (r, r) in err.getvalue()
+    assert "[rank 0] [Gloo] chatter" in err.getvalue()     # non-JSON stdout of rank 0 goes to stderr, not into the result line
 
 
 def test_failed_rank_gives_nonzero_exit_and_ends_the_others(tmp_path):
