@@ -240,6 +240,32 @@ DEVI double rl64(double v, int lane) {  // wave-uniform broadcast of one lane's 
 }
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
+// Sums inside a wave without the LDS crossbar: data-parallel-primitive moves (quad permutes, then the two row mirrors) add up the 16
+// lanes of a row in four steps of plain VALU work; `__shfl_xor` costs two ds_bpermute per double and step.  Fixed order.
+template <int CTRL>
+DEVI double dpp_f64(double v) {
+    const int l = __double2loint(v), h = __double2hiint(v);   // (every lane has a source under these controls: `old` is never used)
+    const int lo = __builtin_amdgcn_update_dpp(l, l, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+DEVI double row16_sum(double v) {   // every lane of a 16-lane row ends up with the row's sum
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    return v;
+}
+DEVI double quad_sum(double v) {    // every lane of a quad ends up with the quad's sum
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    return v;
+}
+DEVI double wave64_sum(double v) {  // every lane ends up with the wave's sum: rows by DPP, the four row sums through scalar reads
+    v = row16_sum(v);
+    return ((rl64(v, 0) + rl64(v, 16)) + rl64(v, 32)) + rl64(v, 48);
+}
+
 // Huber (robust_kernel_impl.cpp:78-91): returns rho(e), sets *w = rho'(e)
 DEVI double huber(double e, double delta, double* w) {
     const double dsqr = delta * delta;

@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
                 for (int j = i; j < 3; j++) M[gi++] += b0 * er[j] + b1 * er[3 + j];
             }
         }
-#define QUADSUM(v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); }
+#define QUADSUM(v) { v = quad_sum(v); }
         QUADSUM(D) QUADSUM(bl)
 #pragma unroll
         for (int i = 0; i < 6; i++) QUADSUM(M[i])
@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval) {
 // IMU blocks, writes the pdim x pdim block (and its mirror) exactly once.  Diagonal pairs also produce the
 // reduced right-hand side (:436-439), the unreduced b_p and the H_pp diagonal (for LM's lambda init).
 // ------------------------------------------------------------------------------------------------
-DEVI double wave_sum(double v) {
+DEVI double wave_sum(double v) {   // (the 64-lane sums of the diagonal pass stay on the crossbar: with the DPP form k_schur_all needs two registers more and spills)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
@@ -843,13 +843,13 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
             const double* re = B.erec + VBA_EREC1 * (size_t)(d.obs0 + (a_ref ? sb : sa));
             const double* n0 = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + (a_ref ? sa : sb) - d.n_obs);
             const double* Ro = B.kfR + 12 * (size_t)(d.kf0 + (a_ref ? b : a));  // the observer's rotation
-            double N0[9], Rm[9], rec[6], bi0[6], bi1[6], rr0, rr1;
-#pragma unroll
-            for (int i = 0; i < 9; i++) { N0[i] = n0[i]; Rm[i] = Ro[i]; }
+            double N0[9], rec[6], bi0[6], bi1[6], rr0, rr1;
 #pragma unroll
             for (int i = 0; i < 4; i++) rec[i] = re[i];
             rec[4] = rec[5] = 0.0;
-            rebuild_edge(d, Rm, rec, bi0, bi1, rr0, rr1);
+            rebuild_edge(d, Ro, rec, bi0, bi1, rr0, rr1);   // (the rotation is read where it is used: nine registers fewer in flight)
+#pragma unroll
+            for (int i = 0; i < 9; i++) N0[i] = n0[i];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const double* bi = h ? bi1 : bi0;
@@ -871,10 +871,7 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
     // fixed-order butterfly inside each LP-lane group
 #pragma unroll
     for (int i = 0; i < 36; i++) {
-        double v = acc[i];
-#pragma unroll
-        for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        acc[i] = v;
+        acc[i] = (LP == 16) ? row16_sum(acc[i]) : wave64_sum(acc[i]);
     }
     double* blk = blk4 + g * 36;
     if (l16 == 0) {
