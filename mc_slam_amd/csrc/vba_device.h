@@ -7,13 +7,13 @@
 #include <stdint.h>
 
 #define VBA_NB 32          // block size of the dense reduced-system factorisation
-#define VBA_EREC 32        // doubles per edge record, XYZ variants (256 B)
+#define VBA_EREC 18        // doubles per edge record, XYZ variants (144 B): Bi (2x6), g = -Bi^T r
 #define VBA_EREC1 8        // doubles per edge record, inverse-depth variant (64 B): P_c (3), sqrt(rho' w) (1), r (2); the
                            // readers rebuild Bi = [A | B_rot] from it and the observer's rotation (rebuild_edge)
 #define VBA_N0REC 16       // doubles per landmark: N0 = R0 hat(b0) (9), so that Br = [-A | A N0] is rebuilt by the reader
 #define VBA_PREC 32        // doubles per point record  (256 B)
 #define VBA_SLOT 8         // doubles per slot record   (64 B = one line), inverse-depth landmarks
-#define VBA_SLOT3 24       // doubles per slot record, XYZ landmarks: U (6x3), beta (3), pad
+#define VBA_SLOT3 18       // doubles per slot record, XYZ landmarks (144 B): W = Bi^T A (6x3), independent of the damping
 #define VBA_IMUH 960       // doubles per IMU edge pair: 30x30 local Hessian + 30 rhs (+ pad)
 #define VBA_TRACE 64
 

@@ -42,6 +42,7 @@ struct Batch {
     const int *adj_begin, *adj;         // PCG: per free keyframe the other free keyframes it shares a landmark or an IMU edge with
     double* kf_dir;                     // XYZ landmarks: per keyframe the damping-independent part of its diagonal block and b_p (32 doubles)
     double *pcg_v, *pcg_m, *pcg_s;      // PCG: x r z p q (5 nS per window); inverted diagonal blocks (225 per keyframe); CG state (8 per window)
+    const int* slot_lm;                 // [n_obs] landmark of the record in every slot (XYZ gathers fetch the landmark's Sigma through it)
     const int* item_mid;                // per pair: its first item that involves the landmark's reference keyframe
     const unsigned long long* lmask;    // [n_pt x mwords] observing keyframes of every landmark (host-built while validating)
     const int *kf_seg, *ref_seg;        // [n_kf + 1] per window: record range of every keyframe -- slot / edge records by observing
@@ -815,16 +816,36 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
     const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
     int2 nxt = make_int2(0, 0);
-    if (ib + l16 < ie) nxt = items[ib + l16];
-    // every item: the Schur term -U_a U_b^T of one landmark seen from both keyframes
+    int nxt_lm = 0;
+    if (ib + l16 < ie) {
+        nxt = items[ib + l16];
+        if (LD == 3) nxt_lm = B.slot_lm[d.obs0 + nxt.x];
+    }
+    // every item: the Schur term of one landmark seen from both keyframes -- -U_a U_b^T (inverse depth: U = W sqrt(D^-1), 6x1)
+    // or -W_a Sigma W_b^T (XYZ: W 6x3 from the slot records, Sigma = (H_ll + lambda I)^-1 from the landmark's record)
     for (int it = ib + l16; it < ie; it += LP) {
         const int2 itm = nxt;  // indices were fetched one trip ahead: one dependent round trip per item, not two
-        if (it + LP < ie) nxt = items[it + LP];
+        const int lm = nxt_lm;
+        if (it + LP < ie) {
+            nxt = items[it + LP];
+            if (LD == 3) nxt_lm = B.slot_lm[d.obs0 + nxt.x];
+        }
         const double* qa = slots + SS * (size_t)itm.x;
         const double* qb = slots + SS * (size_t)itm.y;
         double UA[6 * LD], UB[6 * LD];
 #pragma unroll
         for (int i = 0; i < 6 * LD; i++) { UA[i] = qa[i]; UB[i] = qb[i]; }
+        if (LD == 3) {
+            const double* sg = B.prec + VBA_PREC * (size_t)(d.pt0 + lm) + 10;
+            const double s00 = sg[0], s01 = sg[1], s02 = sg[2], s11 = sg[3], s12 = sg[4], s22 = sg[5];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {   // UA <- W_a Sigma
+                const double w0 = UA[3 * i], w1 = UA[3 * i + 1], w2 = UA[3 * i + 2];
+                UA[3 * i] = w0 * s00 + w1 * s01 + w2 * s02;
+                UA[3 * i + 1] = w0 * s01 + w1 * s11 + w2 * s12;
+                UA[3 * i + 2] = w0 * s02 + w1 * s12 + w2 * s22;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -937,11 +958,26 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
         // the trials then read the slot records U(lambda) only -- 192 B instead of 384 B per record and trial
         const bool want_u = (LD == 1) || !hd_pass, want_dir = (LD == 1) || hd_pass;
         const double* qa = slots + SS * (size_t)sa;
-        double UA[6 * LD], beta[LD];
+        double UA[6 * LD], UB[6 * LD], beta[LD];   // XYZ: UA = W_a Sigma, UB = W_a, beta = t = Sigma b_l; inverse depth: UA = UB = U, beta
 #pragma unroll
-        for (int i = 0; i < 6 * LD; i++) UA[i] = want_u ? qa[i] : 0.0;
+        for (int i = 0; i < 6 * LD; i++) UB[i] = want_u ? qa[i] : 0.0;
+        if (LD == 1) {
 #pragma unroll
-        for (int l = 0; l < LD; l++) beta[l] = want_u ? qa[6 * LD + l] : 0.0;
+            for (int i = 0; i < 6 * LD; i++) UA[i] = UB[i];
+            beta[0] = qa[6];
+        } else {
+            const double* sg = B.prec + VBA_PREC * (size_t)(d.pt0 + (want_u ? B.slot_lm[d.obs0 + sa] : 0)) + 10;
+            const double s00 = sg[0], s01 = sg[1], s02 = sg[2], s11 = sg[3], s12 = sg[4], s22 = sg[5];
+#pragma unroll
+            for (int l = 0; l < LD; l++) beta[l] = want_u ? sg[6 + l] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double w0 = UB[3 * i], w1 = UB[3 * i + 1], w2 = UB[3 * i + 2];
+                UA[LD * i] = w0 * s00 + w1 * s01 + w2 * s02;
+                UA[LD * i + 1] = w0 * s01 + w1 * s11 + w2 * s12;
+                UA[LD * i + 2] = w0 * s02 + w1 * s12 + w2 * s22;
+            }
+        }
         if (!want_dir) {
         } else if (LD == 1 && sa >= d.n_obs) {
             const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + sa - d.n_obs);
@@ -961,25 +997,25 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
                 rebuild_edge(d, Ra, rec, b0, b1, r0, r1);
             } else {
 #pragma unroll
-                for (int i = 0; i < 6; i++) { b0[i] = ra[i]; b1[i] = ra[6 + i]; }
+                for (int i = 0; i < 6; i++) { b0[i] = ra[i]; b1[i] = ra[6 + i]; }   // XYZ edge record: Bi (12), g (6)
             }
             int gi = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
 #pragma unroll
                 for (int j = i; j < 6; j++) acc[gi++] += b0[i] * b0[j] + b1[i] * b1[j];
-                bp[i] += (LD == 1) ? -(b0[i] * r0 + b1[i] * r1) : ra[24 + i];
+                bp[i] += (LD == 1) ? -(b0[i] * r0 + b1[i] * r1) : ra[12 + i];
             }
         }
         int gi = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
 #pragma unroll
-            for (int l = 0; l < LD; l++) rhs[i] -= UA[LD * i + l] * beta[l];
+            for (int l = 0; l < LD; l++) rhs[i] -= UB[LD * i + l] * beta[l];   // W_a t  (inverse depth: U beta)
 #pragma unroll
             for (int j = i; j < 6; j++) {
 #pragma unroll
-                for (int l = 0; l < LD; l++) acc[gi] -= UA[LD * i + l] * UA[LD * j + l];
+                for (int l = 0; l < LD; l++) acc[gi] -= UA[LD * i + l] * UB[LD * j + l];
                 gi++;
             }
         }

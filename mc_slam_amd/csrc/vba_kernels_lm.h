@@ -2,17 +2,21 @@
 // EdgeNavStatePRPointXYZ) and the Levenberg-Marquardt outer loop (optimization_algorithm_levenberg.cpp:61-164).
 //
 // LM re-solves the SAME linearisation with a different damping per trial: k_lin_xyz stores the
-// undamped products once per outer iteration (edge record: Bi 2x6, A 2x3, g; point record: H_ll, b_l), k_dinv
-// turns them into damped slot records U = W C(lambda), C C^T = (H_ll + lambda I)^-1, so that the Schur term
-// of a keyframe pair is -U_a U_b^T exactly like the inverse-depth path.
+// undamped products once per outer iteration -- slot record W = Bi^T A (the H_pl block), edge record Bi and g, point
+// record H_ll and b_l -- and a trial only recomputes, per LANDMARK, Sigma = (H_ll + lambda I)^-1 and t = Sigma b_l
+// (k_dinv: 150 B per landmark).  The Schur term of a keyframe pair is -W_a Sigma W_b^T, formed in the gather from the
+// two slot records and the landmark's Sigma, as g2o does (block_solver.hpp:373-430).  (Round 1 rebuilt damped slot
+// records U = W chol(Sigma) for every observation and trial: 450 B of HBM traffic per observation, the largest single
+// kernel of a vision-only solve.)
 #pragma once
 #include "vba_kernels.h"
 
 #define LIN_ERR_TRIAL 2
 
-// point record (XYZ): [0..5] H_ll (xx xy xz yy yz zz)  [6..8] b_l  [9] #active edges  [10..15] C (c00 c10 c11 c20 c21 c22)
-//                     [16..18] beta = C^T b_l
-// edge record (XYZ):  [0..11] Bi (2x6 pose Jacobian)  [12..17] A (2x3 point Jacobian)  [24..29] g = -Bi^T r   (all pre-scaled)
+// point record (XYZ): [0..5] H_ll (xx xy xz yy yz zz)  [6..8] b_l  [9] #active edges  [10..15] Sigma = (H_ll + lambda I)^-1
+//                     (xx xy xz yy yz zz)  [16..18] t = Sigma b_l
+// edge record (XYZ):  [0..11] Bi (2x6 pose Jacobian)  [12..17] g = -Bi^T r   (all pre-scaled)
+// slot record (XYZ):  [0..17] W = Bi^T A (6x3, row-major)
 
 DEVI void lin_point_xyz(const Batch& B, const WinDesc& d, const WinCtrl& c, int w, int p, int mode, double& chi,
                         double& maxdiag) {
@@ -40,10 +44,12 @@ DEVI void lin_point_xyz(const Batch& B, const WinDesc& d, const WinCtrl& c, int 
             Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
         }
         B.depth_e[go] = Pc[2];
-        double* rec = B.erec + VBA_EREC * (size_t)(d.obs0 + B.slot_perm[go]);  // records live keyframe-major (slot_perm)
+        const size_t pe = B.slot_perm[go];                                   // records live keyframe-major (slot_perm)
+        double* rec = B.erec + VBA_EREC * (size_t)(d.obs0 + pe);
+        double* sl = B.slot + VBA_SLOT3 * (size_t)(d.obs0 + d.pt0 + pe);
         if (B.lvl[go]) {
             if (mode == LIN_FULL)
-                for (int i = 0; i < 30; i++) rec[i] = 0.0;
+                for (int i = 0; i < 18; i++) { rec[i] = 0.0; sl[i] = 0.0; }
             continue;
         }
         const double iz = 1.0 / Pc[2];
@@ -111,8 +117,9 @@ DEVI void lin_point_xyz(const Batch& B, const WinDesc& d, const WinCtrl& c, int 
         for (int i = 0; i < 12; i++) rec[i] = Bi[i];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            rec[12 + i] = A[i];
-            rec[24 + i] = -(Bi[i] * r0 + Bi[6 + i] * r1);
+            rec[12 + i] = -(Bi[i] * r0 + Bi[6 + i] * r1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) sl[3 * i + k] = Bi[i] * A[k] + Bi[6 + i] * A[3 + k];   // W = Bi^T A
         }
     }
     if (mode == LIN_FULL) {
@@ -217,7 +224,7 @@ __global__ void __launch_bounds__(64) k_chi2_fresh_xyz(Batch B) {
     B.chi2_f[go] = ex * (wgt * ex) + ey * (wgt * ey);
 }
 
-// K_dinv: damped landmark blocks -> slot records (one thread per landmark)
+// K_dinv: the damped landmark blocks of one trial, Sigma = (H_ll + lambda I)^-1 and t = Sigma b_l (one thread per landmark)
 __global__ void __launch_bounds__(64) k_dinv(Batch B) {
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
@@ -229,40 +236,21 @@ __global__ void __launch_bounds__(64) k_dinv(Batch B) {
     double* pr = B.prec + VBA_PREC * gp;
     const double lam = (d.algo == 1) ? c.lambda : 0.0;
     const bool on = pr[9] > 0.0;
-    double C00 = 0, C10 = 0, C11 = 0, C20 = 0, C21 = 0, C22 = 0;
+    double i00 = 0, i01 = 0, i02 = 0, i11 = 0, i12 = 0, i22 = 0;
     if (on) {
         const double h00 = pr[0] + lam, h01 = pr[1], h02 = pr[2], h11 = pr[3] + lam, h12 = pr[4], h22 = pr[5] + lam;
         // Matrix3d::inverse() (cofactors), block_solver.hpp:389
         const double c00 = h11 * h22 - h12 * h12, c01 = h02 * h12 - h01 * h22, c02 = h01 * h12 - h02 * h11;
         const double idet = 1.0 / (h00 * c00 + h01 * c01 + h02 * c02);
-        const double i00 = c00 * idet, i01 = c01 * idet, i02 = c02 * idet;
-        const double i11 = (h00 * h22 - h02 * h02) * idet, i12 = (h01 * h02 - h00 * h12) * idet;
-        const double i22 = (h00 * h11 - h01 * h01) * idet;
-        C00 = sqrt(i00); C10 = i01 / C00; C20 = i02 / C00;
-        C11 = sqrt(i11 - C10 * C10); C21 = (i12 - C20 * C10) / C11;
-        C22 = sqrt(i22 - C20 * C20 - C21 * C21);
+        i00 = c00 * idet; i01 = c01 * idet; i02 = c02 * idet;
+        i11 = (h00 * h22 - h02 * h02) * idet; i12 = (h01 * h02 - h00 * h12) * idet;
+        i22 = (h00 * h11 - h01 * h01) * idet;
     }
     const double b0 = pr[6], b1 = pr[7], b2 = pr[8];
-    const double be0 = C00 * b0 + C10 * b1 + C20 * b2, be1 = C11 * b1 + C21 * b2, be2 = C22 * b2;
-    pr[10] = C00; pr[11] = C10; pr[12] = C11; pr[13] = C20; pr[14] = C21; pr[15] = C22;
-    pr[16] = be0; pr[17] = be1; pr[18] = be2;
-    const int* ob = B.pt_obs_begin + d.pt0 + d.win;
-    double* slots = B.slot + VBA_SLOT3 * (size_t)(d.obs0 + d.pt0);
-    for (int o = ob[p]; o < ob[p + 1]; o++) {
-        const int pe = B.slot_perm[d.obs0 + o];
-        const double* rec = B.erec + VBA_EREC * (size_t)(d.obs0 + pe);
-        double* sl = slots + VBA_SLOT3 * (size_t)pe;
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const double w0 = rec[i] * rec[12] + rec[6 + i] * rec[15];  // W = Bi^T A  (6x3)
-            const double w1 = rec[i] * rec[13] + rec[6 + i] * rec[16];
-            const double w2 = rec[i] * rec[14] + rec[6 + i] * rec[17];
-            sl[3 * i] = w0 * C00 + w1 * C10 + w2 * C20;
-            sl[3 * i + 1] = w1 * C11 + w2 * C21;
-            sl[3 * i + 2] = w2 * C22;
-        }
-        sl[18] = be0; sl[19] = be1; sl[20] = be2;
-    }
+    pr[10] = i00; pr[11] = i01; pr[12] = i02; pr[13] = i11; pr[14] = i12; pr[15] = i22;
+    pr[16] = i00 * b0 + i01 * b1 + i02 * b2;
+    pr[17] = i01 * b0 + i11 * b1 + i12 * b2;
+    pr[18] = i02 * b0 + i12 * b1 + i22 * b2;
 }
 
 // SE3Quat::exp(update) * T  (se3quat.h:223-257, :103-109; VertexSE3Expmap::oplusImpl types_six_dof_expmap.h:73-76)
@@ -316,7 +304,7 @@ __global__ void __launch_bounds__(64) k_update_xyz(Batch B, int nblk_pt) {
             const size_t gp = d.pt0 + p;
             const double* pr = B.prec + VBA_PREC * gp;
             if (pr[9] > 0.0) {
-                double v0 = pr[16], v1 = pr[17], v2 = pr[18];
+                double v0 = pr[6], v1 = pr[7], v2 = pr[8];   // b_l - sum_k W_kl^T x_k   (block_solver.hpp:461-481)
                 const int* ob = B.pt_obs_begin + d.pt0 + d.win;
                 const double* slots = B.slot + VBA_SLOT3 * (size_t)(d.obs0 + d.pt0);
                 for (int o = ob[p]; o < ob[p + 1]; o++) {
@@ -329,7 +317,8 @@ __global__ void __launch_bounds__(64) k_update_xyz(Batch B, int nblk_pt) {
                         v0 -= sl[3 * i] * xi; v1 -= sl[3 * i + 1] * xi; v2 -= sl[3 * i + 2] * xi;
                     }
                 }
-                const double dl0 = pr[10] * v0, dl1 = pr[11] * v0 + pr[12] * v1, dl2 = pr[13] * v0 + pr[14] * v1 + pr[15] * v2;
+                const double dl0 = pr[10] * v0 + pr[11] * v1 + pr[12] * v2, dl1 = pr[11] * v0 + pr[13] * v1 + pr[14] * v2,
+                             dl2 = pr[12] * v0 + pr[14] * v1 + pr[15] * v2;   // Sigma v
                 B.pt[3 * gp] += dl0; B.pt[3 * gp + 1] += dl1; B.pt[3 * gp + 2] += dl2;  // VertexSBAPointXYZ::oplusImpl
                 const double lam = (d.algo == 1) ? c.lambda : 0.0;
                 sc = dl0 * (lam * dl0 + pr[6]) + dl1 * (lam * dl1 + pr[7]) + dl2 * (lam * dl2 + pr[8]);  // computeScale

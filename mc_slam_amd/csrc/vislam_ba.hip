@@ -853,7 +853,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.var_act = dp<int>(h, BUF_VARACT);
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS); B.item_mid = dp<int>(h, BUF_ITEMMID);
-    B.kf_dir = dp<double>(h, BUF_KFDIR);
+    B.kf_dir = dp<double>(h, BUF_KFDIR); B.slot_lm = dp<int>(h, BUF_SLOTOBS);
     B.adj_begin = dp<int>(h, BUF_ADJBEG); B.adj = dp<int>(h, BUF_ADJ); B.pcg_v = dp<double>(h, BUF_PCGV); B.pcg_m = dp<double>(h, BUF_PCGM); B.pcg_s = dp<double>(h, BUF_PCGS);
     B.lmask = dp<unsigned long long>(h, BUF_LMASK); B.kf_seg = dp<int>(h, BUF_KFSEG); B.ref_seg = dp<int>(h, BUF_REFSEG);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
