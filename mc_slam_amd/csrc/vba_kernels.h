@@ -32,6 +32,7 @@ struct Batch {
     const int *imu_i, *imu_j;
     const double *imu_meas, *imu_info;
     double *imuH, *imu_chi;  // imu_chi: [4] per edge: robust prv, robust bias, raw prv, raw bias
+    double* imu_jrec;        // [IMU_JREC] per edge: Jacobian, weighted information, errors of the last linearisation (lin_imu_res -> lin_imu_hess)
     // reduced system
     double *S, *vec, *bpose;
     double *Lf, *yv;  // factor tiles and forward-substituted rhs (written out of place: S tiles are read by
@@ -56,6 +57,9 @@ struct Batch {
     double* part;
     const volatile int* stop_word;
     int* alive_cnt;  // pinned host words: [stage * 32 + it] = 1 if a window is still iterating after control call `it`
+    int* alive_dev;  // device mirror of the group's words ([0,64): Gauss-Newton slots, [64,1024): LM slot groups), zeroed at run start:
+                     // only the FIRST window that flips a mirror word writes the host word (thousands of windows posting the same
+                     // 4 bytes over PCIe cost 0.4 ms per control launch)
     unsigned char* out_outlier;
     double* out_chi2;
     double* dbg;  // 4 KiB scratch for diagnostic builds (in-kernel stamps); never read by the product path
@@ -198,20 +202,22 @@ __global__ void __launch_bounds__(64) k_stage_mark(Batch B) {
 // (block_solver.hpp:502-560); Jacobians never reach HBM unreduced: only their products do.
 // ------------------------------------------------------------------------------------------------
 // EdgeNavStatePRV + EdgeNavStateBias of one keyframe pair (the fused 15-D IMU factor): error, chi2, and in
-// LIN_FULL mode the 30x30 local Hessian J^T (rho' Omega) J and rhs in local order
-// [PR_i V_i B_i | PR_j V_j B_j].  One 64-thread workgroup; lane 0 evaluates the Lie-group part.
-DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm) {
+// LIN_FULL mode the 30x30 local Hessian J^T (rho' Omega) J and rhs in local order [PR_i V_i B_i | PR_j V_j B_j].
+// Two steps.  lin_imu_res: the Lie-group part -- residuals, Huber weights, the 9x30 Jacobian -- is scalar work, ONE LANE per
+// keyframe pair (64 pairs per wave side by side; round 1 ran it on lane 0 of a wave per pair, 63 lanes idle for ~1500
+// instructions); its products go to a 398-double record per pair (imu_jrec: J 270, weighted Omega 81, errors + weights +
+// column masks 47).  lin_imu_hess: one wave per pair turns the record into H = J^T (Omega J) and the rhs.
+#define IMU_JREC 400
+DEVI void lin_imu_res(const Batch& B, const WinDesc& d, int k, int mode) {
     const size_t gk = d.imu0 + k;
     const int i = B.imu_i[gk], j = B.imu_j[gk];
-    double* J = sm;            // 9 x 30
-    double* Om = sm + 270;     // 9 x 9 weighted information
-    double* T = sm + 351;      // 9 x 30 = Om J
-    double* er = sm + 621;     // 9 err + 6 bias err + 2 weights(bias wg, wa scaled) + 30 column masks
-    const int t = threadIdx.x;
     const int act = imu_act(B, d, i, j);
     if (!act) return;  // every vertex fixed: not in the active set
     const double* meas = B.imu_meas + 61 * gk;
-    if (t == 0) {
+    double* J = B.imu_jrec + IMU_JREC * gk;   // 9 x 30
+    double* Om = J + 270;                     // 9 x 9 weighted information
+    double* er = J + 351;                     // 9 err + 6 bias err + 2 weights(bias wg, wa scaled) + 30 column masks
+    {
         const double* Ti = B.pose + 7 * (size_t)(d.kf0 + i);
         const double* Tj = B.pose + 7 * (size_t)(d.kf0 + j);
         const double* Vi = B.vel + 3 * (size_t)(d.kf0 + i);
@@ -323,7 +329,21 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
                 }
         }
     }
-    if (mode != LIN_FULL) return;
+}
+
+// H = J^T (Omega J) + the bias edge's -I / +I terms, rhs = -J^T Omega e, of one keyframe pair (one wave; sm: 672 doubles)
+DEVI void lin_imu_hess(const Batch& B, const WinDesc& d, int k, double* sm) {
+    const size_t gk = d.imu0 + k;
+    const int i = B.imu_i[gk], j = B.imu_j[gk];
+    if (!imu_act(B, d, i, j)) return;
+    double* J = sm;            // 9 x 30
+    double* Om = sm + 270;     // 9 x 9 weighted information
+    double* T = sm + 351;      // 9 x 30 = Om J
+    double* er = sm + 621;     // 9 err + 6 bias err + 2 weights + 30 column masks
+    const int t = threadIdx.x;
+    const double* rec = B.imu_jrec + IMU_JREC * gk;
+    for (int q = t; q < 351; q += 64) sm[q] = rec[q];
+    for (int q = t; q < 47; q += 64) er[q] = rec[351 + q];
     __syncthreads();
     for (int q = t; q < 270; q += 64) {  // T = Om J
         const int a = q / 30, col = q % 30;
@@ -372,17 +392,32 @@ DEVI void lin_imu(const Batch& B, const WinDesc& d, int k, int mode, double* sm)
 #define LIN2_PS 19   // LDS row stride of one landmark: dd, y(3), Xw(3), N0(9), ref_free, sD, beta
 #define LIN2_LDS ((256 * LIN2_ES + 64 * LIN2_PS + 4) * 8)   // 40 480 B: four workgroups per CU
 
-// The IMU factors of the inverse-depth windows: one wave per keyframe pair, in its own launch right behind k_lin2 (same stream)
-// -- inlined into k_lin2 its ~60 live doubles of Lie algebra set the register budget of the 130x more numerous edge workgroups.
-__global__ void __launch_bounds__(64) k_lin_imu(Batch B, int mode) {
+// The IMU factors: a launch of their own behind the vision linearisation (same stream) -- inlined into k_lin2 their ~60 live
+// doubles of Lie algebra set the register budget of the 130x more numerous edge workgroups.  k_lin_imu_res: a lane per keyframe
+// pair; k_lin_imu_hess (LIN_FULL only): a wave per pair.  `gate_lm`: the XYZ / Levenberg-Marquardt gating of k_lin_xyz.
+DEVI bool lin_imu_gate(const WinDesc& d, const WinCtrl& c, int mode) {
+    if (!c.active) return false;
+    if (d.variant == 2) return true;
+    if (mode == 2 /* LIN_ERR_TRIAL */ && !win_on(d, c)) return false;
+    if (mode == LIN_FULL && d.algo == 1 && c.lm_need_trial) return false;
+    return true;
+}
+__global__ void __launch_bounds__(64) k_lin_imu_res(Batch B, int mode) {
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    if (!lin_imu_gate(d, B.ctrl[w], mode)) return;
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= d.n_imu) return;
+    lin_imu_res(B, d, k, (mode == LIN_FULL) ? LIN_FULL : LIN_ERR);
+}
+__global__ void __launch_bounds__(64) k_lin_imu_hess(Batch B) {
     __shared__ double sm[672];
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
-    const WinCtrl& c = B.ctrl[w];
-    if (!c.active) return;
+    if (!lin_imu_gate(d, B.ctrl[w], LIN_FULL)) return;
     const int k = blockIdx.x;
     if (k >= d.n_imu) return;
-    lin_imu(B, d, k, mode, sm);
+    lin_imu_hess(B, d, k, sm);
 }
 
 __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode) {
@@ -677,8 +712,8 @@ __global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval) {
     c.active = active;
     c.chol_fail = 0;
     c.it = it + 1;
-    if (active && B.alive_cnt && it < 32)  // lets the host skip dead iterations; a posted store, not a PCIe atomic
-        __hip_atomic_store(B.alive_cnt + st * 32 + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (active && B.alive_cnt && it < 32 && atomicExch(B.alive_dev + st * 32 + it, 1) == 0)  // lets the host skip dead iterations
+        __hip_atomic_store(B.alive_cnt + st * 32 + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // a posted store, not a PCIe atomic
 }
 
 // ------------------------------------------------------------------------------------------------

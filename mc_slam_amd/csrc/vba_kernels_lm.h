@@ -148,7 +148,7 @@ DEVI double block_max(double v, double* sm) {
 }
 
 __global__ void __launch_bounds__(64) k_lin_xyz(Batch B, int nblk_pt, int mode) {
-    __shared__ double sm[672];
+    __shared__ double sm[64];
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
@@ -156,21 +156,15 @@ __global__ void __launch_bounds__(64) k_lin_xyz(Batch B, int nblk_pt, int mode) 
     if (mode == LIN_ERR_TRIAL && !win_on(d, c)) return;
     if (mode == LIN_FULL && d.algo == 1 && c.lm_need_trial) return;   // "outer" slot of the LM schedule: not for a window that still owes a trial
     const int m = (mode == LIN_FULL) ? LIN_FULL : LIN_ERR;
-    if ((int)blockIdx.x < nblk_pt) {
-        const int p = blockIdx.x * 64 + threadIdx.x;
-        if ((int)blockIdx.x * 64 >= d.n_pt) return;
-        double chi = 0.0, mx = 0.0;
-        if (p < d.n_pt) lin_point_xyz(B, d, c, w, p, m, chi, mx);
-        const double tot = block_sum<64>(chi, sm);
-        const double tmx = block_max<64>(mx, sm);
-        if (threadIdx.x == 0) {
-            B.part[d.part0 + blockIdx.x] = tot;
-            if (m == LIN_FULL) B.part[d.part0 + d.n_part_lin + blockIdx.x] = tmx;
-        }
-    } else {
-        const int k = blockIdx.x - nblk_pt;
-        if (k >= d.n_imu) return;
-        lin_imu(B, d, k, m, sm);
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if ((int)blockIdx.x * 64 >= d.n_pt) return;
+    double chi = 0.0, mx = 0.0;
+    if (p < d.n_pt) lin_point_xyz(B, d, c, w, p, m, chi, mx);
+    const double tot = block_sum<64>(chi, sm);
+    const double tmx = block_max<64>(mx, sm);
+    if (threadIdx.x == 0) {
+        B.part[d.part0 + blockIdx.x] = tot;
+        if (m == LIN_FULL) B.part[d.part0 + d.n_part_lin + blockIdx.x] = tmx;
     }
 }
 
@@ -434,7 +428,7 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_outer(Batch B) {
 // one LM trial has been solved, applied and re-evaluated: rho test, lambda update, accept / reject, and when
 // the do-while ends the per-iteration stop rules (levenberg.cpp:120-161)
 // alive: pinned host word of this slot group; set when the window goes on (another trial or another outer iteration)
-__global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* alive) {
+__global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* alive, int* alive_mirror) {
     __shared__ double sm[64];
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
@@ -474,7 +468,7 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* alive) {
     const int stop = (B.stop_word && *B.stop_word) ? 1 : 0;
     if (rho < 0 && qmax < 10 && !stop) {
         c.lm_need_trial = 1;
-        __hip_atomic_store(alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // a posted store, not a PCIe atomic
+        if (atomicExch(alive_mirror, 1) == 0) __hip_atomic_store(alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // a posted store, not a PCIe atomic
         return;
     }
     c.lm_need_trial = 0;
@@ -489,5 +483,5 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* alive) {
         if (c.nbad >= 3) term = true;
     }
     if (term || c.it >= d.its[st]) c.active = 0;
-    else __hip_atomic_store(alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // goes on to another outer iteration
+    else if (atomicExch(alive_mirror, 1) == 0) __hip_atomic_store(alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // goes on to another outer iteration
 }

@@ -146,7 +146,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_N
 };
 
 struct ProfEvt {
@@ -800,7 +800,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_SLOT, ((size_t)obs0 + pt0) * (probs[0]->variant == VBA_VARIANT_PRV_IDP ? VBA_SLOT : VBA_SLOT3) * 8)) return -1;
     if (dalloc(h, BUF_CHI2F, (size_t)obs0 * 8)) return -1;
     if (h2d(h, BUF_IMUI, imui) || h2d(h, BUF_IMUJ, imuj) || h2d(h, BUF_IMUMEAS, meas) || h2d(h, BUF_IMUINFO, info)) return -1;
-    if (dalloc(h, BUF_IMUH, (size_t)imu0 * VBA_IMUH * 8) || dalloc(h, BUF_IMUCHI, (size_t)imu0 * 4 * 8)) return -1;
+    if (dalloc(h, BUF_IMUH, (size_t)imu0 * VBA_IMUH * 8) || dalloc(h, BUF_IMUCHI, (size_t)imu0 * 4 * 8) || dalloc(h, BUF_IMUJREC, (size_t)imu0 * IMU_JREC * 8)) return -1;
     if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
     if (dalloc(h, BUF_LF, S_tot * 8) || dalloc(h, BUF_YV, (size_t)vec0 * 8)) return -1;
     if (h2d_vec(h, BUF_TLSTEP, tlstep, G.s_int[0]) || h2d_vec(h, BUF_TLPAIR, tlpair, G.s_int[1]) || h2d_vec(h, BUF_TLPANB, tlpanb, G.s_int[2]) ||
@@ -842,7 +842,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC); B.slot = dp<double>(h, BUF_SLOT); B.n0rec = dp<double>(h, BUF_N0REC); B.kf_fix = dp<unsigned char>(h, BUF_KFFIX);
     B.imu_i = dp<int>(h, BUF_IMUI); B.imu_j = dp<int>(h, BUF_IMUJ);
     B.imu_meas = dp<double>(h, BUF_IMUMEAS); B.imu_info = dp<double>(h, BUF_IMUINFO);
-    B.imuH = dp<double>(h, BUF_IMUH); B.imu_chi = dp<double>(h, BUF_IMUCHI);
+    B.imuH = dp<double>(h, BUF_IMUH); B.imu_chi = dp<double>(h, BUF_IMUCHI); B.imu_jrec = dp<double>(h, BUF_IMUJREC);
     B.S = dp<double>(h, BUF_S); B.vec = dp<double>(h, BUF_VEC); B.bpose = dp<double>(h, BUF_BPOSE);
     B.Lf = dp<double>(h, BUF_LF); B.yv = dp<double>(h, BUF_YV);
     B.tl_step_begin = dp<int>(h, BUF_TLSTEP); B.tl_pairs = dp<int>(h, BUF_TLPAIR);
@@ -862,6 +862,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.part = dp<double>(h, BUF_PART);
     B.stop_word = h->stop_dev;
     B.alive_cnt = h->stop_dev + 64;
+    if (dalloc(h, BUF_ALIVE, 14 * 1024 * sizeof(int))) return -1;
+    B.alive_dev = dp<int>(h, BUF_ALIVE);
     B.out_outlier = dp<unsigned char>(h, BUF_OUTL); B.out_chi2 = dp<double>(h, BUF_OUTCHI);
     if (dalloc(h, BUF_DBG, 4096)) return -1;
     B.dbg = dp<double>(h, BUF_DBG);
@@ -983,10 +985,12 @@ void enqueue_lin(Handle* h, int mode) {
     if (h->variant == VBA_VARIANT_PRV_IDP) {
         const size_t shm = LIN2_LDS;
         hipLaunchKernelGGL(k_lin2, dim3(h->max_lin_blk, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
-        if (h->max_imu > 0) hipLaunchKernelGGL(k_lin_imu, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, mode);
+    } else
+        hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
+    if (h->max_imu > 0) {   // the IMU factors: a lane per keyframe pair for the Lie-group part, then a wave per pair for J^T Omega J
+        hipLaunchKernelGGL(k_lin_imu_res, dim3((h->max_imu + 63) / 64, h->n_win), dim3(64), 0, h->stream, h->B, mode);
+        if (mode == LIN_FULL) hipLaunchKernelGGL(k_lin_imu_hess, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B);
     }
-    else
-        hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk + h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
 }
 
 // One group of windows of a batch with its own stream (the whole batch is the only group unless VBA_STREAMS > 1)
@@ -1035,7 +1039,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, g.stream, g.B, h->max_free, 1);
         hipLaunchKernelGGL(k_ctrl_lm_outer, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
     };
-    auto trial = [&](Group& g, int* alive_dev) {
+    auto trial = [&](Group& g, int* alive_dev, int* alive_mirror) {
         {
             ProfScope ps(h, VBA_PROF_MISC);
             hipLaunchKernelGGL(k_backup, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
@@ -1044,7 +1048,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         enqueue_lin(h, LIN_ERR_TRIAL);
         {
             ProfScope ps(h, VBA_PROF_CONTROL);
-            hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(g.n_win), dim3(64), 0, g.stream, g.B, alive_dev);
+            hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(g.n_win), dim3(64), 0, g.stream, g.B, alive_dev, alive_mirror);
             hipLaunchKernelGGL(k_restore, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
         }
     };
@@ -1066,7 +1070,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         for (auto& g : groups) { use(g); stage_begin(g, stage); }
         if (h->max_its[stage] > 0) {
             // upper bound of the slot groups a stage can need: every outer iteration may take up to 10 trials
-            const int max_groups = 10 * h->max_its[stage] + 2;
+            const int max_groups = std::min(478, 10 * h->max_its[stage] + 2);
             std::vector<std::vector<hipEvent_t>> ev(groups.size());
             for (auto& g : groups) g.dead = false;
             for (int j = 0; j < max_groups; j++) {
@@ -1084,7 +1088,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
                     g.alive[j % RING] = 0;   // the word's previous user (group j - RING) was consumed long ago
                     int* alive_dev = h->stop_dev + (g.alive - h->stop_host) + (j % RING);
                     outer(g);
-                    trial(g, alive_dev);
+                    trial(g, alive_dev, g.B.alive_dev + 64 + stage * 480 + j);   // a mirror word of its own per slot group (never reused inside a run)
                     ev[gi].push_back(get_evt(h));
                     if (hipEventRecord(ev[gi][j], g.stream) != hipSuccess) { rc = -1; break; }
                 }
@@ -1232,11 +1236,13 @@ int do_run(Handle* h, const volatile int* stop_flag) {
         groups[g].B.ctrl = B.ctrl + w0;
         groups[g].B.n_win = w1 - w0;
         groups[g].B.alive_cnt = h->stop_dev + 64 + 64 * g;
+        groups[g].B.alive_dev = dp<int>(h, BUF_ALIVE) + 1024 * g;
         groups[g].n_win = w1 - w0;
         groups[g].stream = (g == 0) ? h->stream : h->xstreams[g - 1];
         groups[g].alive = h->stop_host + 64 + 64 * g;
         groups[g].dead = false;
     }
+    HIPCHK(h, hipMemsetAsync(h->buf[BUF_ALIVE].p, 0, 14 * 1024 * sizeof(int), h->stream));   // the mirror words of this run
     // the other streams start after everything already queued on the main stream (upload, previous run)
     if (ngroups > 1) {
         hipEvent_t e0 = get_evt(h);
@@ -1608,7 +1614,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
