@@ -1,0 +1,262 @@
+// vba_host_structure.h -- host half of the structure build (plain C++17, no HIP): included by vislam_ba.hip and by the
+// sanitizer harness tests/host_structure_check.cpp (g++ -fsanitize=address,undefined, tests/test_host_structure.py).
+#pragma once
+#include "../../include/vislam_ba.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#ifndef VBA_NB
+#define VBA_NB 32
+#endif
+
+namespace vba_host {
+
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- structure build (g2o BlockSolver::buildStructure analogue, block_solver.hpp:143-295) -------------
+// Host half: ONE walk over a window's index arrays validates them and leaves, per landmark, the bitmask of its observing
+// keyframes; from the masks come the keyframe-pair occupancy and with it the symbolic tile factorisation, the IMU lists and
+// the write masks.  Everything that needs a sort or a per-pair item list is built on the device from the raw arrays
+// (vba_structure.h).
+struct Structure {
+    std::vector<int> pair_a, pair_b, pimu_begin, pimu;
+    std::vector<int> step_begin, tpairs, pan_begin, pan;  // tile lists of the factorisation
+    std::vector<int> step_npairs;
+    std::vector<int> off_pair, pair_mask;
+    std::vector<unsigned long long> lmask;  // [n_pt][mwords] observing keyframes of every landmark
+    std::vector<int> adj_begin, adj;        // PCG: per free keyframe the other free keyframes its block row of S is non-zero for
+    std::vector<int> linblk;                // k_lin2 work split (inverse-depth windows): (p0, p1, e0, e1) per workgroup
+    int mwords = 1;
+    long long item_cap = 0;            // upper bound of the off-diagonal items (exact when every keyframe is free)
+    int order = 0;                     // elimination order of the reduced system (see below)
+    std::vector<int> kl_begin, klist;  // left-looking factorisation: per column entry the steps k < J that update it
+};
+
+inline int vpos_host(int order, int pdim, int nf, int a, int r) {
+    if (pdim != 15) return 6 * a + r;
+    return order ? 15 * a + r : (r < 6 ? 9 * nf + 6 * a + r : 9 * a + (r - 6));
+}
+
+inline int build_structure(const vba_problem* P, Structure& st, std::string& err) {
+    auto fail = [&err](int, const char* m) { err = m; return -1; };
+    const int h = 0;
+    static const bool timing = getenv("VBA_TIMING") != nullptr;
+    const double t_b0 = timing ? now_ms() : 0.0;
+    const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2, nkf = P->n_kf;
+    auto pidx = [nf](int a, int b) { return a * nf - a * (a - 1) / 2 + (b - a); };
+    st.pair_a.resize(npairs);
+    st.pair_b.resize(npairs);
+    st.off_pair.clear();
+    st.off_pair.reserve(npairs);
+    for (int a = 0; a < nf; a++)
+        for (int b = a; b < nf; b++) {
+            st.pair_a[pidx(a, b)] = a;
+            st.pair_b[pidx(a, b)] = b;
+            if (a != b) st.off_pair.push_back(pidx(a, b));
+        }
+    const bool idp = P->variant == VBA_VARIANT_PRV_IDP;
+    const int mw = (nkf + 63) / 64;
+    st.mwords = mw;
+    st.lmask.assign((size_t)P->n_pt * mw, 0ull);
+    // occ[a] = the keyframes that share a landmark with free keyframe a (observer or reference), as a bitmask
+    std::vector<unsigned long long> occ((size_t)nf * mw, 0ull), tmp(mw);
+    st.item_cap = 0;
+    if (P->n_pt > 0 && P->pt_obs_begin[0] != 0) return fail(h, "pt_obs_begin is not a valid CSR");
+    for (int p = 0; p < P->n_pt; p++) {
+        const int o0 = P->pt_obs_begin[p], o1 = P->pt_obs_begin[p + 1];
+        if (o0 > o1 || o0 < 0 || o1 > P->n_obs) return fail(h, "pt_obs_begin is not a valid CSR");
+        unsigned long long* M = &st.lmask[(size_t)p * mw];
+        int rf = -1;
+        if (idp) {
+            rf = P->pt_ref_kf[p];
+            if (rf < 0 || rf >= nkf) return fail(h, "pt_ref_kf out of range");
+        }
+        for (int o = o0; o < o1; o++) {
+            const int kf = P->obs_kf[o];
+            if (kf < 0 || kf >= nkf) return fail(h, "obs_kf out of range");
+            if (kf == rf) return fail(h, "observation from the reference keyframe is not an edge");
+            const unsigned long long bit = 1ull << (kf & 63);
+            if (M[kf >> 6] & bit) return fail(h, "a landmark is observed twice from one keyframe");
+            M[kf >> 6] |= bit;
+        }
+        const long long m = o1 - o0;
+        st.item_cap += idp ? m * (m + 1) / 2 : m * (m - 1) / 2;
+        // every free keyframe of the track (reference included) shares this landmark with every other one
+        for (int wd = 0; wd < mw; wd++) tmp[wd] = M[wd];
+        if (rf >= 0) tmp[rf >> 6] |= 1ull << (rf & 63);
+        for (int wd = 0; wd < mw; wd++) {
+            unsigned long long bits = tmp[wd];
+            while (bits) {
+                const int a = 64 * wd + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                if (a >= nf) break;
+                for (int w2 = 0; w2 < mw; w2++) occ[(size_t)a * mw + w2] |= tmp[w2];
+            }
+        }
+    }
+    if (P->pt_obs_begin[P->n_pt] != P->n_obs) return fail(h, "pt_obs_begin does not cover the observations");
+    auto pair_vis = [&](int a, int b) { return (occ[(size_t)a * mw + (b >> 6)] >> (b & 63)) & 1ull; };
+    if (idp) {
+        // k_lin2 work split: runs of consecutive landmarks with <= 256 edges and <= 64 landmarks per workgroup
+        // (one 16-B record per workgroup: first / end landmark, first / end edge)
+        st.linblk.clear();
+        int p = 0;
+        while (p < P->n_pt) {
+            const int p_first = p;
+            int ne = 0, np2 = 0;
+            while (p < P->n_pt && np2 < 64) {
+                const int k = P->pt_obs_begin[p + 1] - P->pt_obs_begin[p];
+                if (k > 256) return fail(h, "a landmark with more than 256 observations is not supported");
+                if (ne + k > 256) break;
+                ne += k; np2++; p++;
+            }
+            st.linblk.push_back(p_first); st.linblk.push_back(p);
+            st.linblk.push_back(P->pt_obs_begin[p_first]); st.linblk.push_back(P->pt_obs_begin[p]);
+        }
+    }
+    const double t_b1 = timing ? now_ms() : 0.0;
+    // IMU edges per block pair: (edge, role) with role bit0: a is keyframe j of the edge, bit1: b is keyframe j
+    const int nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
+    st.pimu_begin.assign(npairs + 1, 0);
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<int> fill;
+        if (pass) {
+            for (int i = 0; i < npairs; i++) st.pimu_begin[i + 1] += st.pimu_begin[i];
+            st.pimu.assign(2 * (size_t)st.pimu_begin[npairs], 0);
+            fill.assign(st.pimu_begin.begin(), st.pimu_begin.end() - 1);
+        }
+        auto put = [&](int pi, int k, int role) {
+            if (!pass) { st.pimu_begin[pi + 1]++; return; }
+            st.pimu[2 * (size_t)fill[pi]] = k;
+            st.pimu[2 * (size_t)fill[pi] + 1] = role;
+            fill[pi]++;
+        };
+        for (int k = 0; k < nimu; k++) {
+            const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
+            if (i < 0 || j < 0 || i >= nkf || j >= nkf || i == j) return fail(h, "imu keyframe index out of range");
+            if (i < nf) put(pidx(i, i), k, 0);
+            if (j < nf) put(pidx(j, j), k, 3);
+            if (i < nf && j < nf) {
+                if (i < j) put(pidx(i, j), k, 2);
+                else put(pidx(j, i), k, 1);
+            }
+        }
+    }
+    if (P->solver == VBA_SOLVER_PCG) {   // block rows of S: a shares a landmark or an IMU edge with b
+        st.adj_begin.assign(nf + 1, 0);
+        st.adj.clear();
+        for (int a = 0; a < nf; a++) {
+            for (int b = 0; b < nf; b++) {
+                if (b == a) continue;
+                const int pi = (a < b) ? pidx(a, b) : pidx(b, a);
+                if (pair_vis(a, b) || st.pimu_begin[pi + 1] > st.pimu_begin[pi]) st.adj.push_back(b);
+            }
+            st.adj_begin[a + 1] = (int)st.adj.size();
+        }
+    }
+    // symbolic factorisation on 32x32 tiles (the tile-level analogue of SimplicialLDLT::analyzePattern,
+    // linear_solver_eigen.h:147-152): which tiles of L can be nonzero.  Two elimination orders are tried and the cheaper
+    // one (tile products of the factorisation) kept -- g2o lets AMD pick an order; the reduced system here is either
+    //   order 0: all V/Bias blocks first, PR blocks last -- the IMU chain stays a narrow band, the PR block fills in
+    //            completely: best when most keyframes share landmarks with most others (the usual local window)
+    //   order 1: keyframe by keyframe [PR_a V_a Bias_a] -- a block band whose width is the co-visibility span: best
+    //            for long, thin windows and for maps
+    const int pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
+    const int np = pdim * nf, nS = ((np + VBA_NB - 1) / VBA_NB) * VBA_NB, nb = nS / VBA_NB;
+    auto symbolic = [&](int order, bool lists) -> long long {
+    st.tpairs.clear(); st.pan.clear();
+    std::vector<unsigned char> T((size_t)nb * nb, 0);
+    for (int i = 0; i < nb; i++) T[(size_t)i * nb + i] = 1;
+    for (int pi = 0; pi < npairs; pi++) {
+        const int a = st.pair_a[pi], b = st.pair_b[pi];
+        const bool vis = pair_vis(a, b);
+        const bool imu = st.pimu_begin[pi + 1] > st.pimu_begin[pi];
+        if (!vis && !imu && a != b) continue;
+        // a keyframe's PR dofs (0..5) and V/Bias dofs (6..14) are two contiguous runs: each touches at most two tiles
+        const int nsub = ((imu || a == b) && pdim == 15) ? 2 : 1;
+        for (int sr = 0; sr < nsub; sr++)
+            for (int sc = 0; sc < nsub; sc++) {
+                const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
+                const int ti0 = vpos_host(order, pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(order, pdim, nf, a, r1) / VBA_NB;
+                const int tj0 = vpos_host(order, pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(order, pdim, nf, b, c1) / VBA_NB;
+                for (int ti = ti0; ti <= ti1; ti++)
+                    for (int tj = tj0; tj <= tj1; tj++) T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)] = 1;
+            }
+    }
+    st.step_begin.assign(nb + 1, 0);
+    st.pan_begin.assign(nb + 1, 0);
+    st.step_npairs.assign(nb, 0);
+    std::vector<int> pk;
+    long long cost = 0;
+    for (int k = 0; k < nb; k++) {
+        pk.clear();
+        for (int I = k + 1; I < nb; I++)
+            if (T[(size_t)I * nb + k]) pk.push_back(I);
+        for (int I : pk) st.tpairs.push_back((I << 16) | I);  // diagonal pairs first: pair 0 owns y_k
+        for (size_t i = 0; i < pk.size(); i++)
+            for (size_t j = 0; j < i; j++) {
+                st.tpairs.push_back((pk[i] << 16) | pk[j]);
+                T[(size_t)pk[i] * nb + pk[j]] = 1;  // fill
+            }
+        for (int I : pk) st.pan.push_back(I);
+        st.step_begin[k + 1] = (int)st.tpairs.size();
+        st.pan_begin[k + 1] = (int)st.pan.size();
+        st.step_npairs[k] = st.step_begin[k + 1] - st.step_begin[k];
+    }
+    cost = (long long)st.tpairs.size();   // one tile product per update pair (= the k-list entries of the left-looking form)
+    if (!lists) return cost;
+    // left-looking lists: column entries in the order (J,J), then (I,J) for I in the panel of J; K(I,J) = {k < J : L_Ik, L_Jk != 0}
+    st.kl_begin.clear();
+    st.klist.clear();
+    for (int J = 0; J < nb; J++) {
+        for (int e = -1; e < st.pan_begin[J + 1] - st.pan_begin[J]; e++) {
+            const int I = (e < 0) ? J : st.pan[st.pan_begin[J] + e];
+            st.kl_begin.push_back((int)st.klist.size());
+            for (int k = 0; k < J; k++)
+                if (T[(size_t)I * nb + k] && T[(size_t)J * nb + k]) st.klist.push_back(k);
+        }
+    }
+    st.kl_begin.push_back((int)st.klist.size());
+    // which sub-blocks of a keyframe pair's block can land in a tile the factorisation reads (T now holds L's pattern)
+    st.pair_mask.assign(npairs, 0);
+    for (int pi = 0; pi < npairs; pi++) {
+        const int a = st.pair_a[pi], b = st.pair_b[pi];
+        int mask = 0;
+        const int nsub = (pdim == 15) ? 2 : 1;
+        for (int sr = 0; sr < nsub; sr++)
+            for (int sc = 0; sc < nsub; sc++) {
+                const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
+                const int ti0 = vpos_host(order, pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(order, pdim, nf, a, r1) / VBA_NB;
+                const int tj0 = vpos_host(order, pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(order, pdim, nf, b, c1) / VBA_NB;
+                bool any = false;
+                for (int ti = ti0; ti <= ti1; ti++)
+                    for (int tj = tj0; tj <= tj1; tj++) any = any || T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)];
+                if (any) mask |= 1 << ((sr ? 2 : 0) + (sc ? 1 : 0));
+            }
+        st.pair_mask[pi] = mask;
+    }
+    return cost;
+    };
+    static const int env_order = getenv("VBA_ORDER") ? atoi(getenv("VBA_ORDER")) : -1;
+    st.order = 0;
+    if (pdim == 15) {
+        if (env_order >= 0) st.order = env_order ? 1 : 0;
+        else {
+            const long long c0 = symbolic(0, false), c1 = symbolic(1, false);
+            st.order = (10 * c1 < 7 * c0) ? 1 : 0;  // only a clear win: a batch that mixes both orders pays for both patterns
+            if (timing) fprintf(stderr, "[vba] tile products of the factorisation: V/Bias-first %lld, keyframe order %lld (nb %d)\n", c0, c1, nb);
+        }
+    }
+    symbolic(st.order, true);
+    st.off_pair.resize(npairs, 0);  // padded to the pair stride
+    if (timing) fprintf(stderr, "[vba] structure (host): validation + masks %.3f ms, IMU lists + symbolic factorisation %.3f ms\n", t_b1 - t_b0, now_ms() - t_b1);
+    return 0;
+}
+
+
+}  // namespace vba_host

@@ -6,6 +6,8 @@
 // on the device (k_ctrl_*), the host only enqueues.  No CPU fallback exists: without a HIP device every entry
 // point fails with an error.
 #include "../../include/vislam_ba.h"
+#include "vba_host_structure.h"
+#include "vba_problem_io.h"
 #include "vba_kernels_lm.h"
 #include "vba_preint.h"
 #include "vba_pose.h"
@@ -45,6 +47,9 @@ template <typename T> using hvec = std::vector<T, NoInitAlloc<T>>;
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    void* view = nullptr;     // small batches: the array lives inside the upload arena (one H2D for all of them); not owned
+    size_t view_bytes = 0;
+    void* ptr() const { return view ? view : p; }
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
@@ -167,6 +172,13 @@ struct Handle {
     DevBuf preint;  // arena of vba_preintegrate
     DevBuf pose_arena;  // arena of vba_pose_optimize
     PinnedBuf pose_host_in, pose_host_out;  // its pinned staging: one H2D and one D2H per call
+    // small batches (<= 8 windows): every host-built array of an upload goes through ONE pinned arena and ONE H2D copy into one
+    // device arena (a single window is ~25 arrays of a few KB to a few 100 KB: 25 copies cost 0.4 ms of queue latency)
+    struct Pending { int id; const void* src; size_t bytes; };
+    std::vector<Pending> pending;
+    bool arena_on = false;
+    DevBuf up_arena;
+    PinnedBuf up_arena_host;
     Staging stg;   // pinned staging: upload arrays; download: one D2H per array, windows scattered to the callers' arrays by host threads
     std::vector<Handle*> lanes;   // sub-handles of vba_batch_solve (chunks of a large batch in flight concurrently)
     bool is_lane = false;
@@ -217,7 +229,7 @@ int fail(Handle* h, const std::string& m) {
 
 template <typename T>
 T* dp(Handle* h, int id) {
-    return reinterpret_cast<T*>(h->buf[id].p);
+    return reinterpret_cast<T*>(h->buf[id].ptr());
 }
 
 hipEvent_t get_evt(Handle* h) {
@@ -249,248 +261,23 @@ struct ProfScope {
     }
 };
 
-// ---- structure build (g2o BlockSolver::buildStructure analogue, block_solver.hpp:143-295) -------------
-// Host half: ONE walk over a window's index arrays validates them and leaves, per landmark, the bitmask of its observing
-// keyframes; from the masks come the keyframe-pair occupancy and with it the symbolic tile factorisation, the IMU lists and
-// the write masks.  Everything that needs a sort or a per-pair item list is built on the device from the raw arrays
-// (vba_structure.h).
-struct Structure {
-    std::vector<int> pair_a, pair_b, pimu_begin, pimu;
-    std::vector<int> step_begin, tpairs, pan_begin, pan;  // tile lists of the factorisation
-    std::vector<int> step_npairs;
-    std::vector<int> off_pair, pair_mask;
-    std::vector<unsigned long long> lmask;  // [n_pt][mwords] observing keyframes of every landmark
-    std::vector<int> adj_begin, adj;        // PCG: per free keyframe the other free keyframes its block row of S is non-zero for
-    std::vector<int> linblk;                // k_lin2 work split (inverse-depth windows): (p0, p1, e0, e1) per workgroup
-    int mwords = 1;
-    long long item_cap = 0;            // upper bound of the off-diagonal items (exact when every keyframe is free)
-    int order = 0;                     // elimination order of the reduced system (see below)
-    std::vector<int> kl_begin, klist;  // left-looking factorisation: per column entry the steps k < J that update it
-};
-
-int vpos_host(int order, int pdim, int nf, int a, int r) {
-    if (pdim != 15) return 6 * a + r;
-    return order ? 15 * a + r : (r < 6 ? 9 * nf + 6 * a + r : 9 * a + (r - 6));
-}
-
-double now_ms();
+// ---- structure build, host half: csrc/vba_host_structure.h (plain C++, also compiled into the sanitizer harness of the tests)
+using vba_host::Structure;
+using vba_host::vpos_host;
+using vba_host::now_ms;
 int build_structure(Handle* h, const vba_problem* P, Structure& st) {
-    static const bool timing = getenv("VBA_TIMING") != nullptr;
-    const double t_b0 = timing ? now_ms() : 0.0;
-    const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2, nkf = P->n_kf;
-    auto pidx = [nf](int a, int b) { return a * nf - a * (a - 1) / 2 + (b - a); };
-    st.pair_a.resize(npairs);
-    st.pair_b.resize(npairs);
-    st.off_pair.clear();
-    st.off_pair.reserve(npairs);
-    for (int a = 0; a < nf; a++)
-        for (int b = a; b < nf; b++) {
-            st.pair_a[pidx(a, b)] = a;
-            st.pair_b[pidx(a, b)] = b;
-            if (a != b) st.off_pair.push_back(pidx(a, b));
-        }
-    const bool idp = P->variant == VBA_VARIANT_PRV_IDP;
-    const int mw = (nkf + 63) / 64;
-    st.mwords = mw;
-    st.lmask.assign((size_t)P->n_pt * mw, 0ull);
-    // occ[a] = the keyframes that share a landmark with free keyframe a (observer or reference), as a bitmask
-    std::vector<unsigned long long> occ((size_t)nf * mw, 0ull), tmp(mw);
-    st.item_cap = 0;
-    if (P->n_pt > 0 && P->pt_obs_begin[0] != 0) return fail(h, "pt_obs_begin is not a valid CSR");
-    for (int p = 0; p < P->n_pt; p++) {
-        const int o0 = P->pt_obs_begin[p], o1 = P->pt_obs_begin[p + 1];
-        if (o0 > o1 || o0 < 0 || o1 > P->n_obs) return fail(h, "pt_obs_begin is not a valid CSR");
-        unsigned long long* M = &st.lmask[(size_t)p * mw];
-        int rf = -1;
-        if (idp) {
-            rf = P->pt_ref_kf[p];
-            if (rf < 0 || rf >= nkf) return fail(h, "pt_ref_kf out of range");
-        }
-        for (int o = o0; o < o1; o++) {
-            const int kf = P->obs_kf[o];
-            if (kf < 0 || kf >= nkf) return fail(h, "obs_kf out of range");
-            if (kf == rf) return fail(h, "observation from the reference keyframe is not an edge");
-            const unsigned long long bit = 1ull << (kf & 63);
-            if (M[kf >> 6] & bit) return fail(h, "a landmark is observed twice from one keyframe");
-            M[kf >> 6] |= bit;
-        }
-        const long long m = o1 - o0;
-        st.item_cap += idp ? m * (m + 1) / 2 : m * (m - 1) / 2;
-        // every free keyframe of the track (reference included) shares this landmark with every other one
-        for (int wd = 0; wd < mw; wd++) tmp[wd] = M[wd];
-        if (rf >= 0) tmp[rf >> 6] |= 1ull << (rf & 63);
-        for (int wd = 0; wd < mw; wd++) {
-            unsigned long long bits = tmp[wd];
-            while (bits) {
-                const int a = 64 * wd + __builtin_ctzll(bits);
-                bits &= bits - 1;
-                if (a >= nf) break;
-                for (int w2 = 0; w2 < mw; w2++) occ[(size_t)a * mw + w2] |= tmp[w2];
-            }
-        }
-    }
-    if (P->pt_obs_begin[P->n_pt] != P->n_obs) return fail(h, "pt_obs_begin does not cover the observations");
-    auto pair_vis = [&](int a, int b) { return (occ[(size_t)a * mw + (b >> 6)] >> (b & 63)) & 1ull; };
-    if (idp) {
-        // k_lin2 work split: runs of consecutive landmarks with <= 256 edges and <= 64 landmarks per workgroup
-        // (one 16-B record per workgroup: first / end landmark, first / end edge)
-        st.linblk.clear();
-        int p = 0;
-        while (p < P->n_pt) {
-            const int p_first = p;
-            int ne = 0, np2 = 0;
-            while (p < P->n_pt && np2 < 64) {
-                const int k = P->pt_obs_begin[p + 1] - P->pt_obs_begin[p];
-                if (k > 256) return fail(h, "a landmark with more than 256 observations is not supported");
-                if (ne + k > 256) break;
-                ne += k; np2++; p++;
-            }
-            st.linblk.push_back(p_first); st.linblk.push_back(p);
-            st.linblk.push_back(P->pt_obs_begin[p_first]); st.linblk.push_back(P->pt_obs_begin[p]);
-        }
-    }
-    const double t_b1 = timing ? now_ms() : 0.0;
-    // IMU edges per block pair: (edge, role) with role bit0: a is keyframe j of the edge, bit1: b is keyframe j
-    const int nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
-    st.pimu_begin.assign(npairs + 1, 0);
-    for (int pass = 0; pass < 2; pass++) {
-        std::vector<int> fill;
-        if (pass) {
-            for (int i = 0; i < npairs; i++) st.pimu_begin[i + 1] += st.pimu_begin[i];
-            st.pimu.assign(2 * (size_t)st.pimu_begin[npairs], 0);
-            fill.assign(st.pimu_begin.begin(), st.pimu_begin.end() - 1);
-        }
-        auto put = [&](int pi, int k, int role) {
-            if (!pass) { st.pimu_begin[pi + 1]++; return; }
-            st.pimu[2 * (size_t)fill[pi]] = k;
-            st.pimu[2 * (size_t)fill[pi] + 1] = role;
-            fill[pi]++;
-        };
-        for (int k = 0; k < nimu; k++) {
-            const int i = P->imu_kf_i[k], j = P->imu_kf_j[k];
-            if (i < 0 || j < 0 || i >= nkf || j >= nkf || i == j) return fail(h, "imu keyframe index out of range");
-            if (i < nf) put(pidx(i, i), k, 0);
-            if (j < nf) put(pidx(j, j), k, 3);
-            if (i < nf && j < nf) {
-                if (i < j) put(pidx(i, j), k, 2);
-                else put(pidx(j, i), k, 1);
-            }
-        }
-    }
-    if (P->solver == VBA_SOLVER_PCG) {   // block rows of S: a shares a landmark or an IMU edge with b
-        st.adj_begin.assign(nf + 1, 0);
-        st.adj.clear();
-        for (int a = 0; a < nf; a++) {
-            for (int b = 0; b < nf; b++) {
-                if (b == a) continue;
-                const int pi = (a < b) ? pidx(a, b) : pidx(b, a);
-                if (pair_vis(a, b) || st.pimu_begin[pi + 1] > st.pimu_begin[pi]) st.adj.push_back(b);
-            }
-            st.adj_begin[a + 1] = (int)st.adj.size();
-        }
-    }
-    // symbolic factorisation on 32x32 tiles (the tile-level analogue of SimplicialLDLT::analyzePattern,
-    // linear_solver_eigen.h:147-152): which tiles of L can be nonzero.  Two elimination orders are tried and the cheaper
-    // one (tile products of the factorisation) kept -- g2o lets AMD pick an order; the reduced system here is either
-    //   order 0: all V/Bias blocks first, PR blocks last -- the IMU chain stays a narrow band, the PR block fills in
-    //            completely: best when most keyframes share landmarks with most others (the usual local window)
-    //   order 1: keyframe by keyframe [PR_a V_a Bias_a] -- a block band whose width is the co-visibility span: best
-    //            for long, thin windows and for maps
-    const int pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
-    const int np = pdim * nf, nS = ((np + VBA_NB - 1) / VBA_NB) * VBA_NB, nb = nS / VBA_NB;
-    auto symbolic = [&](int order, bool lists) -> long long {
-    st.tpairs.clear(); st.pan.clear();
-    std::vector<unsigned char> T((size_t)nb * nb, 0);
-    for (int i = 0; i < nb; i++) T[(size_t)i * nb + i] = 1;
-    for (int pi = 0; pi < npairs; pi++) {
-        const int a = st.pair_a[pi], b = st.pair_b[pi];
-        const bool vis = pair_vis(a, b);
-        const bool imu = st.pimu_begin[pi + 1] > st.pimu_begin[pi];
-        if (!vis && !imu && a != b) continue;
-        // a keyframe's PR dofs (0..5) and V/Bias dofs (6..14) are two contiguous runs: each touches at most two tiles
-        const int nsub = ((imu || a == b) && pdim == 15) ? 2 : 1;
-        for (int sr = 0; sr < nsub; sr++)
-            for (int sc = 0; sc < nsub; sc++) {
-                const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
-                const int ti0 = vpos_host(order, pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(order, pdim, nf, a, r1) / VBA_NB;
-                const int tj0 = vpos_host(order, pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(order, pdim, nf, b, c1) / VBA_NB;
-                for (int ti = ti0; ti <= ti1; ti++)
-                    for (int tj = tj0; tj <= tj1; tj++) T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)] = 1;
-            }
-    }
-    st.step_begin.assign(nb + 1, 0);
-    st.pan_begin.assign(nb + 1, 0);
-    st.step_npairs.assign(nb, 0);
-    std::vector<int> pk;
-    long long cost = 0;
-    for (int k = 0; k < nb; k++) {
-        pk.clear();
-        for (int I = k + 1; I < nb; I++)
-            if (T[(size_t)I * nb + k]) pk.push_back(I);
-        for (int I : pk) st.tpairs.push_back((I << 16) | I);  // diagonal pairs first: pair 0 owns y_k
-        for (size_t i = 0; i < pk.size(); i++)
-            for (size_t j = 0; j < i; j++) {
-                st.tpairs.push_back((pk[i] << 16) | pk[j]);
-                T[(size_t)pk[i] * nb + pk[j]] = 1;  // fill
-            }
-        for (int I : pk) st.pan.push_back(I);
-        st.step_begin[k + 1] = (int)st.tpairs.size();
-        st.pan_begin[k + 1] = (int)st.pan.size();
-        st.step_npairs[k] = st.step_begin[k + 1] - st.step_begin[k];
-    }
-    cost = (long long)st.tpairs.size();   // one tile product per update pair (= the k-list entries of the left-looking form)
-    if (!lists) return cost;
-    // left-looking lists: column entries in the order (J,J), then (I,J) for I in the panel of J; K(I,J) = {k < J : L_Ik, L_Jk != 0}
-    st.kl_begin.clear();
-    st.klist.clear();
-    for (int J = 0; J < nb; J++) {
-        for (int e = -1; e < st.pan_begin[J + 1] - st.pan_begin[J]; e++) {
-            const int I = (e < 0) ? J : st.pan[st.pan_begin[J] + e];
-            st.kl_begin.push_back((int)st.klist.size());
-            for (int k = 0; k < J; k++)
-                if (T[(size_t)I * nb + k] && T[(size_t)J * nb + k]) st.klist.push_back(k);
-        }
-    }
-    st.kl_begin.push_back((int)st.klist.size());
-    // which sub-blocks of a keyframe pair's block can land in a tile the factorisation reads (T now holds L's pattern)
-    st.pair_mask.assign(npairs, 0);
-    for (int pi = 0; pi < npairs; pi++) {
-        const int a = st.pair_a[pi], b = st.pair_b[pi];
-        int mask = 0;
-        const int nsub = (pdim == 15) ? 2 : 1;
-        for (int sr = 0; sr < nsub; sr++)
-            for (int sc = 0; sc < nsub; sc++) {
-                const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
-                const int ti0 = vpos_host(order, pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(order, pdim, nf, a, r1) / VBA_NB;
-                const int tj0 = vpos_host(order, pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(order, pdim, nf, b, c1) / VBA_NB;
-                bool any = false;
-                for (int ti = ti0; ti <= ti1; ti++)
-                    for (int tj = tj0; tj <= tj1; tj++) any = any || T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)];
-                if (any) mask |= 1 << ((sr ? 2 : 0) + (sc ? 1 : 0));
-            }
-        st.pair_mask[pi] = mask;
-    }
-    return cost;
-    };
-    static const int env_order = getenv("VBA_ORDER") ? atoi(getenv("VBA_ORDER")) : -1;
-    st.order = 0;
-    if (pdim == 15) {
-        if (env_order >= 0) st.order = env_order ? 1 : 0;
-        else {
-            const long long c0 = symbolic(0, false), c1 = symbolic(1, false);
-            st.order = (10 * c1 < 7 * c0) ? 1 : 0;  // only a clear win: a batch that mixes both orders pays for both patterns
-            if (timing) fprintf(stderr, "[vba] tile products of the factorisation: V/Bias-first %lld, keyframe order %lld (nb %d)\n", c0, c1, nb);
-        }
-    }
-    symbolic(st.order, true);
-    st.off_pair.resize(npairs, 0);  // padded to the pair stride
-    if (timing) fprintf(stderr, "[vba] structure (host): validation + masks %.3f ms, IMU lists + symbolic factorisation %.3f ms\n", t_b1 - t_b0, now_ms() - t_b1);
+    std::string err;
+    if (vba_host::build_structure(P, st, err)) return fail(h, err);
     return 0;
 }
 
 // a pageable std::vector goes through a pinned copy first: a pageable hipMemcpyAsync is a synchronous, staged transfer
 template <typename T>
 int h2d_vec(Handle* h, int id, const std::vector<T>& v, PinVec<T>& pin) {
+    if (h->arena_on) {
+        h->pending.push_back({id, v.data(), v.size() * sizeof(T)});
+        return 0;
+    }
     pin.clear();
     pin.resize(v.size());
     if (!pin.ok) return fail(h, "out of pinned host memory (upload staging)");
@@ -503,8 +290,32 @@ int h2d_vec(Handle* h, int id, const std::vector<T>& v, PinVec<T>& pin) {
 template <typename V>
 int h2d(Handle* h, int id, const V& v) {
     typedef typename V::value_type T;
+    if (h->arena_on) {
+        h->pending.push_back({id, v.data(), v.size() * sizeof(T)});
+        return 0;
+    }
     HIPCHK(h, h->buf[id].ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
     if (!v.empty()) HIPCHK(h, hipMemcpyAsync(h->buf[id].p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->up_stream));
+    return 0;
+}
+// arena mode: lay the recorded arrays out (256-B aligned), gather them into the pinned arena, one copy, point the views
+int h2d_flush(Handle* h) {
+    if (!h->arena_on) return 0;
+    size_t total = 0;
+    for (auto& q : h->pending) total += (std::max<size_t>(q.bytes, 16) + 255) / 256 * 256;
+    HIPCHK(h, h->up_arena.ensure(total + 256));
+    HIPCHK(h, h->up_arena_host.ensure(total + 256));
+    char* hb = reinterpret_cast<char*>(h->up_arena_host.p);
+    char* db = reinterpret_cast<char*>(h->up_arena.p);
+    size_t off = 0;
+    for (auto& q : h->pending) {
+        if (q.bytes) memcpy(hb + off, q.src, q.bytes);
+        h->buf[q.id].view = db + off;
+        h->buf[q.id].view_bytes = std::max<size_t>(q.bytes, 16);
+        off += (std::max<size_t>(q.bytes, 16) + 255) / 256 * 256;
+    }
+    if (total) HIPCHK(h, hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, h->up_stream));
+    h->pending.clear();
     return 0;
 }
 int dalloc(Handle* h, int id, size_t bytes) {
@@ -521,7 +332,6 @@ void quat_to_R_host(const double* q, double* R) {
     R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
 
-double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // >= this many windows: left-looking factorisation kernels, which never modify S (measured: the right-looking pair is faster
 // up to ~256 windows)
@@ -540,6 +350,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->uploaded = false;
     h->n_win = n;
     h->regime_n = n;
+    for (auto& b : h->buf) { b.view = nullptr; b.view_bytes = 0; }
+    h->pending.clear();
+    static const int arena_max = getenv("VBA_ARENA_MAX") ? atoi(getenv("VBA_ARENA_MAX")) : 8;
+    h->arena_on = n <= arena_max;
     h->desc.assign(n, WinDesc());
     h->win_tiles.assign(n, 0);
     Staging& G = h->stg;
@@ -828,6 +642,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_VEC].p, 0, (size_t)vec0 * 8, h->up_stream));
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_YV].p, 0, (size_t)vec0 * 8, h->up_stream));
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_BPOSE].p, 0, (size_t)vec0 * 16, h->up_stream));
+    if (h2d_flush(h)) return -1;
     Batch& B = h->B;
     B.desc = dp<WinDesc>(h, BUF_DESC); B.ctrl = dp<WinCtrl>(h, BUF_CTRL); B.n_win = n;
     B.pose = dp<double>(h, BUF_POSE); B.vel = dp<double>(h, BUF_VEL); B.bias = dp<double>(h, BUF_BIAS); B.kfR = dp<double>(h, BUF_KFR);
@@ -1459,6 +1274,8 @@ int vba_destroy(void* handle) {
     (void)hipStreamSynchronize(h->up_stream);
     (void)hipStreamSynchronize(h->dl_stream);
     h->stg.release();
+    h->up_arena.release();
+    h->up_arena_host.release();
     for (auto& b : h->buf) b.release();
     h->preint.release();
     h->pose_arena.release();
@@ -1592,9 +1409,11 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
 // test/debug hook (not part of include/vislam_ba.h): raw copy out of one device buffer of the last batch
 int vba_debug_copy(void* handle, int32_t buf_id, uint64_t offset_bytes, void* dst, uint64_t nbytes) {
     Handle* h = reinterpret_cast<Handle*>(handle);
-    if (!h || buf_id < 0 || buf_id >= BUF_N || offset_bytes + nbytes > h->buf[buf_id].cap) return -1;
+    if (!h || buf_id < 0 || buf_id >= BUF_N) return -1;
+    const DevBuf& b = h->buf[buf_id];
+    if (offset_bytes + nbytes > (b.view ? b.view_bytes : b.cap)) return -1;
     (void)hipSetDevice(h->device);
-    return hipMemcpy(dst, reinterpret_cast<char*>(h->buf[buf_id].p) + offset_bytes, nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    return hipMemcpy(dst, reinterpret_cast<char*>(b.ptr()) + offset_bytes, nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 int vba_debug_set_streams(void* handle, int32_t n) {
     Handle* h = reinterpret_cast<Handle*>(handle);
@@ -1805,102 +1624,6 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
     }
     return 0;
 }
-
-// ---- on-disk problem format ----
-extern "C++" {
-namespace {
-struct ProblemFileHeader {
-    char magic[4];
-    uint32_t version;
-    int32_t variant, n_kf, n_kf_free, n_pt, n_obs, n_imu, algo, its_stage1, its_stage2, protocol, robust, has_kf_fix;
-    double K[4], T_cb[7], g_w[3], inv_bg_rw2, inv_ba_rw2, huber_vis, huber_prv, huber_bias, chi2_th, depth_min, rho_min;
-};
-struct ArrSpec { size_t off; size_t bytes; };
-// the arrays of a vba_problem in struct order: (pointer member offset, byte size)
-std::vector<ArrSpec> problem_arrays(const ProblemFileHeader& hd) {
-    const size_t kf = hd.n_kf, pt = hd.n_pt, ob = hd.n_obs, im = hd.n_imu;
-    std::vector<ArrSpec> v = {
-        {offsetof(vba_problem, kf_pose), kf * 7 * 8}, {offsetof(vba_problem, kf_vel), kf * 3 * 8}, {offsetof(vba_problem, kf_bias), kf * 12 * 8},
-        {offsetof(vba_problem, pt), pt * 3 * 8}, {offsetof(vba_problem, pt_ref_kf), pt * 4}, {offsetof(vba_problem, pt_obs_begin), (pt + 1) * 4},
-        {offsetof(vba_problem, obs_kf), ob * 4}, {offsetof(vba_problem, obs_uv), ob * 2 * 8}, {offsetof(vba_problem, obs_w), ob * 8},
-        {offsetof(vba_problem, imu_kf_i), im * 4}, {offsetof(vba_problem, imu_kf_j), im * 4},
-        {offsetof(vba_problem, imu_meas), im * VBA_IMU_MEAS_STRIDE * 8}, {offsetof(vba_problem, imu_info_prv), im * 81 * 8},
-        {offsetof(vba_problem, kf_fix), hd.has_kf_fix ? kf : 0}};
-    return v;
-}
-}  // namespace
-}  // extern "C++"
-
-int vba_problem_save(const char* path, const vba_problem* p) {
-    if (!path || !p) return -1;
-    ProblemFileHeader hd;
-    std::memset(&hd, 0, sizeof hd);
-    std::memcpy(hd.magic, "VBAP", 4);
-    hd.version = 1;
-    hd.variant = p->variant; hd.n_kf = p->n_kf; hd.n_kf_free = p->n_kf_free; hd.n_pt = p->n_pt; hd.n_obs = p->n_obs; hd.n_imu = p->n_imu;
-    hd.algo = p->algo; hd.its_stage1 = p->its_stage1; hd.its_stage2 = p->its_stage2; hd.protocol = p->protocol; hd.robust = p->robust;
-    hd.has_kf_fix = p->kf_fix ? 1 : 0;
-    std::memcpy(hd.K, p->K, sizeof hd.K); std::memcpy(hd.T_cb, p->T_cb, sizeof hd.T_cb); std::memcpy(hd.g_w, p->g_w, sizeof hd.g_w);
-    hd.inv_bg_rw2 = p->inv_bg_rw2; hd.inv_ba_rw2 = p->inv_ba_rw2; hd.huber_vis = p->huber_vis; hd.huber_prv = p->huber_prv;
-    hd.huber_bias = p->huber_bias; hd.chi2_th = p->chi2_th; hd.depth_min = p->depth_min; hd.rho_min = p->rho_min;
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return -2;
-    bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1;
-    static const char zeros[16] = {0};
-    for (const ArrSpec& a : problem_arrays(hd)) {
-        const void* src = *reinterpret_cast<void* const*>(reinterpret_cast<const char*>(p) + a.off);
-        if (a.bytes) {
-            if (src) ok = ok && std::fwrite(src, 1, a.bytes, f) == a.bytes;
-            else for (size_t i = 0; i < a.bytes; i += 16) ok = ok && std::fwrite(zeros, 1, std::min<size_t>(16, a.bytes - i), f) > 0;  // absent optional array
-        }
-    }
-    ok = (std::fclose(f) == 0) && ok;
-    return ok ? 0 : -3;
-}
-
-int vba_problem_load(const char* path, vba_problem** out) {
-    if (!path || !out) return -1;
-    *out = nullptr;
-    FILE* f = std::fopen(path, "rb");
-    if (!f) return -2;
-    ProblemFileHeader hd;
-    if (std::fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, "VBAP", 4) != 0 || hd.version != 1 || hd.n_kf < 0 || hd.n_pt < 0 ||
-        hd.n_obs < 0 || hd.n_imu < 0 || hd.n_kf_free < 0 || hd.n_kf_free > hd.n_kf) {
-        std::fclose(f);
-        return -3;
-    }
-    const std::vector<ArrSpec> arrs = problem_arrays(hd);
-    size_t total = (sizeof(vba_problem) + 15) / 16 * 16;
-    for (const ArrSpec& a : arrs) total += (a.bytes + 15) / 16 * 16;
-    char* blk = static_cast<char*>(std::calloc(1, total));
-    if (!blk) { std::fclose(f); return -4; }
-    vba_problem* p = reinterpret_cast<vba_problem*>(blk);
-    p->variant = hd.variant; p->n_kf = hd.n_kf; p->n_kf_free = hd.n_kf_free; p->n_pt = hd.n_pt; p->n_obs = hd.n_obs; p->n_imu = hd.n_imu;
-    p->algo = hd.algo; p->its_stage1 = hd.its_stage1; p->its_stage2 = hd.its_stage2; p->protocol = hd.protocol; p->robust = hd.robust;
-    std::memcpy(p->K, hd.K, sizeof hd.K); std::memcpy(p->T_cb, hd.T_cb, sizeof hd.T_cb); std::memcpy(p->g_w, hd.g_w, sizeof hd.g_w);
-    p->inv_bg_rw2 = hd.inv_bg_rw2; p->inv_ba_rw2 = hd.inv_ba_rw2; p->huber_vis = hd.huber_vis; p->huber_prv = hd.huber_prv;
-    p->huber_bias = hd.huber_bias; p->chi2_th = hd.chi2_th; p->depth_min = hd.depth_min; p->rho_min = hd.rho_min;
-    size_t off = (sizeof(vba_problem) + 15) / 16 * 16;
-    bool ok = true;
-    for (const ArrSpec& a : arrs) {
-        void** slot = reinterpret_cast<void**>(blk + a.off);
-        if (a.bytes) {
-            *slot = blk + off;
-            ok = ok && std::fread(blk + off, 1, a.bytes, f) == a.bytes;
-            off += (a.bytes + 15) / 16 * 16;
-        } else
-            *slot = nullptr;
-    }
-    ok = ok && std::fgetc(f) == EOF;   // nothing may follow the last array
-    std::fclose(f);
-    if (!ok) { std::free(blk); return -5; }
-    // the CSR must be consistent before anybody indexes with it
-    if (p->n_pt > 0 && (p->pt_obs_begin[0] != 0 || p->pt_obs_begin[p->n_pt] != p->n_obs)) { std::free(blk); return -6; }
-    *out = p;
-    return 0;
-}
-
-void vba_problem_free(vba_problem* p) { std::free(p); }
 
 int vba_set_profile(void* handle, int32_t enable) {
     Handle* h = reinterpret_cast<Handle*>(handle);

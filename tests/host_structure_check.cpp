@@ -1,0 +1,45 @@
+// Sanitizer harness of the host half of the structure build (mc_slam_amd/csrc/vba_host_structure.h) and of the problem file
+// reader (vba_problem_io.h): plain C++, built by tests/test_host_structure.py with g++ -fsanitize=address,undefined.
+//   host_structure_check <file.vbap>...   -> one line per file: "ok <summary>" or "error <message>"
+#include "../mc_slam_amd/csrc/vba_host_structure.h"
+#include "../mc_slam_amd/csrc/vba_problem_io.h"
+
+#include <cstdint>
+
+static uint64_t fnv(const std::vector<int>& v, uint64_t h = 1469598103934665603ull) {
+    for (int x : v) { h ^= (uint32_t)x; h *= 1099511628211ull; }
+    return h;
+}
+
+int main(int argc, char** argv) {
+    for (int a = 1; a < argc; a++) {
+        vba_problem* P = nullptr;
+        const int rc = vba_problem_load(argv[a], &P);
+        if (rc) { printf("error load %d\n", rc); continue; }
+        vba_host::Structure st;
+        std::string err;
+        if (vba_host::build_structure(P, st, err)) { printf("error %s\n", err.c_str()); vba_problem_free(P); continue; }
+        long long mask_bits = 0;
+        for (unsigned long long m : st.lmask) mask_bits += __builtin_popcountll(m);
+        const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2;
+        // internal consistency the device side relies on
+        bool ok = (int)st.pair_a.size() == npairs && (int)st.pair_mask.size() == npairs && (int)st.pimu_begin.size() == npairs + 1 &&
+                  st.lmask.size() == (size_t)P->n_pt * st.mwords && st.kl_begin.size() == st.pan.size() + st.step_begin.size();
+        for (size_t i = 0; i + 1 < st.pimu_begin.size(); i++) ok = ok && st.pimu_begin[i] <= st.pimu_begin[i + 1];
+        ok = ok && (size_t)st.pimu_begin.back() * 2 == st.pimu.size();
+        if (P->variant == VBA_VARIANT_PRV_IDP) {   // the k_lin2 runs cover every landmark and edge exactly once, within the limits
+            int p = 0;
+            for (size_t i = 0; i + 3 < st.linblk.size() + 1 && i < st.linblk.size(); i += 4) {
+                ok = ok && st.linblk[i] == p && st.linblk[i + 1] > p && st.linblk[i + 1] - p <= 64 && st.linblk[i + 3] - st.linblk[i + 2] <= 256 &&
+                     st.linblk[i + 2] == P->pt_obs_begin[p] && st.linblk[i + 3] == P->pt_obs_begin[st.linblk[i + 1]];
+                p = st.linblk[i + 1];
+            }
+            ok = ok && p == P->n_pt;
+        }
+        printf("%s order %d mwords %d item_cap %lld mask_bits %lld tiles %zu klist %zu pimu %zu pan %zu h_tiles %llx h_mask %llx\n", ok ? "ok" : "error inconsistent",
+               st.order, st.mwords, st.item_cap, mask_bits, st.tpairs.size(), st.klist.size(), st.pimu.size() / 2, st.pan.size(),
+               (unsigned long long)fnv(st.tpairs), (unsigned long long)fnv(st.pair_mask));
+        vba_problem_free(P);
+    }
+    return 0;
+}
