@@ -1355,16 +1355,24 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
         if (make_handle(h->device, h, &l) != 0) return fail(h, "vba_batch_solve: could not create a lane");
         h->lanes.push_back(l);
     }
-    // balanced chunks (no tiny tail); with three or more of them the first is half a chunk, so that the device starts after half
-    // the packing / transfer time of a full one (the other chunks share the remainder evenly)
-    std::vector<int> cbeg(n_chunks + 1, 0);
+    // chunk boundaries: a ramp at the start (a quarter chunk, then half a chunk: the device starts after a quarter of the packing /
+    // transfer time of a full chunk and never waits for the second), the rest in equal chunks (no tiny tail).  No chunk falls
+    // below 256 windows when the batch has that many: the kernel choice of a chunk (section "regime") then equals the batch's.
+    std::vector<int> cbeg(1, 0);
     {
-        const int even = (n + n_chunks - 1) / n_chunks;
-        const int first = (n_chunks >= 3 && even >= 512) ? even / 2 : even;
-        cbeg[1] = std::min(n, first);
-        for (int c = 1; c < n_chunks; c++) cbeg[c + 1] = cbeg[1] + (int)((long long)(n - cbeg[1]) * c / (n_chunks - 1));
-        cbeg[n_chunks] = n;
+        static const int ramp = getenv("VBA_NO_RAMP") ? 0 : 1;
+        int left = n;
+        if (ramp && n_chunks >= 3 && chunk_max >= 1024) {
+            const int c1 = std::max(256, chunk_max / 4), c2 = std::max(256, chunk_max / 2);
+            cbeg.push_back(c1);
+            cbeg.push_back(c1 + c2);
+            left = n - c1 - c2;
+        }
+        const int rest = std::max(1, (left + chunk_max - 1) / chunk_max);
+        const int base = cbeg.back();
+        for (int c = 1; c <= rest; c++) cbeg.push_back(base + (int)((long long)left * c / rest));
     }
+    const int n_chunks2 = (int)cbeg.size() - 1;
     std::atomic<int> next(0), bad(0);
     std::mutex mu;
     // Lanes that start together stay in step (all pack, then all solve, then all scatter: the GPU idles while the hosts pack).
@@ -1389,7 +1397,7 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
         return rc;
     };
     auto work = [&](Handle* lane) {
-        for (int c = next.fetch_add(1); c < n_chunks && !bad.load(); c = next.fetch_add(1)) {
+        for (int c = next.fetch_add(1); c < n_chunks2 && !bad.load(); c = next.fetch_add(1)) {
             const int w0 = cbeg[c], cn = cbeg[c + 1] - w0;
             if (cn <= 0) continue;
             if (do_upload(lane, cn, inout + w0) || run_gated(lane) || do_download(lane, cn, inout + w0, out ? out + w0 : nullptr)) {
