@@ -55,7 +55,9 @@ struct Batch {
     const int *tl_kl_begin, *tl_kl;  // left-looking factorisation: per column entry (J,J),(I,J).. the steps k < J that update it
     double *dvec, *winv;             // D of the factor (nS per window); L_JJ^-T D_J^-1 of the current step (32x32 per window)
     double* part;
-    const volatile int* stop_word;
+    const volatile int* stop_word;   // DEVICE copy of the caller's stop flag (word 1023 of the group's mirror words), refreshed by k_poll_stop
+                                     // before every control launch: thousands of windows reading the pinned host word cost 0.5 ms per launch
+    const volatile int* stop_host_word;   // the pinned host word itself
     int* alive_cnt;  // pinned host words: [stage * 32 + it] = 1 if a window is still iterating after control call `it`
     int* alive_dev;  // device mirror of the group's words ([0,64): Gauss-Newton slots, [64,1024): LM slot groups), zeroed at run start:
                      // only the FIRST window that flips a mirror word writes the host word (thousands of windows posting the same
@@ -103,6 +105,9 @@ __global__ void __launch_bounds__(64) k_init_pads(Batch B) {
     const int i = d.np + threadIdx.x;
     if (i < d.nS) B.S[d.S0 + (size_t)i * d.nS + i] = 1.0;
 }
+
+// one PCIe read per control launch instead of one per window
+__global__ void k_poll_stop(Batch B) { *const_cast<int*>(B.stop_word) = *B.stop_host_word; }
 
 __global__ void __launch_bounds__(64) k_reset(Batch B) {
     const int w = blockIdx.y;
