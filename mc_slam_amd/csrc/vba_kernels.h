@@ -43,6 +43,7 @@ struct Batch {
     const int *adj_begin, *adj;         // PCG: per free keyframe the other free keyframes it shares a landmark or an IMU edge with
     double* kf_dir;                     // XYZ landmarks: per keyframe the damping-independent part of its diagonal block and b_p (32 doubles)
     double *pcg_v, *pcg_m, *pcg_s;      // PCG: x r z p q (5 nS per window); inverted diagonal blocks (225 per keyframe); CG state (8 per window)
+    const int *slot_o, *rec_lm;         // [n_obs] observation of the record in every slot; [n_pt] landmark of every landmark record
     const int* slot_lm;                 // [n_obs] landmark of the record in every slot (XYZ gathers fetch the landmark's Sigma through it)
     const int* item_mid;                // per pair: its first item that involves the landmark's reference keyframe
     const unsigned long long* lmask;    // [n_pt x mwords] observing keyframes of every landmark (host-built while validating)
@@ -109,26 +110,28 @@ __global__ void __launch_bounds__(64) k_init_pads(Batch B) {
 // one PCIe read per control launch instead of one per window
 __global__ void k_poll_stop(Batch B) { *const_cast<int*>(B.stop_word) = *B.stop_host_word; }
 
-__global__ void __launch_bounds__(64) k_reset(Batch B) {
+__global__ void __launch_bounds__(256) k_reset(Batch B) {
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t < d.n_kf) {
-        const size_t k = d.kf0 + t;
-        for (int i = 0; i < 7; i++) B.pose[7 * k + i] = B.pose0[7 * k + i];
-        for (int i = 0; i < 3; i++) B.vel[3 * k + i] = B.vel0[3 * k + i];
-        for (int i = 0; i < 12; i++) B.bias[12 * k + i] = B.bias0[12 * k + i];
-        kf_cache(B, d, t);
+    // flat, coalesced copies: consecutive threads take consecutive doubles of each array (the first version gave every thread a
+    // whole keyframe / landmark: stride-7 / -3 / -12 scalar loops, 6 ms per 4096 windows)
+    const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    const size_t k0 = d.kf0, p0 = d.pt0, o0 = d.obs0;
+    for (int i = t0; i < 7 * d.n_kf; i += stride) B.pose[7 * k0 + i] = B.pose0[7 * k0 + i];
+    for (int i = t0; i < 3 * d.n_kf; i += stride) B.vel[3 * k0 + i] = B.vel0[3 * k0 + i];
+    for (int i = t0; i < 12 * d.n_kf; i += stride) B.bias[12 * k0 + i] = B.bias0[12 * k0 + i];
+    for (int i = t0; i < 3 * d.n_pt; i += stride) B.pt[3 * p0 + i] = B.pt0[3 * p0 + i];
+    for (int i = t0; i < d.n_obs; i += stride) { B.lvl[o0 + i] = 0; B.chi2_e[o0 + i] = 0.0; }
+    for (int a = t0; a < d.n_kf; a += stride) {   // R|t cache from the UPLOADED pose (the working copy is being written by other threads)
+        const double* T = B.pose0 + 7 * (k0 + a);
+        double* C = B.kfR + 12 * (k0 + a);
+        double R[9];
+        q2R(T + 3, R);
+#pragma unroll
+        for (int i = 0; i < 9; i++) C[i] = R[i];
+        C[9] = T[0]; C[10] = T[1]; C[11] = T[2];
     }
-    if (t < d.n_pt) {
-        const size_t p = d.pt0 + t;
-        for (int i = 0; i < 3; i++) B.pt[3 * p + i] = B.pt0[3 * p + i];
-    }
-    if (t < d.n_obs) {
-        B.lvl[d.obs0 + t] = 0;
-        B.chi2_e[d.obs0 + t] = 0.0;
-    }
-    if (t == 0) {
+    if (t0 == 0) {
         WinCtrl& c = B.ctrl[w];
         c.stage = 0; c.it = 0; c.active = 0; c.status = 0;
         c.its_done[0] = c.its_done[1] = 0;
@@ -172,23 +175,42 @@ __global__ void __launch_bounds__(64) k_stage_clear(Batch B, int stage) {
     }
 }
 
-__global__ void __launch_bounds__(64) k_stage_mark(Batch B) {
+// One wave per (window, keyframe): the keyframe's PR block is in the index mapping if one of its edges is active -- as the
+// observer (its slot records, in slot order) or, for inverse-depth landmarks, as the reference keyframe of a landmark with an
+// active edge.  The wave stops at the first hit, which is almost always in its first 64 records.  (Round 1: a thread per edge,
+// five dependent loads each, 1.9 ms per 4096 windows.)  Blocks behind the keyframes: the IMU edges, a thread each.
+__global__ void __launch_bounds__(64) k_stage_mark(Batch B, int nblk_kf) {
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
-    const int t = blockIdx.x * 64 + threadIdx.x;
     int* va = B.var_act + d.vec0;
-    if (t < d.n_obs && !B.lvl[d.obs0 + t]) {
-        const int kf = B.obs_kf[d.obs0 + t];
-        // thousands of edges mark the same few hundred flags: look before storing (whoever set the first flag of a block
-        // sets the other five as well), the stores to one line would otherwise serialise in the L2
-        if ((kf_free(B, d, kf) & 1) && !va[vpos(d, kf, 0)])
-            for (int i = 0; i < 6; i++) va[vpos(d, kf, i)] = 1;
-        if (d.variant == 2) {
-            const int rf = B.pt_ref[d.pt0 + B.obs_pt[d.obs0 + t]];
-            if ((kf_free(B, d, rf) & 1) && !va[vpos(d, rf, 0)])
-                for (int i = 0; i < 6; i++) va[vpos(d, rf, i)] = 1;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x < nblk_kf) {
+        const int a = blockIdx.x;
+        if (a >= d.n_free || !(kf_free(B, d, a) & 1)) return;
+        const int* kseg = B.kf_seg + d.kf0 + d.win;
+        bool hit = false;
+        for (int c = kseg[a]; c < kseg[a + 1] && !hit; c += 64) {
+            const int slot = c + lane;
+            const bool on = slot < kseg[a + 1] && !B.lvl[d.obs0 + B.slot_o[d.obs0 + slot]];
+            hit = __ballot(on) != 0ull;
         }
+        if (!hit && d.variant == 2) {
+            const int* rseg = B.ref_seg + d.kf0 + d.win;
+            const int* ob = B.pt_obs_begin + d.pt0 + d.win;
+            for (int c = rseg[a]; c < rseg[a + 1] && !hit; c += 64) {
+                const int rec = c + lane;
+                bool on = false;
+                if (rec < rseg[a + 1]) {
+                    const int p = B.rec_lm[d.pt0 + rec];
+                    for (int o = ob[p]; o < ob[p + 1] && !on; o++) on = !B.lvl[d.obs0 + o];
+                }
+                hit = __ballot(on) != 0ull;
+            }
+        }
+        if (hit && lane < 6) va[vpos(d, a, lane)] = 1;
+        return;
     }
+    const int t = (blockIdx.x - nblk_kf) * 64 + lane;
     if (t < d.n_imu) {
         const int i = B.imu_i[d.imu0 + t], j = B.imu_j[d.imu0 + t];
         const int fi = kf_free(B, d, i), fj = kf_free(B, d, j), act = imu_act(B, d, i, j);

@@ -24,6 +24,7 @@ struct StBuild {   // what the build writes (the solve reads the same arrays thr
     u64_t *mask_q, *slot_mask;                    // scratch: the landmark masks in lm_order / per slot record, so that the ranked
                                                   // walks read them in sequence instead of gathering them through an index
     int *ref_q;                                   // scratch: reference keyframe of the landmark at rank q
+    int *slot_o;                                  // observation of the record in slot s (k_stage_mark walks a keyframe's edges through it)
     int smw;                                      // words per slot_mask entry (the largest mwords of the batch)
 };
 
@@ -159,6 +160,7 @@ __global__ void __launch_bounds__(64) k_st_rank_rec(Batch B, StBuild T) {
             while (B.obs_kf[d.obs0 + o] != k) o++;
             T.slot_perm[d.obs0 + o] = slot;
             T.slot_obs[d.obs0 + slot] = p;   // the landmark of the record in this slot
+            T.slot_o[d.obs0 + slot] = o;
             for (int wd = 0; wd < mw; wd++) T.slot_mask[(size_t)(d.obs0 + slot) * T.smw + wd] = M[wd];
             int r = __popcll(M[kw] & ((1ull << kb) - 1ull));
             for (int wd = 0; wd < kw; wd++) r += __popcll(M[wd]);

@@ -151,7 +151,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_SLOTO, BUF_N
 };
 
 struct ProfEvt {
@@ -603,6 +603,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         for (int w = 0; w < n; w++) slotmask_words = std::max(slotmask_words, (size_t)h->desc[w].mwords);
         if (dalloc(h, BUF_MASKQ, (size_t)mask0 * 8) || dalloc(h, BUF_SLOTMASK, (size_t)obs0 * slotmask_words * 8) || dalloc(h, BUF_REFQ, (size_t)pt0 * 4)) return -1;
     }
+    if (dalloc(h, BUF_SLOTO, (size_t)obs0 * 4)) return -1;
     if (dalloc(h, BUF_TSLOT, (size_t)obs0 * 4) || dalloc(h, BUF_KFDIR, (size_t)kf0 * 32 * 8)) return -1;
     if (dalloc(h, BUF_ITEMBEG, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMMID, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMS, (size_t)item0 * 8)) return -1;
     if (dalloc(h, BUF_STKEY, (size_t)pt0 * 4) || dalloc(h, BUF_LMORDER, (size_t)pt0 * 4) || dalloc(h, BUF_SLOTOBS, (size_t)obs0 * 4) || dalloc(h, BUF_PTINV, (size_t)pt0 * 4)) return -1;
@@ -668,7 +669,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.var_act = dp<int>(h, BUF_VARACT);
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS); B.item_mid = dp<int>(h, BUF_ITEMMID);
-    B.kf_dir = dp<double>(h, BUF_KFDIR); B.slot_lm = dp<int>(h, BUF_SLOTOBS);
+    B.kf_dir = dp<double>(h, BUF_KFDIR); B.slot_lm = dp<int>(h, BUF_SLOTOBS); B.slot_o = dp<int>(h, BUF_SLOTO); B.rec_lm = dp<int>(h, BUF_PTINV);
     B.adj_begin = dp<int>(h, BUF_ADJBEG); B.adj = dp<int>(h, BUF_ADJ); B.pcg_v = dp<double>(h, BUF_PCGV); B.pcg_m = dp<double>(h, BUF_PCGM); B.pcg_s = dp<double>(h, BUF_PCGS);
     B.lmask = dp<unsigned long long>(h, BUF_LMASK); B.kf_seg = dp<int>(h, BUF_KFSEG); B.ref_seg = dp<int>(h, BUF_REFSEG);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
@@ -696,6 +697,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         T.key_seg = dp<int>(h, BUF_KEYSEG); T.tslot = dp<int>(h, BUF_TSLOT);
         T.mask_q = dp<unsigned long long>(h, BUF_MASKQ); T.slot_mask = dp<unsigned long long>(h, BUF_SLOTMASK); T.ref_q = dp<int>(h, BUF_REFQ);
         T.smw = (int)slotmask_words;
+        T.slot_o = dp<int>(h, BUF_SLOTO);
         hipLaunchKernelGGL(k_st_hist, dim3(n), dim3(256), sh_order, h->up_stream, B, T);
         hipLaunchKernelGGL(k_st_rank_lm, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
         hipLaunchKernelGGL(k_st_rank_rec, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
@@ -841,7 +843,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
         hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
         if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
-        hipLaunchKernelGGL(k_stage_mark, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        hipLaunchKernelGGL(k_stage_mark, dim3(h->max_free + (h->max_imu + 63) / 64, g.n_win), dim3(64), 0, g.stream, g.B, h->max_free);
     };
     auto stage_end = [&](Group& g) {
         if (h->variant == VBA_VARIANT_PRV_IDP) return;
@@ -881,7 +883,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
     for (auto& g : groups) {
         use(g);
         ProfScope ps(h, VBA_PROF_MISC);
-        hipLaunchKernelGGL(k_reset, dim3(big_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+        hipLaunchKernelGGL(k_reset, dim3(std::max(1, std::min(32, big_blk / 4)), g.n_win), dim3(256), 0, g.stream, g.B);
     }
     const int RING = 32;   // pinned alive words per window group (its 64-word block: [0, RING) used here)
     int rc = 0;
@@ -940,7 +942,7 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
     for (auto& g : groups) {
         use(g);
         ProfScope ps(h, VBA_PROF_MISC);
-        hipLaunchKernelGGL(k_reset, dim3(big_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+        hipLaunchKernelGGL(k_reset, dim3(std::max(1, std::min(32, big_blk / 4)), g.n_win), dim3(256), 0, g.stream, g.B);
     }
     for (int stage = 0; stage < 2 && rc == 0; stage++) {
         for (auto& g : groups) {
@@ -949,7 +951,7 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
             hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
         hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
             if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
-            hipLaunchKernelGGL(k_stage_mark, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+            hipLaunchKernelGGL(k_stage_mark, dim3(h->max_free + (h->max_imu + 63) / 64, g.n_win), dim3(64), 0, g.stream, g.B, h->max_free);
         }
         {
             // The host stays at most two iterations ahead of the device: before enqueuing iteration it of a group it waits
@@ -1448,7 +1450,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE", "SLOTO"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
