@@ -36,7 +36,9 @@ struct WinDesc {
     int pimu0;      // offset into the pair-imu list
     int vec0;       // offset into rhs/x vectors (nS slots per window)
     int part0;      // offset into the chi2 partial array
-    int n_part_lin; // point blocks of this window in the linearise launch
+    int n_part_lin; // workgroups of this window in the linearise launch (= chi2 partials; XYZ: also the max-diagonal partials)
+    int n_part_pt;  // 64-landmark blocks of the window (= the computeScale partials of k_update_xyz)
+    int lin_runs;   // 1: the window has the work split of the edge-parallel linearisation (lin_blk); 0: thread-per-landmark fallback
     int tl_step0;   // offset of this window's step_begin / pan_begin rows (nb + 1 entries each)
     int tl_pair0;   // offset into the tile-pair list
     int tl_pan0;    // offset into the panel-tile list

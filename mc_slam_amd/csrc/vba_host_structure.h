@@ -101,9 +101,10 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
     }
     if (P->pt_obs_begin[P->n_pt] != P->n_obs) return fail(h, "pt_obs_begin does not cover the observations");
     auto pair_vis = [&](int a, int b) { return (occ[(size_t)a * mw + (b >> 6)] >> (b & 63)) & 1ull; };
-    if (idp) {
-        // k_lin2 work split: runs of consecutive landmarks with <= 256 edges and <= 64 landmarks per workgroup
-        // (one 16-B record per workgroup: first / end landmark, first / end edge)
+    {
+        // work split of the edge-parallel linearisation (k_lin2, k_lin_xyz_e): runs of consecutive landmarks with <= 256 edges and
+        // <= 64 landmarks per workgroup (one 16-B record per workgroup: first / end landmark, first / end edge).  XYZ windows with a
+        // longer track fall back to the thread-per-landmark kernel (linblk left empty).
         st.linblk.clear();
         int p = 0;
         while (p < P->n_pt) {
@@ -111,10 +112,16 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
             int ne = 0, np2 = 0;
             while (p < P->n_pt && np2 < 64) {
                 const int k = P->pt_obs_begin[p + 1] - P->pt_obs_begin[p];
-                if (k > 256) return fail(h, "a landmark with more than 256 observations is not supported");
+                if (k > 256) {
+                    if (idp) return fail(h, "a landmark with more than 256 observations is not supported");
+                    st.linblk.clear();
+                    p = P->n_pt + 1;   // leave both loops
+                    break;
+                }
                 if (ne + k > 256) break;
                 ne += k; np2++; p++;
             }
+            if (p > P->n_pt) break;
             st.linblk.push_back(p_first); st.linblk.push_back(p);
             st.linblk.push_back(P->pt_obs_begin[p_first]); st.linblk.push_back(P->pt_obs_begin[p]);
         }

@@ -18,109 +18,127 @@
 // edge record (XYZ):  [0..11] Bi (2x6 pose Jacobian)  [12..17] g = -Bi^T r   (all pre-scaled)
 // slot record (XYZ):  [0..17] W = Bi^T A (6x3, row-major)
 
+// One reprojection edge of an XYZ landmark (EdgeSE3ProjectXYZ / EdgeNavStatePRPointXYZ): depth, chi2, and in LIN_FULL mode its
+// edge record (Bi, g) and slot record (W = Bi^T A); returns through A / r the point Jacobian and weighted residual the
+// landmark sums need.  `act`: the edge is at level 0 and contributes.
+DEVI void xyz_edge(const Batch& B, const WinDesc& d, const WinCtrl& c, size_t go, const double* X, int mode, double& chi, bool& act,
+                   double* A, double& r0, double& r1) {
+    const double fx = d.K[0], fy = d.K[1], cx = d.K[2], cy = d.K[3];
+    act = false;
+    const int kf = B.obs_kf[go];
+    const double* Ci = B.kfR + 12 * (size_t)(d.kf0 + kf);
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = Ci[i];
+    double Pc[3], ta[3] = {0, 0, 0};
+    if (d.variant == 0) {  // SE3Quat::map: R_cw X + t_cw (se3quat.h:217-220)
+        mv3(R, X, Pc);
+        Pc[0] += Ci[9]; Pc[1] += Ci[10]; Pc[2] += Ci[11];
+    } else {               // Rcb Rwb^T (Pw - Pwb) + tcb (g2otypes.h:289-308)
+        const double v[3] = {X[0] - Ci[9], X[1] - Ci[10], X[2] - Ci[11]};
+        mtv3(R, v, ta);
+        mv3(d.Rcb, ta, Pc);
+        Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
+    }
+    B.depth_e[go] = Pc[2];
+    const size_t pe = B.slot_perm[go];                                   // records live keyframe-major (slot_perm)
+    double* rec = B.erec + VBA_EREC * (size_t)(d.obs0 + pe);
+    double* sl = B.slot + VBA_SLOT3 * (size_t)(d.obs0 + d.pt0 + pe);
+    if (B.lvl[go]) {
+        if (mode == LIN_FULL)
+            for (int i = 0; i < 18; i++) { rec[i] = 0.0; sl[i] = 0.0; }
+        return;
+    }
+    const double iz = 1.0 / Pc[2];
+    const double ex = B.obs_uv[2 * go] - (Pc[0] * iz * fx + cx);
+    const double ey = B.obs_uv[2 * go + 1] - (Pc[1] * iz * fy + cy);
+    const double wgt = B.obs_w[go];
+    const double s = ex * (wgt * ex) + ey * (wgt * ey);
+    B.chi2_e[go] = s;
+    double rw = 1.0;
+    if (c.robust_vis) chi += huber(s, d.hub_vis, &rw);
+    else chi += s;
+    if (mode != LIN_FULL) return;
+    act = true;
+    const double sc = sqrt(rw * wgt);
+    const double x = Pc[0], y = Pc[1], z = Pc[2];
+    const double Jp[6] = {fx * iz, 0.0, -x * iz * fx * iz, 0.0, fy * iz, -y * iz * fy * iz};
+    double Bi[12];
+    const bool of = kf_free(B, d, kf) & 1;
+    if (d.variant == 0) {
+        // types_six_dof_expmap.cpp:124-138: J_point = -(1/z) tmp R ; J_pose closed form (rotation, then translation)
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                A[3 * r + k] = -sc * (Jp[3 * r] * R[k] + Jp[3 * r + 1] * R[3 + k] + Jp[3 * r + 2] * R[6 + k]);
+        const double z2 = z * z;
+        Bi[0] = x * y / z2 * fx; Bi[1] = -(1 + (x * x / z2)) * fx; Bi[2] = y / z * fx;
+        Bi[3] = -1. / z * fx;    Bi[4] = 0;                        Bi[5] = x / z2 * fx;
+        Bi[6] = (1 + y * y / z2) * fy; Bi[7] = -x * y / z2 * fy;   Bi[8] = -x / z * fy;
+        Bi[9] = 0;               Bi[10] = -1. / z * fy;            Bi[11] = y / z2 * fy;
+#pragma unroll
+        for (int i = 0; i < 12; i++) Bi[i] = of ? sc * Bi[i] : 0.0;
+    } else {
+        double Jc[6], JA[6];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                Jc[3 * r + k] = Jp[3 * r] * d.Rcb[k] + Jp[3 * r + 1] * d.Rcb[3 + k] + Jp[3 * r + 2] * d.Rcb[6 + k];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                JA[3 * r + k] = Jc[3 * r] * R[3 * k] + Jc[3 * r + 1] * R[3 * k + 1] + Jc[3 * r + 2] * R[3 * k + 2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const double j0 = Jc[3 * r], j1 = Jc[3 * r + 1], j2 = Jc[3 * r + 2];
+            const double h0 = j1 * ta[2] - j2 * ta[1], h1 = j2 * ta[0] - j0 * ta[2], h2 = j0 * ta[1] - j1 * ta[0];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                A[3 * r + k] = -sc * JA[3 * r + k];                 // g2otypes.cpp:406
+                Bi[6 * r + k] = of ? sc * JA[3 * r + k] : 0.0;      // :409
+            }
+            Bi[6 * r + 3] = of ? -sc * h0 : 0.0;                    // :412
+            Bi[6 * r + 4] = of ? -sc * h1 : 0.0;
+            Bi[6 * r + 5] = of ? -sc * h2 : 0.0;
+        }
+    }
+    r0 = sc * ex; r1 = sc * ey;
+#pragma unroll
+    for (int i = 0; i < 12; i++) rec[i] = Bi[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        rec[12 + i] = -(Bi[i] * r0 + Bi[6 + i] * r1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) sl[3 * i + k] = Bi[i] * A[k] + Bi[6 + i] * A[3 + k];   // W = Bi^T A
+    }
+}
+
+// a landmark's sums over its edges, in edge order: H_ll += A^T A, b_l -= A^T r
+DEVI void xyz_accum(double* Hll, double* bl, const double* A, double r0, double r1) {
+    Hll[0] += A[0] * A[0] + A[3] * A[3]; Hll[1] += A[0] * A[1] + A[3] * A[4]; Hll[2] += A[0] * A[2] + A[3] * A[5];
+    Hll[3] += A[1] * A[1] + A[4] * A[4]; Hll[4] += A[1] * A[2] + A[4] * A[5]; Hll[5] += A[2] * A[2] + A[5] * A[5];
+#pragma unroll
+    for (int k = 0; k < 3; k++) bl[k] -= A[k] * r0 + A[3 + k] * r1;
+}
+
+// thread per landmark (the fallback for windows with a landmark of more than 256 observations)
 DEVI void lin_point_xyz(const Batch& B, const WinDesc& d, const WinCtrl& c, int w, int p, int mode, double& chi,
                         double& maxdiag) {
     const size_t gp = d.pt0 + p;
     const double X[3] = {B.pt[3 * gp], B.pt[3 * gp + 1], B.pt[3 * gp + 2]};
-    const double fx = d.K[0], fy = d.K[1], cx = d.K[2], cy = d.K[3];
     double Hll[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
     int nact = 0;
     const int* ob = B.pt_obs_begin + d.pt0 + d.win;
     for (int o = ob[p]; o < ob[p + 1]; o++) {
-        const size_t go = d.obs0 + o;
-        const int kf = B.obs_kf[go];
-        const double* Ci = B.kfR + 12 * (size_t)(d.kf0 + kf);
-        double R[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) R[i] = Ci[i];
-        double Pc[3], ta[3] = {0, 0, 0};
-        if (d.variant == 0) {  // SE3Quat::map: R_cw X + t_cw (se3quat.h:217-220)
-            mv3(R, X, Pc);
-            Pc[0] += Ci[9]; Pc[1] += Ci[10]; Pc[2] += Ci[11];
-        } else {               // Rcb Rwb^T (Pw - Pwb) + tcb (g2otypes.h:289-308)
-            const double v[3] = {X[0] - Ci[9], X[1] - Ci[10], X[2] - Ci[11]};
-            mtv3(R, v, ta);
-            mv3(d.Rcb, ta, Pc);
-            Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
-        }
-        B.depth_e[go] = Pc[2];
-        const size_t pe = B.slot_perm[go];                                   // records live keyframe-major (slot_perm)
-        double* rec = B.erec + VBA_EREC * (size_t)(d.obs0 + pe);
-        double* sl = B.slot + VBA_SLOT3 * (size_t)(d.obs0 + d.pt0 + pe);
-        if (B.lvl[go]) {
-            if (mode == LIN_FULL)
-                for (int i = 0; i < 18; i++) { rec[i] = 0.0; sl[i] = 0.0; }
-            continue;
-        }
-        const double iz = 1.0 / Pc[2];
-        const double ex = B.obs_uv[2 * go] - (Pc[0] * iz * fx + cx);
-        const double ey = B.obs_uv[2 * go + 1] - (Pc[1] * iz * fy + cy);
-        const double wgt = B.obs_w[go];
-        const double s = ex * (wgt * ex) + ey * (wgt * ey);
-        B.chi2_e[go] = s;
-        double rw = 1.0;
-        if (c.robust_vis) chi += huber(s, d.hub_vis, &rw);
-        else chi += s;
-        if (mode != LIN_FULL) continue;
+        double A[6] = {0, 0, 0, 0, 0, 0}, r0 = 0, r1 = 0;
+        bool act;
+        xyz_edge(B, d, c, d.obs0 + o, X, mode, chi, act, A, r0, r1);
+        if (!act) continue;
         nact++;
-        const double sc = sqrt(rw * wgt);
-        const double x = Pc[0], y = Pc[1], z = Pc[2];
-        const double Jp[6] = {fx * iz, 0.0, -x * iz * fx * iz, 0.0, fy * iz, -y * iz * fy * iz};
-        double A[6], Bi[12];
-        const bool of = kf_free(B, d, kf) & 1;
-        if (d.variant == 0) {
-            // types_six_dof_expmap.cpp:124-138: J_point = -(1/z) tmp R ; J_pose closed form (rotation, then translation)
-#pragma unroll
-            for (int r = 0; r < 2; r++)
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    A[3 * r + k] = -sc * (Jp[3 * r] * R[k] + Jp[3 * r + 1] * R[3 + k] + Jp[3 * r + 2] * R[6 + k]);
-            const double z2 = z * z;
-            Bi[0] = x * y / z2 * fx; Bi[1] = -(1 + (x * x / z2)) * fx; Bi[2] = y / z * fx;
-            Bi[3] = -1. / z * fx;    Bi[4] = 0;                        Bi[5] = x / z2 * fx;
-            Bi[6] = (1 + y * y / z2) * fy; Bi[7] = -x * y / z2 * fy;   Bi[8] = -x / z * fy;
-            Bi[9] = 0;               Bi[10] = -1. / z * fy;            Bi[11] = y / z2 * fy;
-#pragma unroll
-            for (int i = 0; i < 12; i++) Bi[i] = of ? sc * Bi[i] : 0.0;
-        } else {
-            double Jc[6], JA[6];
-#pragma unroll
-            for (int r = 0; r < 2; r++)
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    Jc[3 * r + k] = Jp[3 * r] * d.Rcb[k] + Jp[3 * r + 1] * d.Rcb[3 + k] + Jp[3 * r + 2] * d.Rcb[6 + k];
-#pragma unroll
-            for (int r = 0; r < 2; r++)
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    JA[3 * r + k] = Jc[3 * r] * R[3 * k] + Jc[3 * r + 1] * R[3 * k + 1] + Jc[3 * r + 2] * R[3 * k + 2];
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const double j0 = Jc[3 * r], j1 = Jc[3 * r + 1], j2 = Jc[3 * r + 2];
-                const double h0 = j1 * ta[2] - j2 * ta[1], h1 = j2 * ta[0] - j0 * ta[2], h2 = j0 * ta[1] - j1 * ta[0];
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    A[3 * r + k] = -sc * JA[3 * r + k];                 // g2otypes.cpp:406
-                    Bi[6 * r + k] = of ? sc * JA[3 * r + k] : 0.0;      // :409
-                }
-                Bi[6 * r + 3] = of ? -sc * h0 : 0.0;                    // :412
-                Bi[6 * r + 4] = of ? -sc * h1 : 0.0;
-                Bi[6 * r + 5] = of ? -sc * h2 : 0.0;
-            }
-        }
-        const double r0 = sc * ex, r1 = sc * ey;
-        Hll[0] += A[0] * A[0] + A[3] * A[3]; Hll[1] += A[0] * A[1] + A[3] * A[4]; Hll[2] += A[0] * A[2] + A[3] * A[5];
-        Hll[3] += A[1] * A[1] + A[4] * A[4]; Hll[4] += A[1] * A[2] + A[4] * A[5]; Hll[5] += A[2] * A[2] + A[5] * A[5];
-#pragma unroll
-        for (int k = 0; k < 3; k++) bl[k] -= A[k] * r0 + A[3 + k] * r1;
-#pragma unroll
-        for (int i = 0; i < 12; i++) rec[i] = Bi[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            rec[12 + i] = -(Bi[i] * r0 + Bi[6 + i] * r1);
-#pragma unroll
-            for (int k = 0; k < 3; k++) sl[3 * i + k] = Bi[i] * A[k] + Bi[6 + i] * A[3 + k];   // W = Bi^T A
-        }
+        xyz_accum(Hll, bl, A, r0, r1);
     }
     if (mode == LIN_FULL) {
         double* pr = B.prec + VBA_PREC * gp;
@@ -157,7 +175,7 @@ __global__ void __launch_bounds__(64) k_lin_xyz(Batch B, int nblk_pt, int mode) 
     if (mode == LIN_FULL && d.algo == 1 && c.lm_need_trial) return;   // "outer" slot of the LM schedule: not for a window that still owes a trial
     const int m = (mode == LIN_FULL) ? LIN_FULL : LIN_ERR;
     const int p = blockIdx.x * 64 + threadIdx.x;
-    if ((int)blockIdx.x * 64 >= d.n_pt) return;
+    if (d.lin_runs || (int)blockIdx.x * 64 >= d.n_pt) return;   // (windows with a work split are linearised by k_lin_xyz_e)
     double chi = 0.0, mx = 0.0;
     if (p < d.n_pt) lin_point_xyz(B, d, c, w, p, m, chi, mx);
     const double tot = block_sum<64>(chi, sm);
@@ -166,6 +184,72 @@ __global__ void __launch_bounds__(64) k_lin_xyz(Batch B, int nblk_pt, int mode) 
         B.part[d.part0 + blockIdx.x] = tot;
         if (m == LIN_FULL) B.part[d.part0 + d.n_part_lin + blockIdx.x] = tmx;
     }
+}
+
+// The same linearisation, EDGE-parallel (the default): a 256-thread workgroup owns a run of consecutive landmarks with <= 256
+// edges (the k_lin2 work split), a lane per edge evaluates residual and Jacobians and writes the edge's two records, a lane per
+// landmark then adds up its edges' A^T A and A^T r from LDS in edge order (the sums of the thread-per-landmark form, bit for
+// bit).  Six times the parallelism of a thread per landmark and no serial walk over a landmark's observations.
+#define LINX_ES 9   // LDS doubles per edge: A (6), r (2), active
+__global__ void __launch_bounds__(256) k_lin_xyz_e(Batch B, int mode) {
+    __shared__ double ER[256 * LINX_ES];
+    __shared__ double red[4];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    const WinCtrl& c = B.ctrl[w];
+    if (!c.active) return;
+    if (mode == LIN_ERR_TRIAL && !win_on(d, c)) return;
+    if (mode == LIN_FULL && d.algo == 1 && c.lm_need_trial) return;   // "outer" slot of the LM schedule: not for a window that still owes a trial
+    const int m = (mode == LIN_FULL) ? LIN_FULL : LIN_ERR;
+    const int lb = blockIdx.x, t = threadIdx.x;
+    if (!d.lin_runs || lb >= d.n_part_lin) return;
+    const int4 run = reinterpret_cast<const int4*>(B.lin_blk)[d.lb0 + lb];
+    const int p0 = run.x, p1 = run.y, e0 = run.z, e1 = run.w;
+    const int ne = e1 - e0, npb = p1 - p0;
+    double chi = 0.0;
+    if (t < ne) {
+        const size_t go = d.obs0 + e0 + t;
+        const size_t gp = d.pt0 + B.obs_pt[go];
+        const double X[3] = {B.pt[3 * gp], B.pt[3 * gp + 1], B.pt[3 * gp + 2]};
+        double A[6] = {0, 0, 0, 0, 0, 0}, r0 = 0, r1 = 0;
+        bool act;
+        xyz_edge(B, d, c, go, X, m, chi, act, A, r0, r1);
+        if (m == LIN_FULL) {
+            double* er = ER + t * LINX_ES;
+#pragma unroll
+            for (int i = 0; i < 6; i++) er[i] = A[i];
+            er[6] = r0; er[7] = r1; er[8] = act ? 1.0 : 0.0;
+        }
+    }
+    double mx = 0.0;
+    if (m == LIN_FULL) {
+        __syncthreads();
+        if (t < npb) {
+            const int* ob = B.pt_obs_begin + d.pt0 + d.win;
+            const int p = p0 + t;
+            double Hll[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+            int nact = 0;
+            for (int o = ob[p] - e0; o < ob[p + 1] - e0; o++) {
+                const double* er = ER + o * LINX_ES;
+                if (er[8] == 0.0) continue;
+                nact++;
+                xyz_accum(Hll, bl, er, er[6], er[7]);
+            }
+            double* pr = B.prec + VBA_PREC * (size_t)(d.pt0 + p);
+#pragma unroll
+            for (int i = 0; i < 6; i++) pr[i] = Hll[i];
+            pr[6] = bl[0]; pr[7] = bl[1]; pr[8] = bl[2];
+            pr[9] = (double)nact;
+            if (nact) mx = fmax(fmax(fabs(Hll[0]), fabs(Hll[3])), fabs(Hll[5]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    }
+    const double tot = block_sum256(chi, red);
+    if (m == LIN_FULL) {   // (npb <= 64: the landmark lanes are wave 0)
+        if (t == 0) B.part[d.part0 + d.n_part_lin + lb] = mx;
+    }
+    if (t == 0) B.part[d.part0 + lb] = tot;
 }
 
 // depth of every observation at the current estimates, nothing else (isDepthPositive() of the erase loops is
@@ -443,7 +527,7 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* alive, int* 
         const double* bp = B.bpose + 2 * (size_t)d.vec0;
         for (int i = t; i < d.nS; i += 64)
             if (va[i]) sc += x[i] * (c.lambda * x[i] + bp[i]);
-        for (int k = t; k < d.n_part_lin; k += 64) sc += B.part[d.part0 + 2 * d.n_part_lin + k];
+        for (int k = t; k < d.n_part_pt; k += 64) sc += B.part[d.part0 + 2 * d.n_part_lin + k];
         sc = block_sum<64>(sc, sm);
     }
     if (t != 0) return;

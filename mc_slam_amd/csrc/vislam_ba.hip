@@ -186,6 +186,7 @@ struct Handle {
     std::vector<WinDesc> desc;
     std::vector<WinCtrl> hctrl;
     int n_win = 0;
+    bool any_lin_fallback = false;  // an XYZ window of the batch has a landmark with > 256 observations: k_lin_xyz also runs
     int cur_group = 0; // window group being enqueued (its pinned words)
     int regime_n = 0;  // windows of the uploaded batch: decides WHICH kernels run (few-window / many-window variants), so that
                        // cutting the batch into window groups never changes a summation order
@@ -200,6 +201,7 @@ struct Handle {
     volatile int* stop_host = nullptr;  // pinned, device-visible
     int* stop_dev = nullptr;
     bool profile = false;
+    int opt_lin_fallback = 0;  // test hook: XYZ windows without the edge-parallel work split
     int opt_chunk = 0, opt_lanes = 0;  // > 0: chunk size / lanes of vba_batch_solve (test hook; defaults from VBA_CHUNK, VBA_LANES)
     int opt_streams = 0;  // > 0: window groups / streams for GN batches (test hook; default from VBA_STREAMS, 1)
     std::vector<ProfEvt> evts;
@@ -268,6 +270,7 @@ using vba_host::now_ms;
 int build_structure(Handle* h, const vba_problem* P, Structure& st) {
     std::string err;
     if (vba_host::build_structure(P, st, err)) return fail(h, err);
+    if (h->opt_lin_fallback && P->variant != VBA_VARIANT_PRV_IDP) st.linblk.clear();   // test hook: the thread-per-landmark linearisation
     return 0;
 }
 
@@ -380,6 +383,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->max_offp = 1;
     h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
     h->max_its[0] = h->max_its[1] = 0;
+    h->any_lin_fallback = false;
     // Per chunk of windows: (1) the per-window structure (item lists, IMU lists, symbolic tile factorisation: 0.7 ms for a C3
     // window) on a pool of host threads, (2) descriptors and offsets in window order on this thread, (3) the concatenated
     // arrays grown once, (4) the pool again copies every window's arrays to its offsets (2.2 MB per C3 window).
@@ -470,12 +474,16 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
                 adjbeg.insert(adjbeg.end(), st.adj_begin.begin(), st.adj_begin.end());
                 adj.insert(adj.end(), st.adj.begin(), st.adj.end());
             }
-            d.n_part_lin = (d.n_pt + 63) / 64;
-            if (P->variant == VBA_VARIANT_PRV_IDP) {
+            d.n_part_pt = (d.n_pt + 63) / 64;
+            d.n_part_lin = d.n_part_pt;
+            d.lin_runs = 0;
+            if (!st.linblk.empty()) {   // the work split of the edge-parallel linearisation
                 d.lb0 = (int)(linblk.size() / 4);
                 linblk.insert(linblk.end(), st.linblk.begin(), st.linblk.end());
                 d.n_part_lin = (int)(st.linblk.size() / 4);
-            }
+                d.lin_runs = 1;
+            } else
+                h->any_lin_fallback = true;
             d.S0 = (long long)S_tot;
             for (int i = 0; i < 4; i++) d.K[i] = P->K[i];
             quat_to_R_host(P->T_cb + 3, d.Rcb);
@@ -803,8 +811,10 @@ void enqueue_lin(Handle* h, int mode) {
     if (h->variant == VBA_VARIANT_PRV_IDP) {
         const size_t shm = LIN2_LDS;
         hipLaunchKernelGGL(k_lin2, dim3(h->max_lin_blk, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
-    } else
-        hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
+    } else {
+        hipLaunchKernelGGL(k_lin_xyz_e, dim3(h->max_lin_blk, h->n_win), dim3(256), 0, h->stream, h->B, mode);
+        if (h->any_lin_fallback) hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
+    }
     if (h->max_imu > 0) {   // the IMU factors: a lane per keyframe pair for the Lie-group part, then a wave per pair for J^T Omega J
         hipLaunchKernelGGL(k_lin_imu_res, dim3((h->max_imu + 63) / 64, h->n_win), dim3(64), 0, h->stream, h->B, mode);
         if (mode == LIN_FULL) hipLaunchKernelGGL(k_lin_imu_hess, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B);
@@ -1436,6 +1446,12 @@ int vba_debug_set_streams(void* handle, int32_t n) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
     h->opt_streams = n;
+    return 0;
+}
+int vba_debug_set_lin_fallback(void* handle, int32_t on) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    h->opt_lin_fallback = on;
     return 0;
 }
 int vba_debug_set_chunking(void* handle, int32_t chunk, int32_t lanes) {

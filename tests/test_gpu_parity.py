@@ -290,6 +290,23 @@ def test_fused_imu_factor_hessian_equals_edge_navstate(ba, oracle):
     assert checked == p.n_imu >= 6
 
 
+@pytest.mark.parametrize("variant", [abi.VARIANT_SE3_XYZ, abi.VARIANT_PRV_XYZ])
+def test_xyz_linearisation_fallback_equals_edge_parallel(ba, oracle, variant):
+    """XYZ windows are linearised edge-parallel (k_lin_xyz_e); a window with a track longer than 256 observations falls back to a
+    thread per landmark (k_lin_xyz).  Both must give the oracle's result, and a batch may mix them."""
+    p = synth.make_window(variant, algo=abi.ALGO_LM, n_kf=10, n_fixed=2 if variant == abi.VARIANT_SE3_XYZ else 1, n_pt=300, n_obs=1800, seed=36)
+    q1, r1 = ba.solve(p)
+    try:
+        ba.lib.vba_debug_set_lin_fallback(ba.h, 1)
+        q0, r0 = ba.solve(p)
+    finally:
+        ba.lib.vba_debug_set_lin_fallback(ba.h, 0)
+    qo, ro = oracle.solve(p)
+    _check(p, q1, r1, qo, ro)
+    _check(p, q0, r0, qo, ro)
+    assert r0.its_done == r1.its_done and np.abs(q0.kf_pose - q1.kf_pose).max() < 1e-10 and abs(r0.chi2_vis - r1.chi2_vis) <= 1e-10 * r1.chi2_vis
+
+
 def test_rerun_is_bit_reproducible(ba):
     p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=10, n_fixed=1, n_pt=400, n_obs=2000, seed=7)
     ba.upload([p]); ba.run(); q1, r1 = ba.download()
