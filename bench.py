@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--no-pcg", action="store_true", help="c4 / gba: skip the second run of the batch with the PCG solver")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-steps", type=int, default=4, help="timed vba_batch_solve calls over fresh copies of the batch (0: skip)")
+    ap.add_argument("--gen-procs", type=int, default=None, help="worker processes that generate the synthetic windows (default: up to 16; 1 under a profiler)")
     ap.add_argument("--single-reps", type=int, default=21, help="vba_solve repetitions behind single_window_ms (0: skip)")
     args = ap.parse_args()
     if args.batch is None:
@@ -160,7 +161,14 @@ def main():
     if args.workload != "pose":
         n_distinct = max(1, min(args.distinct, args.batch))
         specs = [(args.workload, shard.window_seed(g), args.uniform) for g in shard.window_ids(n_distinct * world, rank, world)]
+    # under rocprofv3 the profiler's preloaded library has initialised the GPU runtime before main(): forking such a process is
+    # what this pool forbids (children inherit the runtime's locks; an intermittent hang of a PMC pass was traced to it) -> serial
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     n_proc = max(1, min(16, (os.cpu_count() or 1) // max(1, local_world)))
+    if args.gen_procs is not None:
+        n_proc = max(1, args.gen_procs)
+    elif profiled:
+        n_proc = 1
     wins = make_windows(specs, n_proc)
 
     import numpy as np
