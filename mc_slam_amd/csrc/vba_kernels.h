@@ -437,6 +437,20 @@ __global__ void __launch_bounds__(64) k_lin_imu_res(Batch B, int mode) {
     if (k >= d.n_imu) return;
     lin_imu_res(B, d, k, (mode == LIN_FULL) ? LIN_FULL : LIN_ERR);
 }
+// few windows: both steps in one launch, a wave per pair (lane 0 runs the Lie-group part), one launch gap less per pass
+__global__ void __launch_bounds__(64) k_lin_imu_pair(Batch B, int mode) {
+    __shared__ double sm[672];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    if (!lin_imu_gate(d, B.ctrl[w], mode)) return;
+    const int k = blockIdx.x;
+    if (k >= d.n_imu) return;
+    if (threadIdx.x == 0) lin_imu_res(B, d, k, (mode == LIN_FULL) ? LIN_FULL : LIN_ERR);
+    if (mode != LIN_FULL) return;
+    __threadfence_block();
+    __syncthreads();
+    lin_imu_hess(B, d, k, sm);
+}
 __global__ void __launch_bounds__(64) k_lin_imu_hess(Batch B) {
     __shared__ double sm[672];
     const int w = blockIdx.y;

@@ -688,7 +688,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.alive_cnt = h->stop_dev + 64;
     if (dalloc(h, BUF_ALIVE, 14 * 1024 * sizeof(int))) return -1;
     B.alive_dev = dp<int>(h, BUF_ALIVE);
-    B.stop_word = B.alive_dev + 1023;
+    B.stop_word = (n >= 64) ? B.alive_dev + 1023 : h->stop_dev;   // few windows read the pinned word themselves (no poll launches)
     B.out_outlier = dp<unsigned char>(h, BUF_OUTL); B.out_chi2 = dp<double>(h, BUF_OUTCHI);
     if (dalloc(h, BUF_DBG, 4096)) return -1;
     B.dbg = dp<double>(h, BUF_DBG);
@@ -815,7 +815,9 @@ void enqueue_lin(Handle* h, int mode) {
         hipLaunchKernelGGL(k_lin_xyz_e, dim3(h->max_lin_blk, h->n_win), dim3(256), 0, h->stream, h->B, mode);
         if (h->any_lin_fallback) hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
     }
-    if (h->max_imu > 0) {   // the IMU factors: a lane per keyframe pair for the Lie-group part, then a wave per pair for J^T Omega J
+    if (h->max_imu > 0 && h->regime_n < 64) {   // few windows: latency matters, one launch
+        hipLaunchKernelGGL(k_lin_imu_pair, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, mode);
+    } else if (h->max_imu > 0) {   // the IMU factors: a lane per keyframe pair for the Lie-group part, then a wave per pair for J^T Omega J
         hipLaunchKernelGGL(k_lin_imu_res, dim3((h->max_imu + 63) / 64, h->n_win), dim3(64), 0, h->stream, h->B, mode);
         if (mode == LIN_FULL) hipLaunchKernelGGL(k_lin_imu_hess, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B);
     }
@@ -850,7 +852,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
     auto use = [&](const Group& g) { h->B = g.B; h->n_win = g.n_win; h->stream = g.stream; h->cur_group = (int)(&g - &groups[0]); };
     auto stage_begin = [&](Group& g, int stage) {
         ProfScope ps(h, VBA_PROF_MISC);
-        hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+        if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
         hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
         if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
         hipLaunchKernelGGL(k_stage_mark, dim3(h->max_free + (h->max_imu + 63) / 64, g.n_win), dim3(64), 0, g.stream, g.B, h->max_free);
@@ -866,7 +868,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         const int ngrp = (g.n_win >= 8) ? 8 * ((g.n_win + 7) / 8) : g.n_win;
         // H_pp diagonal for computeLambdaInit (the block it writes into S is rewritten by the first trial)
         hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, g.stream, g.B, h->max_free, 1);
-        hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+        if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
         hipLaunchKernelGGL(k_ctrl_lm_outer, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
     };
     auto trial = [&](Group& g, int* alive_dev, int* alive_mirror) {
@@ -878,7 +880,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
         enqueue_lin(h, LIN_ERR_TRIAL);
         {
             ProfScope ps(h, VBA_PROF_CONTROL);
-            hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+            if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
             hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(g.n_win), dim3(64), 0, g.stream, g.B, alive_dev, alive_mirror);
             hipLaunchKernelGGL(k_restore, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
         }
@@ -958,7 +960,7 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
         for (auto& g : groups) {
             use(g);
             ProfScope ps(h, VBA_PROF_MISC);
-            hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+            if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
         hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
             if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
             hipLaunchKernelGGL(k_stage_mark, dim3(h->max_free + (h->max_imu + 63) / 64, g.n_win), dim3(64), 0, g.stream, g.B, h->max_free);
@@ -986,7 +988,7 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
                     enqueue_lin(h, LIN_FULL);
                     {
                         ProfScope ps(h, VBA_PROF_CONTROL);
-                        hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+                        if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
                         hipLaunchKernelGGL(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 0);
                     }
                     if (pace) {
@@ -1070,7 +1072,7 @@ int do_run(Handle* h, const volatile int* stop_flag) {
         groups[g].B.n_win = w1 - w0;
         groups[g].B.alive_cnt = h->stop_dev + 64 + 64 * g;
         groups[g].B.alive_dev = dp<int>(h, BUF_ALIVE) + 1024 * g;
-        groups[g].B.stop_word = groups[g].B.alive_dev + 1023;
+        groups[g].B.stop_word = (h->regime_n >= 64) ? groups[g].B.alive_dev + 1023 : h->stop_dev;
         groups[g].n_win = w1 - w0;
         groups[g].stream = (g == 0) ? h->stream : h->xstreams[g - 1];
         groups[g].alive = h->stop_host + 64 + 64 * g;
