@@ -1436,7 +1436,15 @@ int vba_oracle_solve(vba_problem *P, vba_result *out, const volatile int *stop, 
 /* ---- test hooks: one linearisation of the whole problem, dense, for cross-checks against numpy ---- */
 /* Fills H (full (np+nl)^2 dense, row-major), b, and the Schur solution x for the problem's CURRENT state,
  * all edges level 0, Huber as in stage 1.  Returns np+nl (or <0). */
+int vba_oracle_linearize_ex(vba_problem *P, double lambda, int robust_vis, const uint8_t *lvl, double *Hfull, double *bfull,
+                            double *xschur, double *chi2);
 int vba_oracle_linearize(vba_problem *P, double lambda, double *Hfull, double *bfull, double *xschur, double *chi2) {
+    return vba_oracle_linearize_ex(P, lambda, 1, NULL, Hfull, bfull, xschur, chi2);
+}
+/* the same with the stage's settings spelled out: Huber on the vision edges or not, and the g2o level of every vision edge
+ * (NULL: all at level 0) -- lets tests/test_oracle_protocol.py drive the two-stage protocol from Python */
+int vba_oracle_linearize_ex(vba_problem *P, double lambda, int robust_vis, const uint8_t *lvl, double *Hfull, double *bfull,
+                            double *xschur, double *chi2) {
     vba_result dummy;
     memset(&dummy, 0, sizeof dummy);
     ctx C, *c = &C;
@@ -1474,7 +1482,8 @@ int vba_oracle_linearize(vba_problem *P, double lambda, double *Hfull, double *b
     c->Lwork = xcalloc((size_t)c->np * c->np, 8);
     c->ywork = xcalloc(c->np, 8);
     for (int i = 0; i < c->np; i++) c->perm[i] = i;
-    c->vis_robust = 1;
+    c->vis_robust = robust_vis;
+    if (lvl) memcpy(c->lvl, lvl, c->nobs);
     init_active(c);
     *chi2 = compute_errors(c);
     build_system(c);

@@ -74,6 +74,22 @@ def linearize(prob: abi.Problem, lam=0.0, want_H=True):
     return rc, H, b, x, chi.value
 
 
+def linearize_ex(prob: abi.Problem, robust_vis=True, lvl=None, lam=0.0):
+    """Dense H, b and the active robust chi2 at prob's current state, with the stage's settings spelled out: Huber on the vision
+    edges or not, g2o level per vision edge (None: all 0).  Returns (H, b, chi2)."""
+    pdim = 6 if prob.variant == abi.VARIANT_SE3_XYZ else 15
+    ldim = 1 if prob.variant == abi.VARIANT_PRV_IDP else 3
+    n = pdim * prob.n_kf_free + ldim * prob.n_pt
+    H = np.zeros((n, n)); b = np.zeros(n); chi = C.c_double(0)
+    lv = None if lvl is None else np.ascontiguousarray(lvl, dtype=np.uint8)
+    s = prob.as_struct()
+    f = lib().vba_oracle_linearize_ex
+    f.restype = C.c_int
+    f(C.byref(s), C.c_double(lam), C.c_int(1 if robust_vis else 0), None if lv is None else lv.ctypes.data_as(C.POINTER(C.c_uint8)),
+      P(H), P(b), None, C.cast(C.pointer(chi), _pd))
+    return H, b, chi.value
+
+
 # ---- unit-level hooks -------------------------------------------------------------------------
 def _v(n):
     return np.zeros(n, dtype=np.float64)
