@@ -21,16 +21,17 @@ def ba():
     b.close()
 
 
-def _check(p, q, r, qo, ro, tight=True, trace_rtol=1e-7):
+def _check(p, q, r, qo, ro, tight=True, trace_rtol=1e-7, state_scale=1.0):
+    """state_scale loosens the bars on the STATES only, for windows whose system is numerically singular (see test_gpu_stress)"""
     assert r.status == ro.status
     assert r.its_done == ro.its_done, (r.its_done, ro.its_done, r.chi2_trace, ro.chi2_trace)
     assert abs(r.chi2_vis - ro.chi2_vis) <= CHI2_RTOL * max(ro.chi2_vis, 1e-12)
     assert abs(r.chi2_prv - ro.chi2_prv) <= CHI2_RTOL * max(ro.chi2_prv, 1e-9)
     assert abs(r.chi2_bias - ro.chi2_bias) <= CHI2_RTOL * max(ro.chi2_bias, 1e-9)
-    assert np.abs(q.kf_pose[:, :3] - qo.kf_pose[:, :3]).max() <= TRANS_ATOL
-    assert np.abs(q.kf_pose[:, 3:] - qo.kf_pose[:, 3:]).max() <= 1e-6
-    assert np.abs(q.kf_vel - qo.kf_vel).max() <= 1e-5
-    assert np.abs(q.pt - qo.pt).max() <= 1e-6 * max(1.0, np.abs(qo.pt).max())
+    assert np.abs(q.kf_pose[:, :3] - qo.kf_pose[:, :3]).max() <= TRANS_ATOL * state_scale
+    assert np.abs(q.kf_pose[:, 3:] - qo.kf_pose[:, 3:]).max() <= 1e-6 * state_scale
+    assert np.abs(q.kf_vel - qo.kf_vel).max() <= 1e-5 * state_scale
+    assert np.abs(q.pt - qo.pt).max() <= 1e-6 * state_scale * max(1.0, np.abs(qo.pt).max())
     assert (r.obs_outlier == ro.obs_outlier).all()
     np.testing.assert_allclose(r.chi2_trace, ro.chi2_trace, rtol=trace_rtol)
     np.testing.assert_allclose(r.obs_chi2, ro.obs_chi2, rtol=max(1e-5, 100 * trace_rtol), atol=1e-7)

@@ -47,7 +47,12 @@ def test_random_window_matches_oracle(ba, oracle, i):
     qo, ro = oracle.solve(p)
     # the north-star bars as in test_gpu_parity; the chi2 TRACE only to 1e-5: on a slowly converging (ill-conditioned) LM
     # window of the long hunt (i = 63, SE3, 14 iterations) the summation order shows at 1.9e-7 relative
-    _check(p, q, r, qo, ro, trace_rtol=1e-5)
+    # Windows with fewer than six landmarks per keyframe are under-constrained: at i = 63 (26 keyframes, 94 landmarks) the final
+    # system has cond(H) = 2e20 and only the LM damping makes it solvable; a float64 LAPACK twin of the same protocol
+    # (tests/test_oracle_protocol.py) then differs from the oracle by 6e-7 m in the translations, 2e-6 in the landmarks and 1e-5
+    # relative in lambda -- the arithmetic's noise floor.  Iteration counts, the outlier bitmap and chi2 keep their bars there;
+    # the states get ten times the bar.
+    _check(p, q, r, qo, ro, trace_rtol=1e-5, state_scale=10.0 if p.n_pt < 6 * p.n_kf else 1.0)
 
 
 def test_random_windows_in_one_ragged_batch(ba):
