@@ -798,6 +798,7 @@ DEVI void schur_write_block(const Batch& B, const WinDesc& d, const WinCtrl& c, 
     // sub-blocks that no tile of the factor ever reads (structurally zero in L under the V/Bias-first order) are
     // not written at all: bit0 PRxPR, bit1 PRxVB, bit2 VBxPR, bit3 VBxVB (mask built with the tile lists at upload)
     const int mask = B.pair_mask[d.pair0 + pr];
+    if (mask == 0) return;   // nothing of this block is ever read (or it keeps the zero of the upload)
     if (mask == 1 && !diag && qb == qe) {  // only the 6x6 PR x PR sub-block lands in a tile the factor reads, no IMU term
         for (int q = t; q < 36; q += nt) {
             const int r = q / 6, col = q % 6;
@@ -965,10 +966,11 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
             }
         }
     }
-    // fixed-order butterfly inside each LP-lane group
+    // fixed-order sums inside each LP-lane group (skipped when no pair of the wave has an item: most keyframe pairs of a window
+    // share no landmark, and in distance order they fill whole waves)
+    if (__ballot(ib < ie) != 0ull) {
 #pragma unroll
-    for (int i = 0; i < 36; i++) {
-        acc[i] = (LP == 16) ? row16_sum(acc[i]) : wave64_sum(acc[i]);
+        for (int i = 0; i < 36; i++) acc[i] = (LP == 16) ? row16_sum(acc[i]) : wave64_sum(acc[i]);
     }
     double* blk = blk4 + g * 36;
     if (l16 == 0) {

@@ -583,9 +583,13 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             put(pair_a.data() + d.pair0, st.pair_a.data(), d.n_pairs);
             put(pair_b.data() + d.pair0, st.pair_b.data(), d.n_pairs);
             put(offpair.data() + d.pair0, st.off_pair.data(), d.n_pairs);
-            if (pristine)   // S stays pristine: a sub-block nothing is ever added to keeps the zero of the upload
-                for (int pi = 0; pi < d.n_pairs; pi++)
-                    if (st.pair_a[pi] != st.pair_b[pi] && st.pimu_begin[pi + 1] == st.pimu_begin[pi]) st.pair_mask[pi] &= 1;
+            for (int pi = 0; pi < d.n_pairs; pi++) {
+                const bool has_items = (st.pair_mask[pi] & 16) != 0;
+                st.pair_mask[pi] &= 15;
+                // S stays pristine: a sub-block nothing is ever added to keeps the zero of the upload -- without an IMU edge only
+                // the 6x6 PR block of a pair is ever written, and a pair without shared landmarks is not written at all
+                if (pristine && st.pair_a[pi] != st.pair_b[pi] && st.pimu_begin[pi + 1] == st.pimu_begin[pi]) st.pair_mask[pi] &= has_items ? 1 : 0;
+            }
             put(pairmask.data() + d.pair0, st.pair_mask.data(), d.n_pairs);
             put(pimu_begin.data() + d.pair0 + w, st.pimu_begin.data(), (size_t)d.n_pairs + 1);
             put(pimu.data() + 2 * (size_t)d.pimu0, st.pimu.data(), st.pimu.size());
