@@ -37,6 +37,7 @@ struct Batch {
     double *S, *vec, *bpose;
     double *Lf, *yv;  // factor tiles and forward-substituted rhs (written out of place: S tiles are read by
                       // other workgroups of the same launch)
+    int l_packed;     // Lf holds the factor tile by tile in MFMA operand order (left-looking kernels, ll_pk) instead of row-major
     int* var_act;
     // structure (g2o buildStructure analogue, built on the host at upload)
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
@@ -1490,76 +1491,45 @@ __global__ void __launch_bounds__(64) k_chol_update(Batch B, int k) {
 //                   needs no serial triangular solve)
 //   panel tile    : C_IJ, then L_IJ = C_IJ W_J as one more MFMA product.
 // ------------------------------------------------------------------------------------------------
-// PF: register double buffer -- the tiles of step e+1 are in flight while the MFMAs of step e run.  It pays for the
-// diagonal tile (one wave per window: the launch is latency-bound and the extra registers cost nothing) and not for the
-// panel tiles (many waves per window: 171 instead of 118 VGPRs drop the occupancy from 3 to 2 waves per SIMD).
-template <bool PF>
-DEVI void ll_accumulate(const Batch& B, const WinDesc& d, int I, int J, int kb, int ke, double* XI, double* XJ, double* ys,
-                        d4_t (&acc)[2][2], double* rhs_dot) {
-    __shared__ double dgs[32];
+// In this mode the factor is stored TILE BY TILE -- tile (I,J) at 1024 (I nb + J) doubles -- in the order the MFMA operand
+// registers want it: element (r, c) of a tile belongs to lane (c & 3) * 16 + (r & 15), the lane's 16 elements being the two row
+// halves x eight k-steps of v_mfma_f64_16x16x4 (operand A[row][k]: row = lane & 15, k = 4 ks + (lane >> 4)), two k-steps per 16-byte
+// piece.  A panel wave then loads both operand tiles of a product with 8 + 8 fully coalesced global_load_dwordx4 straight into
+// the registers the MFMAs read: no LDS, no barrier, and the occupancy is set by the registers alone.
+DEVI int ll_pk(int r, int c) { return (((((r >> 4) * 4 + (c >> 3)) * 64) + ((c & 3) * 16 + (r & 15))) * 2) + ((c >> 2) & 1); }
+DEVI size_t ll_tile(const WinDesc& d, int I, int J) { return 1024 * ((size_t)I * d.nb + J); }
+
+// diagonal tile of block column J: C_JJ = S_JJ - sum_k L_Jk D_k L_Jk^T and the dot products L_Jk y_k for the forward substitution.
+// Both MFMA operands are the one packed tile L_Jk (A = -L_Jk, B = L_Jk D_k), loaded straight into registers.
+DEVI void ll_diag_accumulate(const Batch& B, const WinDesc& d, int J, int kb, int ke, d4_t (&acc)[2][2], double& sdot_out) {
     const int lane = threadIdx.x, n = d.nS;
     const double* S = B.S + d.S0;
     const double* Lf = B.Lf + d.S0;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int row = lane >> 1, c0 = (lane & 1) * 16;  // staging: 16 consecutive doubles of one tile row per lane
 #pragma unroll
     for (int ti = 0; ti < 2; ti++)
 #pragma unroll
         for (int tj = 0; tj < 2; tj++) {
-            const double* C = S + ((size_t)I * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
+            const double* C = S + ((size_t)J * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[ti][tj][i] = C[(size_t)(l4 + 4 * i) * n + l15];
         }
     const int* kl = B.tl_kl + d.tl_k0;
-    double sdot = 0.0;
-    double pi[PF ? 16 : 1], pj[PF ? 16 : 1], pd[PF ? 16 : 1], py = 0.0;
-    if (PF && kb < ke) {
-        const size_t dk = (size_t)kl[kb] * 32;
-        const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
-        const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
-        const double* sd = B.dvec + d.vec0 + dk + c0;
-#pragma unroll
-        for (int q = 0; q < (PF ? 16 : 1); q++) { pi[q] = si[q]; pj[q] = sj[q]; pd[q] = sd[q]; }
-        if (rhs_dot && lane < 32) py = B.yv[d.vec0 + dk + lane];
-    }
+    double p0 = 0.0, p1 = 0.0;   // this lane's share of (L_Jk y_k) for rows l15 and 16 + l15: columns 4 ks + l4
     for (int e = kb; e < ke; e++) {
-        __syncthreads();  // the previous step's MFMAs are done with XI / XJ
-        if (PF) {
+        const int k = kl[e];
+        const double2* t = reinterpret_cast<const double2*>(Lf + ll_tile(d, J, k)) + lane;
+        const double* sd = B.dvec + d.vec0 + (size_t)k * 32 + l4;
+        const double* sy = B.yv + d.vec0 + (size_t)k * 32 + l4;
+        double2 x[8];
+        double dv[8], yk[8];
 #pragma unroll
-            for (int q = 0; q < (PF ? 16 : 1); q++) {
-                XI[row * 34 + c0 + q] = pi[q];
-                XJ[row * 34 + c0 + q] = pj[q] * pd[q];
-            }
-            if (rhs_dot && lane < 32) ys[lane] = py;
-            __syncthreads();
-            if (e + 1 < ke) {
-                const size_t dk = (size_t)kl[e + 1] * 32;
-                const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
-                const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
-                const double* sd = B.dvec + d.vec0 + dk + c0;
+        for (int q = 0; q < 8; q++) { x[q] = t[64 * q]; dv[q] = sd[4 * q]; yk[q] = sy[4 * q]; }
 #pragma unroll
-                for (int q = 0; q < (PF ? 16 : 1); q++) { pi[q] = si[q]; pj[q] = sj[q]; pd[q] = sd[q]; }
-                if (rhs_dot && lane < 32) py = B.yv[d.vec0 + dk + lane];
-            }
-        } else {
-            const size_t dk = (size_t)kl[e] * 32;
-            if (lane < 32) {   // D_k (and y_k) once per wave through LDS, not 16 doubles per lane from memory
-                dgs[lane] = B.dvec[d.vec0 + dk + lane];
-                if (rhs_dot) ys[lane] = B.yv[d.vec0 + dk + lane];
-            }
-            __syncthreads();
-            const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
-            const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                XI[row * 34 + c0 + q] = si[q];
-                XJ[row * 34 + c0 + q] = sj[q] * dgs[c0 + q];
-            }
-            __syncthreads();
-        }
-        if (rhs_dot && lane < 32) {
-#pragma unroll
-            for (int q = 0; q < 32; q++) sdot += XI[lane * 34 + q] * ys[q];
+        for (int ks = 0; ks < 8; ks++) {
+            const double2 a0 = x[ks >> 1], a1 = x[4 + (ks >> 1)];
+            p0 += ((ks & 1) ? a0.y : a0.x) * yk[ks];
+            p1 += ((ks & 1) ? a1.y : a1.x) * yk[ks];
         }
 #pragma unroll
         for (int ti = 0; ti < 2; ti++)
@@ -1567,28 +1537,29 @@ DEVI void ll_accumulate(const Batch& B, const WinDesc& d, int I, int J, int kb, 
             for (int tj = 0; tj < 2; tj++) {
 #pragma unroll
                 for (int ks = 0; ks < 8; ks++) {
-                    const double av = -XI[(16 * ti + l15) * 34 + 4 * ks + l4];
-                    const double bv = XJ[(16 * tj + l15) * 34 + 4 * ks + l4];
+                    const double2 pi = x[ti * 4 + (ks >> 1)], pj = x[tj * 4 + (ks >> 1)];
+                    const double av = -((ks & 1) ? pi.y : pi.x);
+                    const double bv = ((ks & 1) ? pj.y : pj.x) * dv[ks];
                     acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[ti][tj], 0, 0, 0);
                 }
             }
     }
-    if (rhs_dot) *rhs_dot = sdot;
-    __syncthreads();
+    p0 += __shfl_xor(p0, 16, 64); p0 += __shfl_xor(p0, 32, 64);
+    p1 += __shfl_xor(p1, 16, 64); p1 += __shfl_xor(p1, 32, 64);
+    sdot_out = (lane & 16) ? p1 : p0;   // lane r < 32 holds the sum of row r (lanes 32..63 mirror them)
 }
 
-// diagonal tile of block column J: C_JJ, its L D L^T, y_J, D_J and W_J = L_JJ^-T D_J^-1
-DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, double* XI, double* XJ, double* ys, double* rd) {
+// diagonal tile of block column J: C_JJ, its L D L^T, y_J, D_J and W_J = (L_JJ^-T D_J^-1)^T (packed like a factor tile)
+DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, double* CT, double* rd) {
     const int* pb = B.tl_pan_begin + d.tl_step0;
     const int* klb = B.tl_kl_begin + d.tl_kb0;
     const int ent = pb[J] + J;  // column entry of (J,J)
-    const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5, n = d.nS;
+    const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
     const int l15 = lane & 15, l4 = lane >> 4;
     d4_t acc[2][2];
     double sdot = 0.0;
-    ll_accumulate<true>(B, d, J, J, klb[ent], klb[ent + 1], XI, XJ, ys, acc, &sdot);
+    ll_diag_accumulate(B, d, J, klb[ent], klb[ent + 1], acc, sdot);
     // C_JJ through LDS into one row per lane
-    double* CT = XI;
 #pragma unroll
     for (int ti = 0; ti < 2; ti++)
 #pragma unroll
@@ -1602,18 +1573,17 @@ DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, do
     double rdiag;
     bool bad;
     ldl32_regs(a, r, rdiag, bad);
-    double* Lf = B.Lf + d.S0;
+    double* Ljj = B.Lf + d.S0 + ll_tile(d, J, J);
     const size_t dk = (size_t)J * 32;
-    double* Lk = XJ;  // 32 x 33
+    double* Lk = CT;  // 32 x 33, over the tile every lane has taken its row of
     __syncthreads();
     if (hi == 0) {
 #pragma unroll
         for (int q = 0; q < 32; q++) Lk[r * 33 + q] = (q <= r) ? a[q] : 0.0;
         rd[r] = rdiag;
-        double* lrow = Lf + (dk + r) * n + dk;
 #pragma unroll
         for (int q = 0; q < 32; q++)
-            if (q <= r) lrow[q] = a[q];
+            if (q <= r) Ljj[ll_pk(r, q)] = a[q];
         double dr = 0.0;  // a[r] without a dynamic register index
 #pragma unroll
         for (int q = 0; q < 32; q++) dr = (q == r) ? a[q] : dr;
@@ -1622,7 +1592,7 @@ DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, do
     if (lane == 0 && bad) c.chol_fail = 1;
     __syncthreads();
     // y_J = L_JJ^-1 (b_J - sum_k L_Jk y_k)
-    double zr = (B.vec + d.vec0)[dk + r] - __shfl(sdot, r, 64);  // sdot lives in lanes 0..31; lanes 32..63 mirror them
+    double zr = (B.vec + d.vec0)[dk + r] - __shfl(sdot, r, 64);
 #pragma unroll
     for (int q = 0; q < 32; q++) {
         const double zq = rl64(zr, q);
@@ -1630,7 +1600,7 @@ DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, do
     }
     if (hi == 0) (B.yv + d.vec0)[dk + r] = zr;
     // Z = L_JJ^-1 (unit lower) by columns: the two halves of the wave share a column, rows split even / odd is not
-    // possible (each row needs all earlier ones), so lanes 0..31 own one column each; W[j][k] = Z[j][k] / d_j, row-major
+    // possible (each row needs all earlier ones), so lanes 0..31 own one column each; W[j][k] = Z[j][k] / d_j
     if (hi == 0) {
         double z[32];
 #pragma unroll
@@ -1642,77 +1612,120 @@ DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, do
         }
         double* W = B.winv + 1024 * (size_t)d.win;  // d.win: the batch-wide window index (w is relative to the window group)
 #pragma unroll
-        for (int j = 0; j < 32; j++) W[j * 32 + r] = z[j] * rd[j];
+        for (int j = 0; j < 32; j++) W[ll_pk(j, r)] = z[j] * rd[j];
     }
 }
 
 // (A fused variant -- the wave that owns tile (J+1,J) going on to factor diagonal tile J+1 -- was measured: no gain at 512
 // windows)
 __global__ void __launch_bounds__(64) k_chol_diag_ll(Batch B, int J) {
-    __shared__ double XI[32 * 34];
-    __shared__ double XJ[32 * 34];
-    __shared__ double ys[32], rd[32];
+    __shared__ double CT[32 * 34];
+    __shared__ double rd[32];
     const int w = blockIdx.x;
     if (w >= B.n_win) return;
     const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
     if (!win_on(d, c)) return;
     if (J >= d.nb) return;
-    ll_diag(B, d, c, w, J, XI, XJ, ys, rd);
+    ll_diag(B, d, c, w, J, CT, rd);
 }
 
-__global__ void __launch_bounds__(64) k_chol_panel_ll(Batch B, int J) {
-    __shared__ double XI[32 * 34];
-    __shared__ double XJ[32 * 34];
-    __shared__ double ys[32];
-    const int w = blockIdx.y;
+// panel tile (I,J): C_IJ = S_IJ - sum_k L_Ik D_k L_Jk^T, then L_IJ = C_IJ W_J.  The wave accumulates the TRANSPOSED tile
+// (A operand = L_Jk D_k, B operand = -L_Ik: the same products in the same order as the row-major form, so the same bits): the
+// accumulator registers of C^T are then exactly the B operand of L_IJ^T = W_J^T C_IJ^T, and that product's result registers are
+// exactly the packed order of tile (I,J) -- nothing passes through LDS.
+DEVI void ll_panel_init(const double* S, int n, int I, int J, int l15, int l4, d4_t (&acc)[2][2]) {
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++) {
+            const double* C = S + ((size_t)I * 32 + 16 * ti + l15) * n + (size_t)J * 32 + 16 * tj + l4;
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[tj][ti][i] = C[4 * i];   // acc[tj][ti][i] = C[32 I + 16 ti + l15][32 J + 16 tj + 4 i + l4]
+        }
+}
+DEVI void ll_panel_mfma(const double (&av)[2][8], const double2 (&xi)[8], d4_t (&acc)[2][2]) {
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                const double2 pi = xi[ti * 4 + (ks >> 1)];
+                const double bv = -((ks & 1) ? pi.y : pi.x);
+                acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tj][ks], bv, acc[tj][ti], 0, 0, 0);
+            }
+        }
+}
+// L_IJ^T = W_J^T C_IJ^T: A operand = the packed W tile, B operand = the accumulators; the result registers are the packed tile
+DEVI void ll_panel_finish(const double2 (&xw)[8], const d4_t (&acc)[2][2], double2* out) {
+#pragma unroll
+    for (int tk = 0; tk < 2; tk++)
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++) {
+            d4_t o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                const double2 pw = xw[tk * 4 + (ks >> 1)];
+                const double av = (ks & 1) ? pw.y : pw.x;
+                const double bv = acc[ks >> 2][ti][ks & 3];
+                o = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, o, 0, 0, 0);
+            }
+            // o[i] = L[16 ti + l15][16 tk + 4 i + l4]: k-steps 4 tk + i of row half ti
+            out[64 * (ti * 4 + 2 * tk)] = make_double2(o[0], o[1]);
+            out[64 * (ti * 4 + 2 * tk + 1)] = make_double2(o[2], o[3]);
+        }
+}
+
+// One wave per tile.  (Measured and not kept, all within +-3 % of this form at 4096 windows: two tiles of the column per wave sharing
+// L_Jk D_k and W_J -- a quarter less traffic; one 32-byte record per tile instead of the chain column row -> panel entry -> list
+// bounds -> list; a register double buffer for the next product's tiles; 2, 3 or 4 waves per SIMD.  See DESIGN.md section 6.)
+__global__ void __launch_bounds__(64) k_chol_panel_ll(Batch B, int J, int per_win) {
+    // the waves of one window sit on one XCD (schur_map)
+    int w, bx;
+    if (!schur_map(B, per_win, w, bx)) return;
     const WinDesc& d = B.desc[w];
     if (!win_on(d, B.ctrl[w])) return;
     if (J >= d.nb) return;
     const int* pb = B.tl_pan_begin + d.tl_step0;
     const int* pan = B.tl_pan + d.tl_pan0;
     const int npan = pb[J + 1] - pb[J];
-    const int bx = blockIdx.x;
     if (bx >= npan) return;
     const int I = pan[pb[J] + bx];
     const int* klb = B.tl_kl_begin + d.tl_kb0;
     const int ent = pb[J] + J + 1 + bx;
     const int lane = threadIdx.x, n = d.nS;
     const int l15 = lane & 15, l4 = lane >> 4;
+    const double* S = B.S + d.S0;
+    double* Lf = B.Lf + d.S0;
     d4_t acc[2][2];
-    ll_accumulate<false>(B, d, I, J, klb[ent], klb[ent + 1], XI, XJ, ys, acc, nullptr);
-    // L_IJ = C_IJ W_J
-    double* CT = XI;
-    double* WT = XJ;
+    ll_panel_init(S, n, I, J, l15, l4, acc);
+    const int* kl = B.tl_kl + d.tl_k0;
+    const int kb = klb[ent], ke = klb[ent + 1];
+    for (int e = kb; e < ke; e++) {
+        const int k = kl[e];
+        const double2* tj_ = reinterpret_cast<const double2*>(Lf + ll_tile(d, J, k)) + lane;
+        const double2* ti_ = reinterpret_cast<const double2*>(Lf + ll_tile(d, I, k)) + lane;
+        const double* sd = B.dvec + d.vec0 + (size_t)k * 32 + l4;
+        double2 xj[8], xi[8];
+        double dv[8];
 #pragma unroll
-    for (int ti = 0; ti < 2; ti++)
+        for (int q = 0; q < 8; q++) { xj[q] = tj_[64 * q]; xi[q] = ti_[64 * q]; dv[q] = sd[4 * q]; }
+        double av[2][8];
 #pragma unroll
         for (int tj = 0; tj < 2; tj++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) CT[(16 * ti + l4 + 4 * i) * 34 + 16 * tj + l15] = acc[ti][tj][i];
-    {
-        const int row = lane >> 1, c0 = (lane & 1) * 16;
-        const double* sw = B.winv + 1024 * (size_t)d.win + row * 32 + c0;
-#pragma unroll
-        for (int q = 0; q < 16; q++) WT[row * 34 + c0 + q] = sw[q];
-    }
-    __syncthreads();
-    double* Lf = B.Lf + d.S0;
-#pragma unroll
-    for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
-            d4_t o = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
             for (int ks = 0; ks < 8; ks++) {
-                const double av = CT[(16 * ti + l15) * 34 + 4 * ks + l4];
-                const double bv = WT[(16 * tj + l15) * 34 + 4 * ks + l4];
-                o = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, o, 0, 0, 0);
+                const double2 pj = xj[tj * 4 + (ks >> 1)];
+                av[tj][ks] = ((ks & 1) ? pj.y : pj.x) * dv[ks];
             }
-            double* C = Lf + ((size_t)I * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
+        ll_panel_mfma(av, xi, acc);
+    }
+    const double2* tw = reinterpret_cast<const double2*>(B.winv + 1024 * (size_t)d.win) + lane;
+    double2 xw[8];
 #pragma unroll
-            for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = o[i];
-        }
+    for (int q = 0; q < 8; q++) xw[q] = tw[64 * q];
+    ll_panel_finish(xw, acc, reinterpret_cast<double2*>(Lf + ll_tile(d, I, J)) + lane);
 }
 
 // K_trsv: L^T x = y.  One 256-thread workgroup per window walks the block columns from the bottom: the
@@ -1727,43 +1740,84 @@ __global__ void __launch_bounds__(256) k_trsv(Batch B) {
     double* part = xs + n;
     double* Lt = part + 256;
     const double* S = B.Lf + d.S0;
+    const bool pk = B.l_packed;   // left-looking mode: the factor is stored tile by tile (ll_pk)
     double* vec = B.vec + d.vec0;
     const double* yv = B.yv + d.vec0;
     const int* pb = B.tl_pan_begin + d.tl_step0;
     const int* pan = B.tl_pan + d.tl_pan0;
     for (int q = t; q < n; q += 256) xs[q] = yv[q];
+    for (int q = t; q < 256; q += 256) part[q] = 0.0;
     __syncthreads();
-    // the column's panel tiles are dealt to the four waves; a lane takes 16 rows of a tile, so its 16 loads are in flight
+    // the column's panel tiles are dealt to the four waves; a lane takes 16 elements of a tile, so its loads are in flight
     // together and a column with m tiles costs ceil(m / 4) memory round trips, not m
     const int cc = t & 31, rl = t >> 5, wave = t >> 6, half = (t >> 5) & 1;
-    // the diagonal tile of the next block column is fetched while this one is solved
+    const int lane = t & 63, l15 = lane & 15, l4 = lane >> 4;
+    // the diagonal tile of the next block column is fetched while this one is solved; element u of a thread sits at (dr[u], dc[u])
     double nx[4];
-    {
-        const size_t dk = (size_t)(d.nb - 1) * 32;
+    int dpos[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int q = t + 256 * u; nx[u] = S[(dk + (q >> 5)) * n + dk + (q & 31)]; }
+    for (int u = 0; u < 4; u++) {
+        const int q = t + 256 * u;   // row-major: element (q >> 5, q & 31); packed: piece q >> 1 of lane (q >> 1) & 63, half q & 1
+        const int pr = 16 * (q >> 9) + ((q >> 1) & 15), pc = 8 * ((q >> 7) & 3) + 4 * (q & 1) + ((q >> 5) & 3);
+        dpos[u] = pk ? pr * 33 + pc : (q >> 5) * 33 + (q & 31);
     }
+    auto diag_fetch = [&](int k) {
+        if (pk) {
+            const double* tdk = S + ll_tile(d, k, k);
+#pragma unroll
+            for (int u = 0; u < 4; u++) nx[u] = tdk[t + 256 * u];
+        } else {
+            const size_t dk = (size_t)k * 32;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int q = t + 256 * u; nx[u] = S[(dk + (q >> 5)) * n + dk + (q & 31)]; }
+        }
+    };
+    diag_fetch(d.nb - 1);
     for (int k = d.nb - 1; k >= 0; k--) {
         const size_t dk = (size_t)k * 32;
-        double s = 0.0;
         const int i0 = pb[k], m = pb[k + 1] - i0;
-        for (int i = wave; i < m; i += 4) {
-            const int I = pan[i0 + i];
-            const int r0 = I * 32 + half * 16;
-            double lv[16];
+        if (pk) {
+            // a wave per tile: 8 coalesced 16-byte loads per lane; the lane's 16 elements are rows l15 and 16 + l15 of the
+            // columns 4 ks + l4 -- eight column sums per lane, reduced over the 16 lanes of a DPP row at the end
+            double cs[8];
 #pragma unroll
-            for (int rr = 0; rr < 16; rr++) lv[rr] = S[(size_t)(r0 + rr) * n + dk + cc];
+            for (int q = 0; q < 8; q++) cs[q] = 0.0;
+            for (int i = wave; i < m; i += 4) {
+                const int I = pan[i0 + i];
+                const double2* tp = reinterpret_cast<const double2*>(S + ll_tile(d, I, k)) + lane;
+                double2 lv[8];
 #pragma unroll
-            for (int rr = 0; rr < 16; rr++) s += lv[rr] * xs[r0 + rr];
+                for (int q = 0; q < 8; q++) lv[q] = tp[64 * q];
+                const double x0 = xs[I * 32 + l15], x1 = xs[I * 32 + 16 + l15];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    cs[2 * j] += lv[j].x * x0;
+                    cs[2 * j + 1] += lv[j].y * x0;
+                    cs[2 * j] += lv[4 + j].x * x1;
+                    cs[2 * j + 1] += lv[4 + j].y * x1;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const double v = row16_sum(cs[q]);
+                if (l15 == 0) part[wave * 32 + 4 * q + l4] = v;
+            }
+        } else {
+            double s = 0.0;
+            for (int i = wave; i < m; i += 4) {
+                const int I = pan[i0 + i];
+                const int r0 = I * 32 + half * 16;
+                double lv[16];
+#pragma unroll
+                for (int rr = 0; rr < 16; rr++) lv[rr] = S[(size_t)(r0 + rr) * n + dk + cc];
+#pragma unroll
+                for (int rr = 0; rr < 16; rr++) s += lv[rr] * xs[r0 + rr];
+            }
+            part[rl * 32 + cc] = s;
         }
-        part[rl * 32 + cc] = s;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int q = t + 256 * u; Lt[(q >> 5) * 33 + (q & 31)] = nx[u]; }
-        if (k > 0) {
-            const size_t dn = dk - 32;
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int q = t + 256 * u; nx[u] = S[(dn + (q >> 5)) * n + dn + (q & 31)]; }
-        }
+        for (int u = 0; u < 4; u++) Lt[dpos[u]] = nx[u];
+        if (k > 0) diag_fetch(k - 1);
         __syncthreads();
         if (t < 64) {
             const int c = t & 31;

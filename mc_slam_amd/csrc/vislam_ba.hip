@@ -673,6 +673,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     B.imuH = dp<double>(h, BUF_IMUH); B.imu_chi = dp<double>(h, BUF_IMUCHI); B.imu_jrec = dp<double>(h, BUF_IMUJREC);
     B.S = dp<double>(h, BUF_S); B.vec = dp<double>(h, BUF_VEC); B.bpose = dp<double>(h, BUF_BPOSE);
     B.Lf = dp<double>(h, BUF_LF); B.yv = dp<double>(h, BUF_YV);
+    B.l_packed = h->ll_mode ? 1 : 0;
     B.tl_step_begin = dp<int>(h, BUF_TLSTEP); B.tl_pairs = dp<int>(h, BUF_TLPAIR);
     B.tl_pan_begin = dp<int>(h, BUF_TLPANB); B.tl_pan = dp<int>(h, BUF_TLPAN);
     B.tl_kl_begin = dp<int>(h, BUF_TLKB); B.tl_kl = dp<int>(h, BUF_TLK);
@@ -733,9 +734,9 @@ void enqueue_solve_iteration(Handle* h) {
     const int n = h->n_win;         // windows of this group: grid sizes
     const int rn = h->regime_n;     // windows of the batch: kernel choice
     const bool idp = h->variant == VBA_VARIANT_PRV_IDP;
+    const int ngrp = (n >= 8) ? 8 * ((n + 7) / 8) : n;   // grids whose workgroups schur_map() deals to the XCDs by window
     {
         ProfScope ps(h, VBA_PROF_SCHUR);
-        const int ngrp = (n >= 8) ? 8 * ((n + 7) / 8) : n;
         if (idp) {
             static const int fused_schur = getenv("VBA_SCHUR_SPLIT") ? 0 : 1;
             if (rn >= 8 && fused_schur) {
@@ -785,7 +786,7 @@ void enqueue_solve_iteration(Handle* h) {
         if (rn >= split_min || ll) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
             for (int k = 0; k < h->max_nb && ll; k++) {  // every tile read once, updated in registers, written once
                 hipLaunchKernelGGL(k_chol_diag_ll, dim3(n), dim3(64), 0, h->stream, B, k);
-                if (h->pan_grid[k] > 0) hipLaunchKernelGGL(k_chol_panel_ll, dim3(h->pan_grid[k], n), dim3(64), 0, h->stream, B, k);
+                if (h->pan_grid[k] > 0) hipLaunchKernelGGL(k_chol_panel_ll, dim3(h->pan_grid[k] * ngrp), dim3(64), 0, h->stream, B, k, h->pan_grid[k]);
             }
             for (int k = 0; k < h->max_nb && !ll; k++) {
                 hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (h->pan_grid[k] + 1) / 2), n), dim3(64), 0, h->stream, B, k);
