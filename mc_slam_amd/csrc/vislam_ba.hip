@@ -202,6 +202,7 @@ struct Handle {
     int* stop_dev = nullptr;
     bool profile = false;
     int opt_lin_fallback = 0;  // test hook: XYZ windows without the edge-parallel work split
+    int opt_ll_min = 0;        // test hook: batch size from which the left-looking factorisation kernels are used (0: VBA_LL_MIN / 256)
     int opt_chunk = 0, opt_lanes = 0;  // > 0: chunk size / lanes of vba_batch_solve (test hook; defaults from VBA_CHUNK, VBA_LANES)
     int opt_streams = 0;  // > 0: window groups / streams for GN batches (test hook; default from VBA_STREAMS, 1)
     std::vector<ProfEvt> evts;
@@ -338,10 +339,10 @@ void quat_to_R_host(const double* q, double* R) {
 
 // >= this many windows: left-looking factorisation kernels, which never modify S (measured: the right-looking pair is faster
 // up to ~256 windows)
-bool use_left_looking(int n) {
+bool use_left_looking(const Handle* h, int n) {
     static const int left_looking = getenv("VBA_RIGHT_LOOKING") ? 0 : 1;
     static const int ll_min = getenv("VBA_LL_MIN") ? atoi(getenv("VBA_LL_MIN")) : 256;
-    return left_looking && n >= ll_min;
+    return left_looking && n >= (h->opt_ll_min > 0 ? h->opt_ll_min : ll_min);
 }
 
 int do_upload(Handle* h, int n, vba_problem* const* probs) {
@@ -405,7 +406,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         pair_a.reserve(spair); pair_b.reserve(spair); offpair.reserve(spair); pairmask.reserve(spair);
         pimu_begin.reserve(spair + n);
     }
-    const bool pristine = use_left_looking(n);
+    const bool pristine = use_left_looking(h, n);
     h->ll_mode = pristine;
     std::vector<Structure> sts;
     auto run_pool = [&](int cn, const std::function<void(int)>& job) {
@@ -646,8 +647,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
     // S: zero everything once, identity on the pads
     // (PCG reads whole keyframe-pair blocks, also the sub-blocks no factor tile covers and no Schur kernel writes: zero them once)
-    if (use_left_looking(n) || pcg) HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->up_stream));
-    for (int w = 0; w < n && !(use_left_looking(n) || pcg); w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
+    if (use_left_looking(h, n) || pcg) HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->up_stream));
+    for (int w = 0; w < n && !(use_left_looking(h, n) || pcg); w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
         const WinDesc& d = h->desc[w];
         if (d.nS > d.np)
             HIPCHK(h, hipMemsetAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)d.np * d.nS, 0, (size_t)(d.nS - d.np) * d.nS * 8, h->up_stream));
@@ -1379,6 +1380,7 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
     while ((int)h->lanes.size() < n_lanes) {
         Handle* l = nullptr;
         if (make_handle(h->device, h, &l) != 0) return fail(h, "vba_batch_solve: could not create a lane");
+        l->opt_ll_min = h->opt_ll_min;
         h->lanes.push_back(l);
     }
     // chunk boundaries: a ramp at the start (a quarter chunk, then half a chunk: the device starts after a quarter of the packing /
@@ -1422,11 +1424,20 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
         run_cv.notify_one();
         return rc;
     };
+    static const bool timing = getenv("VBA_TIMING") != nullptr;
+    const double t_call = now_ms();
     auto work = [&](Handle* lane) {
         for (int c = next.fetch_add(1); c < n_chunks2 && !bad.load(); c = next.fetch_add(1)) {
             const int w0 = cbeg[c], cn = cbeg[c + 1] - w0;
             if (cn <= 0) continue;
-            if (do_upload(lane, cn, inout + w0) || run_gated(lane) || do_download(lane, cn, inout + w0, out ? out + w0 : nullptr)) {
+            const double t0 = now_ms();
+            int rc = do_upload(lane, cn, inout + w0);
+            const double t1 = now_ms();
+            if (!rc) rc = run_gated(lane);
+            const double t2 = now_ms();
+            if (!rc) rc = do_download(lane, cn, inout + w0, out ? out + w0 : nullptr);
+            if (timing) fprintf(stderr, "[vba_batch_solve] chunk %d (%d windows): upload %.1f..%.1f  run ..%.1f  download ..%.1f ms\n", c, cn, t0 - t_call, t1 - t_call, t2 - t_call, now_ms() - t_call);
+            if (rc) {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!bad.exchange(1)) h->err = "vba_batch_solve, windows " + std::to_string(w0) + ".." + std::to_string(w0 + cn - 1) + ": " + lane->err;
                 return;
@@ -1459,6 +1470,13 @@ int vba_debug_set_lin_fallback(void* handle, int32_t on) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
     h->opt_lin_fallback = on;
+    return 0;
+}
+int vba_debug_set_ll_min(void* handle, int32_t n) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    h->opt_ll_min = n;
+    for (Handle* l : h->lanes) l->opt_ll_min = n;
     return 0;
 }
 int vba_debug_set_chunking(void* handle, int32_t chunk, int32_t lanes) {

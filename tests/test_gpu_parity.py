@@ -466,3 +466,25 @@ def test_large_batches_switch_factorisation_kernels(ba, oracle, variant, nwin):
         _check(p, q, r, qo, ro)
     for i in range(4, nwin):   # twins inside the batch agree bit for bit
         assert (qs[i].kf_pose == qs[i % 4].kf_pose).all() and rs[i].chi2_vis == rs[i % 4].chi2_vis
+
+
+def test_left_looking_kernels_at_full_window_size(ba, oracle):
+    """The left-looking factorisation (tile-packed factor, operands loaded straight into the MFMA registers) is what batches of
+    >= 256 windows run; here it is forced on full-size ragged C3 windows (40..60 keyframes: 19..28 block columns) and on a
+    full-size C2 window, one window at a time, against the oracle and against the right-looking kernels."""
+    ps = [synth.config_c3_ragged(100 + s) for s in (1, 2, 5)] + [synth.config_c2()]
+    ref = [ba.solve(p) for p in ps]
+    try:
+        ba.lib.vba_debug_set_ll_min(ba.h, 1)
+        got = [ba.solve(p) for p in ps]
+        ba.upload(ps[:3]); ba.run(); qs, rs = ba.download()    # ragged windows in one batch
+    finally:
+        ba.lib.vba_debug_set_ll_min(ba.h, 0)
+    for i, p in enumerate(ps):
+        (q, r), (q1, r1) = got[i], ref[i]
+        qo, ro = oracle.solve(p)
+        _check(p, q, r, qo, ro)
+        assert r.its_done == r1.its_done and (r.obs_outlier == r1.obs_outlier).all()
+        np.testing.assert_allclose(r.chi2_trace, r1.chi2_trace, rtol=1e-8)
+        if i < 3:
+            assert (qs[i].kf_pose == q.kf_pose).all() and rs[i].chi2_vis == r.chi2_vis   # batch == single solve, bit for bit
