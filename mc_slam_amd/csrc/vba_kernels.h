@@ -1516,15 +1516,23 @@ DEVI void ll_diag_accumulate(const Batch& B, const WinDesc& d, int J, int kb, in
         }
     const int* kl = B.tl_kl + d.tl_k0;
     double p0 = 0.0, p1 = 0.0;   // this lane's share of (L_Jk y_k) for rows l15 and 16 + l15: columns 4 ks + l4
-    for (int e = kb; e < ke; e++) {
-        const int k = kl[e];
+    // one wave per window, a chain of dependent products: the tile of step e+1 is in flight (registers) while the MFMAs of step e run
+    double2 nx[8];
+    double ndv[8], nyk[8];
+    auto fetch = [&](int k) {
         const double2* t = reinterpret_cast<const double2*>(Lf + ll_tile(d, J, k)) + lane;
         const double* sd = B.dvec + d.vec0 + (size_t)k * 32 + l4;
         const double* sy = B.yv + d.vec0 + (size_t)k * 32 + l4;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { nx[q] = t[64 * q]; ndv[q] = sd[4 * q]; nyk[q] = sy[4 * q]; }
+    };
+    if (kb < ke) fetch(kl[kb]);
+    for (int e = kb; e < ke; e++) {
         double2 x[8];
         double dv[8], yk[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) { x[q] = t[64 * q]; dv[q] = sd[4 * q]; yk[q] = sy[4 * q]; }
+        for (int q = 0; q < 8; q++) { x[q] = nx[q]; dv[q] = ndv[q]; yk[q] = nyk[q]; }
+        if (e + 1 < ke) fetch(kl[e + 1]);
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             const double2 a0 = x[ks >> 1], a1 = x[4 + (ks >> 1)];

@@ -1366,14 +1366,31 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
     if (n <= 0 || !inout) return fail(h, "vba_batch_solve: bad arguments");
-    // measured on MI355X, 4096 fresh C3 windows (scripts/e2e_sweep.py): chunk x lanes 512x3 7.7k windows/s, 768x3 8.0k, 1024x3 8.1k,
-    // 1024x2 8.2k (resident: 10.8k) -- one lane solves while the other packs / transfers / builds its structure / scatters
+    // measured on MI355X, 4096 fresh C3 windows (scripts/e2e_sweep.py, resident 12.1-13.0k windows/s): chunk x lanes 512x4 7.8k windows/s,
+    // 768x3 8.1k, 1024x2 9.05k, 1024x3 8.97k, 1365x2 9.3-9.4k, 1536x2 9.4k, 1700x2 9.6k, 2048x2 (no ramp) 7.7k -- one lane solves while
+    // the other packs / transfers / builds its structure / scatters; every chunk pays the fixed cost of its ~1700 launches again
     static const int env_lanes = getenv("VBA_LANES") ? atoi(getenv("VBA_LANES")) : 2;
-    static const int env_chunk = getenv("VBA_CHUNK") ? atoi(getenv("VBA_CHUNK")) : 1024;
+    static const int env_chunk = getenv("VBA_CHUNK") ? atoi(getenv("VBA_CHUNK")) : 1536;
     const int chunk_max = std::max(1, h->opt_chunk > 0 ? h->opt_chunk : env_chunk);
-    const int n_chunks = (n + chunk_max - 1) / chunk_max;
-    const int n_lanes = std::max(1, std::min(h->opt_lanes > 0 ? h->opt_lanes : env_lanes, n_chunks));
-    if (n_chunks == 1) {
+    // chunk boundaries: a ramp at the start (a quarter chunk, then half a chunk: the device starts after a quarter of the packing /
+    // transfer time of a full chunk and never waits for the second), the rest in equal chunks (no tiny tail).  No chunk falls
+    // below 256 windows when the batch has that many: the kernel choice of a chunk (section "regime") then equals the batch's.
+    std::vector<int> cbeg(1, 0);
+    {
+        static const int ramp = getenv("VBA_NO_RAMP") ? 0 : 1;
+        int left = n;
+        const int c1 = std::max(256, chunk_max / 4), c2 = std::max(256, chunk_max / 2);
+        if (ramp && chunk_max >= 1024 && n >= c1 + c2 + 256) {
+            cbeg.push_back(c1);
+            cbeg.push_back(c1 + c2);
+            left = n - c1 - c2;
+        }
+        const int rest = std::max(1, (left + chunk_max - 1) / chunk_max);
+        const int base = cbeg.back();
+        for (int c = 1; c <= rest; c++) cbeg.push_back(base + (int)((long long)left * c / rest));
+    }
+    const int n_lanes = std::max(1, std::min(h->opt_lanes > 0 ? h->opt_lanes : env_lanes, (int)cbeg.size() - 1));
+    if (cbeg.size() == 2) {
         if (do_upload(h, n, inout) || do_run(h, stop_flag)) return -1;
         return do_download(h, n, inout, out);
     }
@@ -1382,23 +1399,6 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
         if (make_handle(h->device, h, &l) != 0) return fail(h, "vba_batch_solve: could not create a lane");
         l->opt_ll_min = h->opt_ll_min;
         h->lanes.push_back(l);
-    }
-    // chunk boundaries: a ramp at the start (a quarter chunk, then half a chunk: the device starts after a quarter of the packing /
-    // transfer time of a full chunk and never waits for the second), the rest in equal chunks (no tiny tail).  No chunk falls
-    // below 256 windows when the batch has that many: the kernel choice of a chunk (section "regime") then equals the batch's.
-    std::vector<int> cbeg(1, 0);
-    {
-        static const int ramp = getenv("VBA_NO_RAMP") ? 0 : 1;
-        int left = n;
-        if (ramp && n_chunks >= 3 && chunk_max >= 1024) {
-            const int c1 = std::max(256, chunk_max / 4), c2 = std::max(256, chunk_max / 2);
-            cbeg.push_back(c1);
-            cbeg.push_back(c1 + c2);
-            left = n - c1 - c2;
-        }
-        const int rest = std::max(1, (left + chunk_max - 1) / chunk_max);
-        const int base = cbeg.back();
-        for (int c = 1; c <= rest; c++) cbeg.push_back(base + (int)((long long)left * c / rest));
     }
     const int n_chunks2 = (int)cbeg.size() - 1;
     std::atomic<int> next(0), bad(0);
