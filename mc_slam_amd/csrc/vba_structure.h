@@ -67,20 +67,20 @@ struct SlotRow {
 
 // 1. One workgroup per window: first keyframe of every track, observation -> landmark, and the three histograms with their
 //    prefix sums = the segment starts (landmarks per first keyframe, observations per observer, landmarks per reference).
-__global__ void __launch_bounds__(256) k_st_hist(Batch B, StBuild T) {
+__global__ void __launch_bounds__(1024) k_st_hist(Batch B, StBuild T) {
     extern __shared__ int sh[];
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
-    const int nk = d.n_kf, npt = d.n_pt, t = threadIdx.x, mw = d.mwords;
+    const int nk = d.n_kf, npt = d.n_pt, t = threadIdx.x, mw = d.mwords, nt = blockDim.x;
     const bool idp = d.variant == 2;
     int* hk = sh;                 // landmarks per first keyframe
     int* ho = sh + (nk + 1);      // observations per observing keyframe
     int* hr = ho + (nk + 1);      // landmarks per reference keyframe
-    for (int i = t; i < 3 * (nk + 1); i += 256) sh[i] = 0;
+    for (int i = t; i < 3 * (nk + 1); i += nt) sh[i] = 0;
     __syncthreads();
     const int* ob = B.pt_obs_begin + d.pt0 + d.win;
     const u64_t* LM = B.lmask + d.mask0;
-    for (int p = t; p < npt; p += 256) {
+    for (int p = t; p < npt; p += nt) {
         const int ref = B.pt_ref[d.pt0 + p];
         int key = idp ? ref : nk - 1;
         for (int wd = 0; wd < mw; wd++) {
@@ -93,14 +93,14 @@ __global__ void __launch_bounds__(256) k_st_hist(Batch B, StBuild T) {
         for (int o = ob[p]; o < ob[p + 1]; o++) T.obs_pt[d.obs0 + o] = p;
         if (!idp) T.pt_perm[d.pt0 + p] = p;   // XYZ landmarks have no reference keyframe: point records stay in landmark order
     }
-    for (int o = t; o < d.n_obs; o += 256) atomicAdd(&ho[B.obs_kf[d.obs0 + o] + 1], 1);
+    for (int o = t; o < d.n_obs; o += nt) atomicAdd(&ho[B.obs_kf[d.obs0 + o] + 1], 1);
     __syncthreads();
     if (t < 3) {
         int* h = sh + t * (nk + 1);
         for (int i = 0; i < nk; i++) h[i + 1] += h[i];
     }
     __syncthreads();
-    for (int i = t; i <= nk; i += 256) {
+    for (int i = t; i <= nk; i += nt) {
         T.key_seg[d.kf0 + d.win + i] = hk[i];
         T.kf_seg[d.kf0 + d.win + i] = ho[i];
         T.ref_seg[d.kf0 + d.win + i] = idp ? hr[i] : 0;

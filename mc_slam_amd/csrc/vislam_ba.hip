@@ -712,7 +712,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         T.mask_q = dp<unsigned long long>(h, BUF_MASKQ); T.slot_mask = dp<unsigned long long>(h, BUF_SLOTMASK); T.ref_q = dp<int>(h, BUF_REFQ);
         T.smw = (int)slotmask_words;
         T.slot_o = dp<int>(h, BUF_SLOTO);
-        hipLaunchKernelGGL(k_st_hist, dim3(n), dim3(256), sh_order, h->up_stream, B, T);
+        hipLaunchKernelGGL(k_st_hist, dim3(n), dim3(n <= 64 ? 1024 : 256), sh_order, h->up_stream, B, T);
         hipLaunchKernelGGL(k_st_rank_lm, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
         hipLaunchKernelGGL(k_st_rank_rec, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
         hipLaunchKernelGGL(k_st_count, dim3(h->max_free, n), dim3(64), sh_row, h->up_stream, B, T, h->max_free);
