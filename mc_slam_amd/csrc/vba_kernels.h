@@ -233,18 +233,22 @@ __global__ void __launch_bounds__(64) k_stage_mark(Batch B, int nblk_kf) {
 // LIN_FULL mode the 30x30 local Hessian J^T (rho' Omega) J and rhs in local order [PR_i V_i B_i | PR_j V_j B_j].
 // Two steps.  lin_imu_res: the Lie-group part -- residuals, Huber weights, the 9x30 Jacobian -- is scalar work, ONE LANE per
 // keyframe pair (64 pairs per wave side by side; round 1 ran it on lane 0 of a wave per pair, 63 lanes idle for ~1500
-// instructions); its products go to a 398-double record per pair (imu_jrec: J 270, weighted Omega 81, errors + weights +
-// column masks 47).  lin_imu_hess: one wave per pair turns the record into H = J^T (Omega J) and the rhs.
-#define IMU_JREC 400
+// instructions); its products go to a 104-double record per pair (imu_jrec): the six 3x3 matrices the Jacobian is made of (R_i^T,
+// hat(R_i^T vP), JrInv R_j^T R_i, hat(R_i^T vV), JrInv Exp(r_phi)^T Jr JRg, JrInv: 54), the errors, weights and column masks (47),
+// the Huber weight and the active flags (3).  The records of a window are stored ELEMENT-major (element q of pair k at
+// q * n_imu + k): the lanes of k_lin_imu_res -- one pair each -- store to consecutive addresses.  (Round 2 first wrote the whole
+// 9x30 Jacobian and the weighted 9x9 information, 400 doubles pair-major: 400 store instructions of 49 scattered 8-byte pieces each,
+// 2 GB of partial-line writes per pass and 0.6 of the kernel's 0.89 ms.)  lin_imu_hess: one wave per pair rebuilds J (preintegration
+// Jacobians from imu_meas) and Omega = w * info, then H = J^T (Omega J) and the rhs.
+#define IMU_JREC 104
 DEVI void lin_imu_res(const Batch& B, const WinDesc& d, int k, int mode) {
     const size_t gk = d.imu0 + k;
     const int i = B.imu_i[gk], j = B.imu_j[gk];
     const int act = imu_act(B, d, i, j);
     if (!act) return;  // every vertex fixed: not in the active set
     const double* meas = B.imu_meas + 61 * gk;
-    double* J = B.imu_jrec + IMU_JREC * gk;   // 9 x 30
-    double* Om = J + 270;                     // 9 x 9 weighted information
-    double* er = J + 351;                     // 9 err + 6 bias err + 2 weights(bias wg, wa scaled) + 30 column masks
+    double* jr = B.imu_jrec + IMU_JREC * (size_t)d.imu0 + k;   // element q of this pair: jr[q * n_imu]
+    const int js = d.n_imu;
     {
         const double* Ti = B.pose + 7 * (size_t)(d.kf0 + i);
         const double* Tj = B.pose + 7 * (size_t)(d.kf0 + j);
@@ -304,19 +308,21 @@ DEVI void lin_imu_res(const Batch& B, const WinDesc& d, int k, int mode) {
         double* ch = B.imu_chi + 4 * gk;
         ch[0] = (act & 1) ? rob : 0.0; ch[1] = (act & 2) ? robb : 0.0; ch[2] = (act & 1) ? s : 0.0; ch[3] = (act & 2) ? sb : 0.0;
         if (mode == LIN_FULL) {
-            for (int a = 0; a < 9; a++) er[a] = e[a];
-            for (int a = 0; a < 6; a++) er[9 + a] = eb[a];
-            er[15] = (act & 2) ? rwb * wg : 0.0; er[16] = (act & 2) ? rwb * wa : 0.0;
+            // record elements 54..100: 9 err + 6 bias err + 2 weights (bias wg, wa scaled) + 30 column masks; 101: Huber weight of the
+            // PRV edge (0: edge inactive), so that Omega = w * info is formed by the reader
+            for (int a = 0; a < 9; a++) jr[(54 + a) * js] = e[a];
+            for (int a = 0; a < 6; a++) jr[(54 + 9 + a) * js] = eb[a];
+            jr[(54 + 15) * js] = (act & 2) ? rwb * wg : 0.0; jr[(54 + 16) * js] = (act & 2) ? rwb * wa : 0.0;
             {   // column mask of the 30 local variables: 0 where the vertex is fixed through kf_fix
                 const int fi = (i < d.n_free) ? kf_free(B, d, i) : 7, fj = (j < d.n_free) ? kf_free(B, d, j) : 7;
                 for (int q = 0; q < 15; q++) {
                     const int part = (q < 6) ? 0 : ((q < 9) ? 1 : 2);
-                    er[17 + q] = ((fi >> part) & 1) ? 1.0 : 0.0;
-                    er[32 + q] = ((fj >> part) & 1) ? 1.0 : 0.0;
+                    jr[(54 + 17 + q) * js] = ((fi >> part) & 1) ? 1.0 : 0.0;
+                    jr[(54 + 32 + q) * js] = ((fj >> part) & 1) ? 1.0 : 0.0;
                 }
             }
-            for (int a = 0; a < 81; a++) Om[a] = (act & 1) ? rw * info[a] : 0.0;
-            for (int a = 0; a < 270; a++) J[a] = 0.0;
+            jr[101 * js] = rw;
+            jr[102 * js] = (act & 1) ? 1.0 : 0.0;
             // Jacobians (g2otypes.cpp:296-359); local columns: PR_i 0..5, V_i 6..8, B_i 9..14, PR_j 15..20, V_j 21..23
             double RiT[9], RjT[9], JrI[9], H1[9], H2[9], T1[9], T2[9];
             for (int a = 0; a < 3; a++)
@@ -340,20 +346,13 @@ DEVI void lin_imu_res(const Batch& B, const WinDesc& d, int k, int mode) {
             for (int a = 0; a < 3; a++)
                 for (int b = 0; b < 3; b++) {
                     const int q = 3 * a + b;
-                    J[(0 + a) * 30 + 0 + b] = -RiT[q];            // d rP / d P_i
-                    J[(0 + a) * 30 + 3 + b] = H1[q];              // d rP / d phi_i
-                    J[(3 + a) * 30 + 3 + b] = -T2[q];             // d rphi / d phi_i
-                    J[(6 + a) * 30 + 3 + b] = H2[q];              // d rV / d phi_i
-                    J[(0 + a) * 30 + 6 + b] = -RiT[q] * dT;       // d rP / d V_i
-                    J[(6 + a) * 30 + 6 + b] = -RiT[q];            // d rV / d V_i
-                    J[(0 + a) * 30 + 9 + b] = -JPg[q];            // d rP / d dbg_i
-                    J[(0 + a) * 30 + 12 + b] = -JPa[q];           // d rP / d dba_i
-                    J[(3 + a) * 30 + 9 + b] = -T1[q];             // d rphi / d dbg_i
-                    J[(6 + a) * 30 + 9 + b] = -JVg[q];
-                    J[(6 + a) * 30 + 12 + b] = -JVa[q];
-                    J[(0 + a) * 30 + 15 + b] = RiT[q];            // d rP / d P_j
-                    J[(3 + a) * 30 + 18 + b] = JrI[q];            // d rphi / d phi_j
-                    J[(6 + a) * 30 + 21 + b] = RiT[q];            // d rV / d V_j
+                    // the Jacobian's building blocks (assembled by lin_imu_fill_J): record elements 0..53
+                    jr[(0 + q) * js] = RiT[q];
+                    jr[(9 + q) * js] = H1[q];
+                    jr[(18 + q) * js] = T2[q];
+                    jr[(27 + q) * js] = H2[q];
+                    jr[(36 + q) * js] = T1[q];
+                    jr[(45 + q) * js] = JrI[q];
                 }
         }
     }
@@ -366,12 +365,40 @@ DEVI void lin_imu_hess(const Batch& B, const WinDesc& d, int k, double* sm) {
     if (!imu_act(B, d, i, j)) return;
     double* J = sm;            // 9 x 30
     double* Om = sm + 270;     // 9 x 9 weighted information
-    double* T = sm + 351;      // 9 x 30 = Om J
+    double* T = sm + 351;      // 9 x 30 = Om J ; before that: the 54 building blocks of J
     double* er = sm + 621;     // 9 err + 6 bias err + 2 weights + 30 column masks
     const int t = threadIdx.x;
-    const double* rec = B.imu_jrec + IMU_JREC * gk;
-    for (int q = t; q < 351; q += 64) sm[q] = rec[q];
-    for (int q = t; q < 47; q += 64) er[q] = rec[351 + q];
+    const double* jr = B.imu_jrec + IMU_JREC * (size_t)d.imu0 + k;
+    const int js = d.n_imu;
+    const double* meas = B.imu_meas + 61 * gk;
+    const double* info = B.imu_info + 81 * gk;
+    const double rw = jr[101 * js];
+    const bool on = jr[102 * js] != 0.0;
+    for (int q = t; q < 270; q += 64) J[q] = 0.0;
+    if (t < 54) T[t] = jr[t * js];
+    if (t < 47) er[t] = jr[(54 + t) * js];
+    for (int q = t; q < 81; q += 64) Om[q] = on ? rw * info[q] : 0.0;
+    __syncthreads();
+    if (t < 9) {   // Jacobians (g2otypes.cpp:296-359); local columns: PR_i 0..5, V_i 6..8, B_i 9..14, PR_j 15..20, V_j 21..23
+        const int a = t / 3, b = t % 3, q = t;
+        const double dT = meas[0];
+        const double *JPg = meas + 16, *JPa = meas + 25, *JVg = meas + 34, *JVa = meas + 43;
+        const double *RiT = T, *H1 = T + 9, *T2 = T + 18, *H2 = T + 27, *T1 = T + 36, *JrI = T + 45;
+        J[(0 + a) * 30 + 0 + b] = -RiT[q];            // d rP / d P_i
+        J[(0 + a) * 30 + 3 + b] = H1[q];              // d rP / d phi_i
+        J[(3 + a) * 30 + 3 + b] = -T2[q];             // d rphi / d phi_i
+        J[(6 + a) * 30 + 3 + b] = H2[q];              // d rV / d phi_i
+        J[(0 + a) * 30 + 6 + b] = -RiT[q] * dT;       // d rP / d V_i
+        J[(6 + a) * 30 + 6 + b] = -RiT[q];            // d rV / d V_i
+        J[(0 + a) * 30 + 9 + b] = -JPg[q];            // d rP / d dbg_i
+        J[(0 + a) * 30 + 12 + b] = -JPa[q];           // d rP / d dba_i
+        J[(3 + a) * 30 + 9 + b] = -T1[q];             // d rphi / d dbg_i
+        J[(6 + a) * 30 + 9 + b] = -JVg[q];
+        J[(6 + a) * 30 + 12 + b] = -JVa[q];
+        J[(0 + a) * 30 + 15 + b] = RiT[q];            // d rP / d P_j
+        J[(3 + a) * 30 + 18 + b] = JrI[q];            // d rphi / d phi_j
+        J[(6 + a) * 30 + 21 + b] = RiT[q];            // d rV / d V_j
+    }
     __syncthreads();
     for (int q = t; q < 270; q += 64) {  // T = Om J
         const int a = q / 30, col = q % 30;
