@@ -183,6 +183,7 @@ def main():
             local_rank = 0
             torch.cuda.set_device(0)
             dist.init_process_group("gloo", rank=rank, world_size=world)
+            args.batch = max(256, args.batch // world)   # the ranks share one card's HBM here: the rehearsal checks the launcher, not the rate
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
