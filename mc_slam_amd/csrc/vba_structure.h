@@ -25,6 +25,11 @@ struct StBuild {   // what the build writes (the solve reads the same arrays thr
                                                   // walks read them in sequence instead of gathering them through an index
     int *ref_q;                                   // scratch: reference keyframe of the landmark at rank q
     int *slot_o;                                  // observation of the record in slot s (k_stage_mark walks a keyframe's edges through it)
+    int *rec_cnt;                                 // scratch: per chunk of 64 landmarks (lm_order) and keyframe the observed / referenced counts, then their prefix
+    int *slot_ref, *slot_q, *rec_q, *tsq;         // scratch, so that the pair-row walk gathers nothing through a landmark index: reference
+                                                  // keyframe and lm_order rank of the landmark in slot s, rank of the landmark in record r,
+                                                  // and per RANK the first eight slots of the landmark's row (neighbouring records of a
+                                                  // keyframe are neighbouring ranks: their rows share cache lines)
     int smw;                                      // words per slot_mask entry (the largest mwords of the batch)
 };
 
@@ -48,15 +53,20 @@ DEVI int st_slot_of(const StBuild& T, const WinDesc& d, const u64_t* LM, const i
 // that walk then cost no memory round trip (tracks longer than eight fall back to the table)
 struct SlotRow {
     int v[8];
-    DEVI void load(const StBuild& T, const WinDesc& d, const int* ob, int p, bool valid) {
-        const int o0 = valid ? ob[p] : 0, n = valid ? ob[p + 1] - o0 : 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = (i < n) ? T.tslot[d.obs0 + o0 + i] : 0;
+    DEVI void load(const StBuild& T, const WinDesc& d, int q, bool valid) {   // q: lm_order rank of the landmark
+        const int4* row = reinterpret_cast<const int4*>(T.tsq + 8 * (size_t)(d.pt0 + (valid ? q : 0)));
+        const int4 lo = row[0], hi = row[1];   // entries beyond the track length are never selected
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
     }
-    DEVI int at(const StBuild& T, const WinDesc& d, const u64_t* LM, const int* ob, int p, int b) const {
-        const u64_t* M = LM + (size_t)p * d.mwords;
-        int r = __popcll(M[b >> 6] & ((1ull << (b & 63)) - 1ull));
-        for (int wd = 0; wd < (b >> 6); wd++) r += __popcll(M[wd]);
+    // m0: word 0 of the landmark's mask, already in a register (windows of <= 64 keyframes need nothing else)
+    DEVI int at(const StBuild& T, const WinDesc& d, const u64_t* LM, const int* ob, int p, int b, u64_t m0) const {
+        int r;
+        if (d.mwords == 1) r = __popcll(m0 & ((1ull << (b & 63)) - 1ull));
+        else {
+            const u64_t* M = LM + (size_t)p * d.mwords;
+            r = __popcll(M[b >> 6] & ((1ull << (b & 63)) - 1ull));
+            for (int wd = 0; wd < (b >> 6); wd++) r += __popcll(M[wd]);
+        }
         if (r >= 8) return T.tslot[d.obs0 + ob[p] + r];
         int x = v[0];
 #pragma unroll
@@ -107,73 +117,173 @@ __global__ void __launch_bounds__(1024) k_st_hist(Batch B, StBuild T) {
     }
 }
 
-// 2. landmarks by (first keyframe, index): one wave per (window, bucket) walks the landmarks in index order
-__global__ void __launch_bounds__(64) k_st_rank_lm(Batch B, StBuild T) {
-    const int w = blockIdx.y, k = blockIdx.x;
+// 2. landmarks by (first keyframe, index), stable: one wave per chunk of 64 landmarks in index order counts its members per bucket
+//    (k_st_lm_count), k_st_rec_scan turns the counts into prefixes over the chunks, k_st_lm_fill ranks.  Same scratch (rec_cnt,
+//    column 0) and same shape as the record ranking below.
+__global__ void __launch_bounds__(64) k_st_lm_count(Batch B, StBuild T, int max_chunks) {
+    const int w = blockIdx.y, c = blockIdx.x;
     const WinDesc& d = B.desc[w];
-    if (k >= d.n_kf) return;
-    const int npt = d.n_pt, lane = threadIdx.x;
-    int base = T.key_seg[d.kf0 + d.win + k];
-    const int end = T.key_seg[d.kf0 + d.win + k + 1];
-    const u64_t lt = lanes_below();
-    for (int c = 0; c < npt && base < end; c += 64) {
-        const int p = c + lane;
-        const bool has = p < npt && T.st_key[d.pt0 + p] == k;
-        const u64_t m = __ballot(has);
-        if (has) {
-            const int q = base + __popcll(m & lt);
-            T.lm_order[d.pt0 + q] = p;
-            T.ref_q[d.pt0 + q] = B.pt_ref[d.pt0 + p];
-            for (int wd = 0; wd < d.mwords; wd++) T.mask_q[d.mask0 + (size_t)q * d.mwords + wd] = B.lmask[d.mask0 + (size_t)p * d.mwords + wd];
+    if (64 * c >= d.n_pt) return;
+    const int lane = threadIdx.x, nk = d.n_kf, p = 64 * c + lane;
+    const int key = (p < d.n_pt) ? T.st_key[d.pt0 + p] : -1;
+    int* cnt = T.rec_cnt + 2 * ((size_t)d.kf0 * max_chunks + (size_t)c * nk);
+    for (int wd = 0; wd < (nk + 63) / 64; wd++) {
+        const u64_t kb = (key >= 0 && (key >> 6) == wd) ? (1ull << (key & 63)) : 0ull;
+        u64_t U = wave_or64(kb);
+        int co = 0;
+        while (U) {
+            const int bb = __builtin_ctzll(U);
+            U &= U - 1;
+            const int no = __popcll(__ballot((kb >> bb) & 1ull));
+            if (lane == bb) co = no;
         }
-        base += __popcll(m);
+        const int k = 64 * wd + lane;
+        if (k < nk) { cnt[2 * k] = co; cnt[2 * k + 1] = 0; }
+    }
+}
+__global__ void __launch_bounds__(64) k_st_lm_fill(Batch B, StBuild T, int max_chunks) {
+    const int w = blockIdx.y, c = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    if (64 * c >= d.n_pt) return;
+    const int lane = threadIdx.x, nk = d.n_kf, mw = d.mwords, p = 64 * c + lane;
+    const int key = (p < d.n_pt) ? T.st_key[d.pt0 + p] : -1;
+    const int* pre = T.rec_cnt + 2 * ((size_t)d.kf0 * max_chunks + (size_t)c * nk);
+    const int* kseg = T.key_seg + d.kf0 + d.win;
+    const u64_t lt = lanes_below();
+    for (int wd = 0; wd < (nk + 63) / 64; wd++) {
+        const u64_t kb = (key >= 0 && (key >> 6) == wd) ? (1ull << (key & 63)) : 0ull;
+        u64_t U = wave_or64(kb);
+        while (U) {
+            const int bb = __builtin_ctzll(U);
+            U &= U - 1;
+            const int k = 64 * wd + bb;
+            const bool has = (kb >> bb) & 1ull;
+            const u64_t m = __ballot(has);
+            if (has) {
+                const int q = kseg[k] + pre[2 * k] + __popcll(m & lt);
+                T.lm_order[d.pt0 + q] = p;
+                T.ref_q[d.pt0 + q] = B.pt_ref[d.pt0 + p];
+                for (int v = 0; v < mw; v++) T.mask_q[d.mask0 + (size_t)q * mw + v] = B.lmask[d.mask0 + (size_t)p * mw + v];
+            }
+        }
     }
 }
 
-// 3. observation records by (observing keyframe, lm_order) and landmark records by (reference keyframe, lm_order): one wave
-//    per (window, keyframe) walks the landmarks in lm_order
-__global__ void __launch_bounds__(64) k_st_rank_rec(Batch B, StBuild T) {
-    const int w = blockIdx.y, k = blockIdx.x;
+// 3. observation records by (observing keyframe, lm_order) and landmark records by (reference keyframe, lm_order).  One wave per
+//    CHUNK of 64 landmarks in lm_order (a lane per landmark: its mask, reference, CSR row and the keyframes of its first eight
+//    observations are loaded once), three launches:
+//      k_st_rec_count  per chunk and keyframe: how many of the chunk's landmarks the keyframe observes / is the reference of
+//                      (one ballot per keyframe that occurs in the chunk)
+//      k_st_rec_scan   per window and keyframe: exclusive prefix over the chunks
+//      k_st_rec_fill   the same ballots again; record position = segment start + prefix of the chunk + rank inside the ballot
+//    (Round 2 first had one wave per (window, KEYFRAME) scan all landmark masks -- n_kf x the mask reads -- and look the observation
+//    up per incidence through the landmark's CSR row: 2 scattered lines per incidence instead of 2 per landmark, 9.7 ms per 4096 windows.)
+//    cnt: [chunk][n_kf][2] ints per window at 2 * kf0 * max_chunks (max_chunks = 64-landmark blocks of the largest window of the batch)
+struct RecLane {   // what a lane knows about its landmark
+    bool valid;
+    int q, p, ref, ob0, nob;
+    int okf[8];
+};
+DEVI void rec_lane_load(const Batch& B, const StBuild& T, const WinDesc& d, int c, RecLane& L, bool full) {
+    const int lane = threadIdx.x;
+    L.q = 64 * c + lane;
+    L.valid = L.q < d.n_pt;
+    L.ref = (L.valid && d.variant == 2) ? T.ref_q[d.pt0 + L.q] : -1;
+    L.p = 0; L.ob0 = 0; L.nob = 0;
+    if (full && L.valid) {
+        const int* ob = B.pt_obs_begin + d.pt0 + d.win;
+        L.p = T.lm_order[d.pt0 + L.q];
+        L.ob0 = ob[L.p];
+        L.nob = ob[L.p + 1] - L.ob0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) L.okf[i] = (i < L.nob) ? B.obs_kf[d.obs0 + L.ob0 + i] : -1;
+    }
+}
+__global__ void __launch_bounds__(64) k_st_rec_count(Batch B, StBuild T, int max_chunks) {
+    const int w = blockIdx.y, c = blockIdx.x;
     const WinDesc& d = B.desc[w];
-    if (k >= d.n_kf) return;
-    const int npt = d.n_pt, lane = threadIdx.x, mw = d.mwords;
-    const bool idp = d.variant == 2;
-    const int* ob = B.pt_obs_begin + d.pt0 + d.win;
-    const u64_t* LM = B.lmask + d.mask0;
-    int bo = T.kf_seg[d.kf0 + d.win + k], br = T.ref_seg[d.kf0 + d.win + k];
-    const int eo = T.kf_seg[d.kf0 + d.win + k + 1], er = T.ref_seg[d.kf0 + d.win + k + 1];
-    const int kw = k >> 6, kb = k & 63;
+    if (64 * c >= d.n_pt) return;
+    const int lane = threadIdx.x, mw = d.mwords, nk = d.n_kf;
+    RecLane L;
+    rec_lane_load(B, T, d, c, L, false);
+    const u64_t* M = T.mask_q + d.mask0 + (size_t)(L.valid ? L.q : 0) * mw;
+    int* cnt = T.rec_cnt + 2 * ((size_t)d.kf0 * max_chunks + (size_t)c * nk);
+    for (int wd = 0; wd < mw; wd++) {
+        const u64_t m = L.valid ? M[wd] : 0ull;
+        const u64_t rb = (L.ref >= 0 && (L.ref >> 6) == wd) ? (1ull << (L.ref & 63)) : 0ull;
+        u64_t U = wave_or64(m | rb);
+        int co = 0, cr = 0;   // lane l: the counts of keyframe 64 wd + l
+        while (U) {
+            const int bb = __builtin_ctzll(U);
+            U &= U - 1;
+            const int no = __popcll(__ballot((m >> bb) & 1ull)), nr = __popcll(__ballot((rb >> bb) & 1ull));
+            if (lane == bb) { co = no; cr = nr; }
+        }
+        const int k = 64 * wd + lane;
+        if (k < nk) { cnt[2 * k] = co; cnt[2 * k + 1] = cr; }
+    }
+}
+__global__ void __launch_bounds__(256) k_st_rec_scan(Batch B, StBuild T, int max_chunks) {
+    const int w = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    const int nk = d.n_kf, nch = (d.n_pt + 63) / 64;
+    int* cnt = T.rec_cnt + 2 * (size_t)d.kf0 * max_chunks;
+    for (int k2 = threadIdx.x; k2 < 2 * nk; k2 += 256) {   // (keyframe, obs / ref) columns: exclusive prefix over the chunks
+        int run = 0;
+        for (int c = 0; c < nch; c++) {
+            const int v = cnt[(size_t)c * 2 * nk + k2];
+            cnt[(size_t)c * 2 * nk + k2] = run;
+            run += v;
+        }
+    }
+}
+__global__ void __launch_bounds__(64) k_st_rec_fill(Batch B, StBuild T, int max_chunks) {
+    const int w = blockIdx.y, c = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    if (64 * c >= d.n_pt) return;
+    const int lane = threadIdx.x, mw = d.mwords, nk = d.n_kf;
+    RecLane L;
+    rec_lane_load(B, T, d, c, L, true);
+    const u64_t* M = T.mask_q + d.mask0 + (size_t)(L.valid ? L.q : 0) * mw;
+    const int* pre = T.rec_cnt + 2 * ((size_t)d.kf0 * max_chunks + (size_t)c * nk);
+    const int* kseg = T.kf_seg + d.kf0 + d.win;
+    const int* rseg = T.ref_seg + d.kf0 + d.win;
     const u64_t lt = lanes_below();
-    // a track that contains k starts at k or before: only the landmarks of the first k + 1 buckets of lm_order can be members
-    const int q_end = min(npt, T.key_seg[d.kf0 + d.win + k + 1]);
-    for (int c = 0; c < q_end && (bo < eo || br < er); c += 64) {
-        const int q = c + lane;
-        const bool valid = q < q_end;
-        const u64_t* M = T.mask_q + d.mask0 + (size_t)(valid ? q : 0) * mw;   // masks in lm_order: read in sequence
-        const bool haso = valid && ((M[kw] >> kb) & 1ull);
-        const bool hasr = valid && idp && T.ref_q[d.pt0 + q] == k;
-        const int p = (haso || hasr) ? T.lm_order[d.pt0 + q] : 0;
-        const u64_t mo = __ballot(haso);
-        if (haso) {
-            const int slot = bo + __popcll(mo & lt);
-            int o = ob[p];
-            while (B.obs_kf[d.obs0 + o] != k) o++;
-            T.slot_perm[d.obs0 + o] = slot;
-            T.slot_obs[d.obs0 + slot] = p;   // the landmark of the record in this slot
-            T.slot_o[d.obs0 + slot] = o;
-            for (int wd = 0; wd < mw; wd++) T.slot_mask[(size_t)(d.obs0 + slot) * T.smw + wd] = M[wd];
-            int r = __popcll(M[kw] & ((1ull << kb) - 1ull));
-            for (int wd = 0; wd < kw; wd++) r += __popcll(M[wd]);
-            T.tslot[d.obs0 + ob[p] + r] = slot;   // the landmark's slots in keyframe order (st_slot_of)
+    int below = 0;   // observing keyframes of this landmark in the mask words already walked
+    for (int wd = 0; wd < mw; wd++) {
+        const u64_t m = L.valid ? M[wd] : 0ull;
+        const u64_t rb = (L.ref >= 0 && (L.ref >> 6) == wd) ? (1ull << (L.ref & 63)) : 0ull;
+        u64_t U = wave_or64(m | rb);
+        while (U) {
+            const int bb = __builtin_ctzll(U);
+            U &= U - 1;
+            const int k = 64 * wd + bb;
+            const bool haso = (m >> bb) & 1ull, hasr = (rb >> bb) & 1ull;
+            const u64_t mo = __ballot(haso), mr = __ballot(hasr);
+            if (haso) {
+                const int slot = kseg[k] + pre[2 * k] + __popcll(mo & lt);
+                int o = -1;
+#pragma unroll
+                for (int i = 0; i < 8; i++) o = (L.okf[i] == k) ? L.ob0 + i : o;
+                if (o < 0) { o = L.ob0 + 8; while (B.obs_kf[d.obs0 + o] != k) o++; }   // tracks longer than eight observations
+                T.slot_perm[d.obs0 + o] = slot;
+                T.slot_obs[d.obs0 + slot] = L.p;   // the landmark of the record in this slot
+                T.slot_o[d.obs0 + slot] = o;
+                T.slot_q[d.obs0 + slot] = L.q;
+                T.slot_ref[d.obs0 + slot] = L.ref;
+                for (int v = 0; v < mw; v++) T.slot_mask[(size_t)(d.obs0 + slot) * T.smw + v] = M[v];
+                const int r = below + __popcll(m & ((1ull << bb) - 1ull));
+                T.tslot[d.obs0 + L.ob0 + r] = slot;   // the landmark's slots in keyframe order (st_slot_of)
+                if (r < 8) T.tsq[8 * (size_t)(d.pt0 + L.q) + r] = slot;
+            }
+            if (hasr) {
+                const int r = rseg[k] + pre[2 * k + 1] + __popcll(mr & lt);
+                T.pt_perm[d.pt0 + L.p] = r;
+                T.pt_inv[d.pt0 + r] = L.p;
+                T.rec_q[d.pt0 + r] = L.q;
+            }
         }
-        bo += __popcll(mo);
-        const u64_t mr = __ballot(hasr);
-        if (hasr) {
-            const int r = br + __popcll(mr & lt);
-            T.pt_perm[d.pt0 + p] = r;
-            T.pt_inv[d.pt0 + r] = p;
-        }
-        br += __popcll(mr);
+        below += __popcll(m);
     }
 }
 
@@ -214,10 +324,11 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
     for (int c = kseg[a]; c < kseg[a + 1]; c += 64) {
         const int slot = c + lane;
         const bool valid = slot < kseg[a + 1];
-        const int p = valid ? T.slot_obs[d.obs0 + slot] : 0;
-        const int r = (valid && idp) ? B.pt_ref[d.pt0 + p] : -1;
+        const int p = (FILL && valid) ? T.slot_obs[d.obs0 + slot] : 0;
+        const int r = (valid && idp) ? T.slot_ref[d.obs0 + slot] : -1;
         SlotRow sr;
-        if (FILL) sr.load(T, d, ob, p, valid);
+        if (FILL) sr.load(T, d, valid ? T.slot_q[d.obs0 + slot] : 0, valid);
+        const u64_t lmw0 = valid ? T.slot_mask[(size_t)(d.obs0 + slot) * T.smw] : 0ull;   // word 0 of the landmark's mask
         for (int wd = a >> 6; wd < mw; wd++) {
             const u64_t rg = range(wd);
             if (!rg) continue;
@@ -231,7 +342,7 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
                 const bool h0 = (Mr >> bb) & 1ull, h1 = (rb >> bb) & 1ull;
                 const u64_t m0 = __ballot(h0), m1 = __ballot(h1);
                 if (FILL) {
-                    if (h0) items[c0[b] + __popcll(m0 & lt)] = make_int2(slot, sr.at(T, d, LM, ob, p, b));
+                    if (h0) items[c0[b] + __popcll(m0 & lt)] = make_int2(slot, sr.at(T, d, LM, ob, p, b, lmw0));
                     if (h1) items[c1[b] + __popcll(m1 & lt)] = make_int2(slot, d.n_obs + T.pt_perm[d.pt0 + p]);
                 }
                 __syncthreads();   // one wave: orders the LDS reads above before lane 0's update
@@ -245,13 +356,16 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
         for (int c = rseg[a]; c < rseg[a + 1]; c += 64) {
             const int rec = c + lane;
             const bool valid = rec < rseg[a + 1];
-            const int p = valid ? T.pt_inv[d.pt0 + rec] : 0;
+            const int p = (FILL && valid) ? T.pt_inv[d.pt0 + rec] : 0;
+            const int q = valid ? T.rec_q[d.pt0 + rec] : 0;
+            const u64_t* MQ = T.mask_q + d.mask0 + (size_t)q * mw;   // the landmark's mask, stored in lm_order
             SlotRow sr;
-            if (FILL) sr.load(T, d, ob, p, valid);
+            if (FILL) sr.load(T, d, q, valid);
+            const u64_t lmw0 = valid ? MQ[0] : 0ull;
             for (int wd = a >> 6; wd < mw; wd++) {
                 const u64_t rg = range(wd);
                 if (!rg) continue;
-                const u64_t Mr = valid ? (LM[(size_t)p * mw + wd] & rg) : 0ull;
+                const u64_t Mr = valid ? (MQ[wd] & rg) : 0ull;
                 u64_t U = wave_or64(Mr);
                 while (U) {
                     const int bb = __builtin_ctzll(U);
@@ -259,7 +373,7 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
                     const int b = 64 * wd + bb;
                     const bool h1 = (Mr >> bb) & 1ull;
                     const u64_t m1 = __ballot(h1);
-                    if (FILL && h1) items[c1[b] + __popcll(m1 & lt)] = make_int2(d.n_obs + rec, sr.at(T, d, LM, ob, p, b));
+                    if (FILL && h1) items[c1[b] + __popcll(m1 & lt)] = make_int2(d.n_obs + rec, sr.at(T, d, LM, ob, p, b, lmw0));
                     __syncthreads();
                     if (lane == 0) c1[b] += __popcll(m1);
                     __syncthreads();

@@ -151,7 +151,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_SLOTO, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_SLOTO, BUF_SLOTREF, BUF_SLOTQ, BUF_RECQ, BUF_TSQ, BUF_RECCNT, BUF_N
 };
 
 struct ProfEvt {
@@ -618,6 +618,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     }
     if (dalloc(h, BUF_SLOTO, (size_t)obs0 * 4)) return -1;
     if (dalloc(h, BUF_TSLOT, (size_t)obs0 * 4) || dalloc(h, BUF_KFDIR, (size_t)kf0 * 32 * 8)) return -1;
+    if (dalloc(h, BUF_SLOTREF, (size_t)obs0 * 4) || dalloc(h, BUF_SLOTQ, (size_t)obs0 * 4) || dalloc(h, BUF_RECQ, (size_t)pt0 * 4) || dalloc(h, BUF_TSQ, (size_t)pt0 * 8 * 4)) return -1;
     if (dalloc(h, BUF_ITEMBEG, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMMID, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMS, (size_t)item0 * 8)) return -1;
     if (dalloc(h, BUF_STKEY, (size_t)pt0 * 4) || dalloc(h, BUF_LMORDER, (size_t)pt0 * 4) || dalloc(h, BUF_SLOTOBS, (size_t)obs0 * 4) || dalloc(h, BUF_PTINV, (size_t)pt0 * 4)) return -1;
     if (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow)) return -1;
@@ -712,9 +713,19 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         T.mask_q = dp<unsigned long long>(h, BUF_MASKQ); T.slot_mask = dp<unsigned long long>(h, BUF_SLOTMASK); T.ref_q = dp<int>(h, BUF_REFQ);
         T.smw = (int)slotmask_words;
         T.slot_o = dp<int>(h, BUF_SLOTO);
+        T.slot_ref = dp<int>(h, BUF_SLOTREF); T.slot_q = dp<int>(h, BUF_SLOTQ); T.rec_q = dp<int>(h, BUF_RECQ); T.tsq = dp<int>(h, BUF_TSQ);
         hipLaunchKernelGGL(k_st_hist, dim3(n), dim3(n <= 64 ? 1024 : 256), sh_order, h->up_stream, B, T);
-        hipLaunchKernelGGL(k_st_rank_lm, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
-        hipLaunchKernelGGL(k_st_rank_rec, dim3(max_kf, n), dim3(64), 0, h->up_stream, B, T);
+        {
+            const int max_chunks = std::max(1, h->max_pt_blk);   // 64-landmark blocks of the largest window
+            if (dalloc(h, BUF_RECCNT, (size_t)kf0 * max_chunks * 2 * 4)) return -1;
+            T.rec_cnt = dp<int>(h, BUF_RECCNT);
+            hipLaunchKernelGGL(k_st_lm_count, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
+            hipLaunchKernelGGL(k_st_rec_scan, dim3(n), dim3(256), 0, h->up_stream, B, T, max_chunks);
+            hipLaunchKernelGGL(k_st_lm_fill, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
+            hipLaunchKernelGGL(k_st_rec_count, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
+            hipLaunchKernelGGL(k_st_rec_scan, dim3(n), dim3(256), 0, h->up_stream, B, T, max_chunks);
+            hipLaunchKernelGGL(k_st_rec_fill, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
+        }
         hipLaunchKernelGGL(k_st_count, dim3(h->max_free, n), dim3(64), sh_row, h->up_stream, B, T, h->max_free);
         hipLaunchKernelGGL(k_st_scan, dim3(n), dim3(256), 0, h->up_stream, B, T);
         hipLaunchKernelGGL(k_st_fill, dim3(h->max_free, n), dim3(64), sh_row, h->up_stream, B, T, h->max_free);
@@ -1491,7 +1502,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE", "SLOTO"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE", "SLOTO", "SLOTREF", "SLOTQ", "RECQ", "TSQ", "RECCNT"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
