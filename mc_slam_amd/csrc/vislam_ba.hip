@@ -1383,22 +1383,28 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
     static const int env_lanes = getenv("VBA_LANES") ? atoi(getenv("VBA_LANES")) : 2;
     static const int env_chunk = getenv("VBA_CHUNK") ? atoi(getenv("VBA_CHUNK")) : 1536;
     const int chunk_max = std::max(1, h->opt_chunk > 0 ? h->opt_chunk : env_chunk);
-    // chunk boundaries: a ramp at the start (a quarter chunk, then half a chunk: the device starts after a quarter of the packing /
-    // transfer time of a full chunk and never waits for the second), the rest in equal chunks (no tiny tail).  No chunk falls
-    // below 256 windows when the batch has that many: the kernel choice of a chunk (section "regime") then equals the batch's.
+    // chunk boundaries: a ramp at the start, then equal chunks (no tiny tail).  Uploads go one at a time in chunk order (below) at
+    // ~57 us per window, a chunk of s windows solves in ~14 + 0.075 s ms: chunk k+1 is on the device before chunk k's solve ends when
+    // the uploads of chunks 2..k+1 fit into the solves of chunks 1..k -- sizes c, 2c, 3.25c, 4.5c with c a quarter of VBA_CHUNK (384,
+    // 768, 1248, 1696 for 4096 windows: measured timeline in DESIGN.md section 6).  No chunk falls below 256 windows when the batch has
+    // that many: the kernel choice of a chunk (section "regime") then equals the batch's.
     std::vector<int> cbeg(1, 0);
     {
         static const int ramp = getenv("VBA_NO_RAMP") ? 0 : 1;
         int left = n;
-        const int c1 = std::max(256, chunk_max / 4), c2 = std::max(256, chunk_max / 2);
-        if (ramp && chunk_max >= 1024 && n >= c1 + c2 + 256) {
-            cbeg.push_back(c1);
-            cbeg.push_back(c1 + c2);
-            left = n - c1 - c2;
+        const int c = std::max(256, chunk_max / 4);
+        const int steps[4] = {c, 2 * c, 13 * c / 4, 9 * c / 2};
+        int cap = chunk_max;
+        if (ramp && chunk_max >= 1024) {
+            cap = steps[3];
+            for (int i = 0; i < 4 && left >= steps[i] + 256; i++) {
+                cbeg.push_back(cbeg.back() + steps[i]);
+                left -= steps[i];
+            }
         }
-        const int rest = std::max(1, (left + chunk_max - 1) / chunk_max);
+        const int rest = std::max(1, (left + cap - 1) / cap);
         const int base = cbeg.back();
-        for (int c = 1; c <= rest; c++) cbeg.push_back(base + (int)((long long)left * c / rest));
+        for (int q = 1; q <= rest; q++) cbeg.push_back(base + (int)((long long)left * q / rest));
     }
     const int n_lanes = std::max(1, std::min(h->opt_lanes > 0 ? h->opt_lanes : env_lanes, (int)cbeg.size() - 1));
     if (cbeg.size() == 2) {
@@ -1437,12 +1443,30 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
     };
     static const bool timing = getenv("VBA_TIMING") != nullptr;
     const double t_call = now_ms();
+    int up_turn = 0;
+    std::mutex up_mu;
+    std::condition_variable up_cv;
     auto work = [&](Handle* lane) {
         for (int c = next.fetch_add(1); c < n_chunks2 && !bad.load(); c = next.fetch_add(1)) {
             const int w0 = cbeg[c], cn = cbeg[c + 1] - w0;
-            if (cn <= 0) continue;
+            if (cn <= 0) {
+                { std::unique_lock<std::mutex> lk(up_mu); up_cv.wait(lk, [&] { return up_turn == c || bad.load(); }); up_turn = c + 1; }
+                up_cv.notify_all();
+                continue;
+            }
+            {   // uploads go one at a time, in chunk order: the first chunk gets every host thread and the whole link (lanes that
+                // start together share them and the device waits for the slower of two half-speed uploads), and a third lane
+                // can have chunk c+1 on the device before chunk c's solve ends
+                std::unique_lock<std::mutex> lk(up_mu);
+                up_cv.wait(lk, [&] { return up_turn == c || bad.load(); });
+            }
             const double t0 = now_ms();
-            int rc = do_upload(lane, cn, inout + w0);
+            int rc = bad.load() ? -1 : do_upload(lane, cn, inout + w0);
+            {
+                std::lock_guard<std::mutex> lk(up_mu);
+                up_turn = c + 1;
+            }
+            up_cv.notify_all();
             const double t1 = now_ms();
             if (!rc) rc = run_gated(lane);
             const double t2 = now_ms();
@@ -1451,6 +1475,7 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
             if (rc) {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!bad.exchange(1)) h->err = "vba_batch_solve, windows " + std::to_string(w0) + ".." + std::to_string(w0 + cn - 1) + ": " + lane->err;
+                up_cv.notify_all();   // lanes waiting for their upload turn see `bad`
                 return;
             }
         }
