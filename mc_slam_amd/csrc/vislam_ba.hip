@@ -881,10 +881,12 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
     };
     auto outer = [&](Group& g) {   // linearise + computeLambdaInit of one outer iteration
         enqueue_lin(h, LIN_FULL);
-        ProfScope ps(h, VBA_PROF_CONTROL);
         const int ngrp = (g.n_win >= 8) ? 8 * ((g.n_win + 7) / 8) : g.n_win;
-        // H_pp diagonal for computeLambdaInit (the block it writes into S is rewritten by the first trial)
-        hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, g.stream, g.B, h->max_free, 1);
+        {   // H_pp diagonal for computeLambdaInit (the block it writes into S is rewritten by the first trial): a Schur diagonal pass
+            ProfScope ps(h, VBA_PROF_SCHUR);
+            hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, g.stream, g.B, h->max_free, 1);
+        }
+        ProfScope ps(h, VBA_PROF_CONTROL);
         if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
         hipLaunchKernelGGL(k_ctrl_lm_outer, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
     };
@@ -899,6 +901,9 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
             ProfScope ps(h, VBA_PROF_CONTROL);
             if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
             hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(g.n_win), dim3(64), 0, g.stream, g.B, alive_dev, alive_mirror);
+        }
+        {
+            ProfScope ps(h, VBA_PROF_MISC);   // pop of a rejected step (with k_backup, the push)
             hipLaunchKernelGGL(k_restore, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
         }
     };
