@@ -209,10 +209,11 @@ typedef struct vba_frame_result {
 int vba_pose_optimize(void *handle, int32_t n_frames, vba_frame_problem *const *inout, vba_frame_result *const *out);
 
 /* ---- on-disk problem format: one vba_problem per file, so that windows recorded from a live system can
- * be replayed as fixtures.  Little-endian; header "VBAP" u32 version(=1) then the scalar fields in struct order
- * (i32 variant n_kf n_kf_free n_pt n_obs n_imu algo its_stage1 its_stage2 protocol robust has_kf_fix, f64 K[4] T_cb[7]
- * g_w[3] inv_bg_rw2 inv_ba_rw2 huber_vis huber_prv huber_bias chi2_th depth_min rho_min), then the arrays in struct order
- * with the sizes of the struct comments.  vba_problem_load allocates one block that vba_problem_free releases. */
+ * be replayed as fixtures.  Little-endian; header "VBAP" u32 version(=2) then the scalar fields in struct order
+ * (i32 variant n_kf n_kf_free n_pt n_obs n_imu algo its_stage1 its_stage2 protocol robust has_kf_fix solver reserved(0), f64 K[4]
+ * T_cb[7] g_w[3] inv_bg_rw2 inv_ba_rw2 huber_vis huber_prv huber_bias chi2_th depth_min rho_min), then the arrays in struct order
+ * with the sizes of the struct comments.  Version 1 (no solver / reserved ints; solver = VBA_SOLVER_LDLT) is still read.
+ * vba_problem_load allocates one block that vba_problem_free releases. */
 int vba_problem_save(const char *path, const vba_problem *p);
 int vba_problem_load(const char *path, vba_problem **out);
 void vba_problem_free(vba_problem *p);

@@ -314,18 +314,21 @@ class FrameResultBuf:
                            np.array(s.chi2_round[:]), np.array(s.marg_cov_inv[:]).reshape(15, 15), np.array(st.nav[:]))
 
 
-# ---- on-disk problem format "VBAP" v1 (include/vislam_ba.h: vba_problem_save / vba_problem_load) ----
-_HDR = np.dtype([("magic", "S4"), ("version", "<u4"), ("i", "<i4", 12), ("K", "<f8", 4), ("T_cb", "<f8", 7), ("g_w", "<f8", 3),
+# ---- on-disk problem format "VBAP" v2 (include/vislam_ba.h: vba_problem_save / vba_problem_load); v1 = the same without the
+# two ints `solver`, `reserved0` behind has_kf_fix: still read ----
+_HDR = np.dtype([("magic", "S4"), ("version", "<u4"), ("i", "<i4", 14), ("K", "<f8", 4), ("T_cb", "<f8", 7), ("g_w", "<f8", 3),
                  ("s", "<f8", 8)])
+_HDR1 = np.dtype([("magic", "S4"), ("version", "<u4"), ("i", "<i4", 12), ("K", "<f8", 4), ("T_cb", "<f8", 7), ("g_w", "<f8", 3),
+                  ("s", "<f8", 8)])
 
 
 def save_problem(path, p: "Problem"):
     """numpy twin of vba_problem_save (same bytes)."""
     s = p.as_struct()
     hd = np.zeros(1, dtype=_HDR)
-    hd["magic"] = b"VBAP"; hd["version"] = 1
+    hd["magic"] = b"VBAP"; hd["version"] = 2
     hd["i"] = [p.variant, p.n_kf, p.n_kf_free, p.n_pt, p.n_obs, p.n_imu, p.algo, p.its_stage1, p.its_stage2, p.protocol, p.robust,
-               1 if p.kf_fix is not None else 0]
+               1 if p.kf_fix is not None else 0, p.solver, 0]
     hd["K"], hd["T_cb"], hd["g_w"] = p.K, p.T_cb, p.g_w
     hd["s"] = [s.inv_bg_rw2, s.inv_ba_rw2, p.huber_vis, p.huber_prv, p.huber_bias, p.chi2_th, p.depth_min, p.rho_min]
     with open(path, "wb") as f:
@@ -340,11 +343,13 @@ def save_problem(path, p: "Problem"):
 def load_problem(path) -> "Problem":
     """numpy twin of vba_problem_load."""
     raw = open(path, "rb").read()
-    hd = np.frombuffer(raw[:_HDR.itemsize], dtype=_HDR)[0]
-    if hd["magic"] != b"VBAP" or hd["version"] != 1:
-        raise ValueError("not a VBAP v1 file")
-    variant, n_kf, n_free, n_pt, n_obs, n_imu, algo, its1, its2, proto, robust, has_fix = [int(x) for x in hd["i"]]
-    off = [_HDR.itemsize]
+    if len(raw) < 8 or raw[:4] != b"VBAP" or int(np.frombuffer(raw[4:8], "<u4")[0]) not in (1, 2):
+        raise ValueError("not a VBAP v1 / v2 file")
+    hdt = _HDR if int(np.frombuffer(raw[4:8], "<u4")[0]) == 2 else _HDR1
+    hd = np.frombuffer(raw[:hdt.itemsize], dtype=hdt)[0]
+    variant, n_kf, n_free, n_pt, n_obs, n_imu, algo, its1, its2, proto, robust, has_fix = [int(x) for x in hd["i"][:12]]
+    solver = int(hd["i"][12]) if hdt is _HDR else 0
+    off = [hdt.itemsize]
 
     def take(n, dt):
         a = np.frombuffer(raw, dtype=dt, count=n, offset=off[0]).copy()
@@ -362,4 +367,4 @@ def load_problem(path) -> "Problem":
                    kf_vel=vel, kf_bias=bias, pt_ref_kf=ref, T_cb=hd["T_cb"].copy(), g_w=hd["g_w"].copy(), imu_kf_i=ii, imu_kf_j=ij,
                    imu_meas=meas, imu_info_prv=info, algo=algo, its_stage1=its1, its_stage2=its2, chi2_th=float(sc[5]),
                    depth_min=float(sc[6]), rho_min=float(sc[7]), huber_vis=float(sc[2]), huber_prv=float(sc[3]), huber_bias=float(sc[4]),
-                   protocol=proto, robust=robust, kf_fix=fix)
+                   protocol=proto, robust=robust, kf_fix=fix, solver=solver)

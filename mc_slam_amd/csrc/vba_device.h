@@ -79,7 +79,7 @@ struct WinCtrl {
     int lm_restore;   // 1: the last trial was rejected, k_restore must pop the state
     int nbad;
     int lin_its;      // PCG iterations of all solves so far
-    int pad_;
+    int polls;        // terminate() polls of this window so far (test hook vba_debug_set_stop_after; oracle twin: stop_now)
     double lambda, ni;
     double chi_prev;  // GN: preChi2 of the last started iteration.  LM: currentChi
     double chi_ini;   // LM: iniChi

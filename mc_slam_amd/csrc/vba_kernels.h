@@ -67,10 +67,21 @@ struct Batch {
     unsigned char* out_outlier;
     double* out_chi2;
     double* dbg;  // 4 KiB scratch for diagnostic builds (in-kernel stamps); never read by the product path
+    int dbg_stop_after;  // test hook (vba_debug_set_stop_after): >= 0 -- the stop flag reads 1 from that poll of a window on; -1: off
 };
 
 #define LIN_FULL 0
 #define LIN_ERR 1
+
+// One read of the caller's stop flag by one window: g2o's terminate() before an iteration (sparse_optimizer.cpp:376), inside the
+// Levenberg-Marquardt trial loop (levenberg.cpp:149), and the bDoMore check between the stages (src/Optimizer.cpp:462-466).  The
+// polls of a window are counted from the first terminate() of its first optimize() so that a test can raise the flag at a chosen
+// poll (dbg_stop_after) -- the deterministic stand-in for LocalMapping::InterruptBA firing in the middle of a solve; the oracle
+// counts the same polls (stop_now in oracle/vba_oracle.c).  Thread 0 of the window's control workgroup only.
+DEVI int poll_stop(const Batch& B, WinCtrl& c) {
+    const int n = c.polls++;
+    return ((B.stop_word && *B.stop_word) || (B.dbg_stop_after >= 0 && n >= B.dbg_stop_after)) ? 1 : 0;
+}
 
 // window takes part in the current solve: GN -> while its optimize() loop runs; LM -> only while a trial is due
 DEVI bool win_on(const WinDesc& d, const WinCtrl& c) { return c.active && (d.algo == 0 || c.lm_need_trial); }
@@ -139,7 +150,7 @@ __global__ void __launch_bounds__(256) k_reset(Batch B) {
         c.robust_vis = (d.protocol == 1) ? (d.robust != 0) : 1;
         c.chol_fail = 0; c.aborted = 0;
         c.n_trace = 0; c.n_outliers = 0;
-        c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0; c.lin_its = 0;
+        c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0; c.lin_its = 0; c.polls = 0;
         c.lambda = 0; c.ni = 2; c.chi_prev = 0; c.chi_ini = 0;
         c.chi2_vis = c.chi2_prv = c.chi2_bias = 0;
     }
@@ -156,13 +167,14 @@ __global__ void __launch_bounds__(64) k_stage_clear(Batch B, int stage) {
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t < d.nS) B.var_act[d.vec0 + t] = 0;
     if (t == 0) {
-        const int stop = B.stop_word ? *B.stop_word : 0;
         if (stage == 0) {
+            const int stop = B.stop_word ? *B.stop_word : 0;   // the check on entry: not one of the counted polls
             if (stop) { c.aborted = 1; c.status = 2; c.active = 0; }  // src/Optimizer.cpp:453-455
             else c.active = 1;
         } else if (d.protocol == 1) {
             c.active = 0;  // BundleAdjustment: a single optimize(nIterations), no second stage (:3517, :835)
         } else {
+            const int stop = (c.status == 2) ? 1 : poll_stop(B, c);
             if (c.aborted || stop) {  // :462-470 -- skip stage 2
                 if (!c.aborted) { c.aborted = 1; c.status = 1; }
                 c.active = 0;
@@ -173,6 +185,7 @@ __global__ void __launch_bounds__(64) k_stage_clear(Batch B, int stage) {
         if (d.its[stage] <= 0) c.active = 0;  // optimize(0) runs nothing
         c.stage = stage; c.it = 0; c.chol_fail = 0;
         c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0; c.ni = 2;
+        c.lambda = 0;   // each optimize() starts its own lambda (computeLambdaInit at its iteration 0)
     }
 }
 
@@ -764,20 +777,24 @@ __global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval) {
     const double cur = window_chi2(B, d, sm);
     if (threadIdx.x != 0) return;
     const int st = c.stage, it = c.it;
-    if (c.n_trace < VBA_TRACE) c.trace[c.n_trace++] = cur;
     int active = 1;
     if (it >= 1) {
         c.its_done[st] = it;  // iterations 0..it-1 have run (++cjIterations)
+        // solver Fail (zero / non-finite pivot, linear_solver_eigen.h:105-111): the step was dropped (k_update), this optimize() ends
+        // (Terminate or Fail both leave the loop of sparse_optimizer.cpp:376), the window reports VBA_SOLVER_FAILED
         if (c.chol_fail) { c.status = -2; active = 0; }
         if (fabs(c.chi_prev - cur) < 1e-3) active = 0;  // Terminate, gauss_newton.cpp:97
     }
-    c.chi_prev = cur;
     if (final_eval || it >= d.its[st]) active = 0;
-    if (active && B.stop_word && *B.stop_word) {  // terminate() before each iteration, sparse_optimizer.cpp:376
+    if (active && poll_stop(B, c)) {  // terminate() before each iteration, sparse_optimizer.cpp:376
         c.aborted = 1;
         if (st == 0) c.status = 1;
         active = 0;
     }
+    // the trace holds preChi2 of iteration 0 and afterChi2 of every iteration run: an optimize() stopped before its first
+    // iteration has evaluated nothing
+    if ((it >= 1 || active) && c.n_trace < VBA_TRACE) c.trace[c.n_trace++] = cur;
+    c.chi_prev = cur;
     c.active = active;
     c.chol_fail = 0;
     c.it = it + 1;

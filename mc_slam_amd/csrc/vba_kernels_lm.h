@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_outer(Batch B) {
         mx = block_max<64>(mx, sm);
     }
     if (t != 0) return;
-    if (B.stop_word && *B.stop_word) {  // terminate() before the iteration
+    if (poll_stop(B, c)) {  // terminate() before the iteration
         c.aborted = 1;
         if (c.stage == 0) c.status = 1;
         c.active = 0;
@@ -549,8 +549,7 @@ __global__ void __launch_bounds__(64) k_ctrl_lm_trial(Batch B, int* alive, int* 
     c.chi_prev = cur;
     c.chol_fail = 0;
     const int qmax = ++c.lm_trial;
-    const int stop = (B.stop_word && *B.stop_word) ? 1 : 0;
-    if (rho < 0 && qmax < 10 && !stop) {
+    if (rho < 0 && qmax < 10 && !poll_stop(B, c)) {   // (short-circuit: terminate() is only called when a retry is due, levenberg.cpp:149)
         c.lm_need_trial = 1;
         if (atomicExch(alive_mirror, 1) == 0) __hip_atomic_store(alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // a posted store, not a PCIe atomic
         return;

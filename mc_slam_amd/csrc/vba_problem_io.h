@@ -1,4 +1,4 @@
-// vba_problem_io.h -- the on-disk problem format "VBAP" v1 (include/vislam_ba.h: vba_problem_save / _load / _free), plain C++17.
+// vba_problem_io.h -- the on-disk problem format "VBAP" v2 (v1 files still load) (include/vislam_ba.h: vba_problem_save / _load / _free), plain C++17.
 // Compiled into libvislam_ba.so (vislam_ba.hip) and into the sanitizer harness tests/host_structure_check.cpp.
 #pragma once
 #include "../../include/vislam_ba.h"
@@ -14,12 +14,21 @@
 // translation unit of a binary)
 // ---- on-disk problem format ----
 namespace vba_io {
-struct ProblemFileHeader {
+// v2 = v1 + two ints behind has_kf_fix: solver (VBA_SOLVER_*) and a reserved zero (keeps the doubles 8-byte aligned).  The
+// writer always writes v2; the reader takes both (a v1 file has solver = VBA_SOLVER_LDLT, the only solver there was).
+struct ProblemFileHeaderV1 {
     char magic[4];
     uint32_t version;
     int32_t variant, n_kf, n_kf_free, n_pt, n_obs, n_imu, algo, its_stage1, its_stage2, protocol, robust, has_kf_fix;
     double K[4], T_cb[7], g_w[3], inv_bg_rw2, inv_ba_rw2, huber_vis, huber_prv, huber_bias, chi2_th, depth_min, rho_min;
 };
+struct ProblemFileHeader {
+    char magic[4];
+    uint32_t version;
+    int32_t variant, n_kf, n_kf_free, n_pt, n_obs, n_imu, algo, its_stage1, its_stage2, protocol, robust, has_kf_fix, solver, reserved0;
+    double K[4], T_cb[7], g_w[3], inv_bg_rw2, inv_ba_rw2, huber_vis, huber_prv, huber_bias, chi2_th, depth_min, rho_min;
+};
+static_assert(sizeof(ProblemFileHeaderV1) == 56 + 22 * 8 && sizeof(ProblemFileHeader) == 64 + 22 * 8, "VBAP headers are packed");
 struct ArrSpec { size_t off; size_t bytes; };
 // the arrays of a vba_problem in struct order: (pointer member offset, byte size)
 inline std::vector<ArrSpec> problem_arrays(const ProblemFileHeader& hd) {
@@ -34,17 +43,18 @@ inline std::vector<ArrSpec> problem_arrays(const ProblemFileHeader& hd) {
     return v;
 }
 }  // namespace vba_io
-using vba_io::ProblemFileHeader; using vba_io::ArrSpec; using vba_io::problem_arrays;
+using vba_io::ProblemFileHeader; using vba_io::ProblemFileHeaderV1; using vba_io::ArrSpec; using vba_io::problem_arrays;
 
 int vba_problem_save(const char* path, const vba_problem* p) {
     if (!path || !p) return -1;
     ProblemFileHeader hd;
     std::memset(&hd, 0, sizeof hd);
     std::memcpy(hd.magic, "VBAP", 4);
-    hd.version = 1;
+    hd.version = 2;
     hd.variant = p->variant; hd.n_kf = p->n_kf; hd.n_kf_free = p->n_kf_free; hd.n_pt = p->n_pt; hd.n_obs = p->n_obs; hd.n_imu = p->n_imu;
     hd.algo = p->algo; hd.its_stage1 = p->its_stage1; hd.its_stage2 = p->its_stage2; hd.protocol = p->protocol; hd.robust = p->robust;
     hd.has_kf_fix = p->kf_fix ? 1 : 0;
+    hd.solver = p->solver;
     std::memcpy(hd.K, p->K, sizeof hd.K); std::memcpy(hd.T_cb, p->T_cb, sizeof hd.T_cb); std::memcpy(hd.g_w, p->g_w, sizeof hd.g_w);
     hd.inv_bg_rw2 = p->inv_bg_rw2; hd.inv_ba_rw2 = p->inv_ba_rw2; hd.huber_vis = p->huber_vis; hd.huber_prv = p->huber_prv;
     hd.huber_bias = p->huber_bias; hd.chi2_th = p->chi2_th; hd.depth_min = p->depth_min; hd.rho_min = p->rho_min;
@@ -69,14 +79,28 @@ int vba_problem_load(const char* path, vba_problem** out) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return -2;
     ProblemFileHeader hd;
-    if (std::fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, "VBAP", 4) != 0 || hd.version != 1 || hd.n_kf < 0 || hd.n_pt < 0 ||
-        hd.n_obs < 0 || hd.n_imu < 0 || hd.n_kf_free < 0 || hd.n_kf_free > hd.n_kf) {
+    std::memset(&hd, 0, sizeof hd);
+    size_t hd_bytes = sizeof hd;
+    bool hok = std::fread(&hd, 8, 1, f) == 1 && std::memcmp(hd.magic, "VBAP", 4) == 0 && (hd.version == 1 || hd.version == 2);
+    if (hok && hd.version == 2) hok = std::fread(reinterpret_cast<char*>(&hd) + 8, sizeof hd - 8, 1, f) == 1;
+    else if (hok) {   // v1: the same fields without solver / reserved0
+        ProblemFileHeaderV1 h1;
+        hd_bytes = sizeof h1;
+        hok = std::fread(reinterpret_cast<char*>(&h1) + 8, sizeof h1 - 8, 1, f) == 1;
+        if (hok) {
+            std::memcpy(&hd.variant, &h1.variant, 12 * sizeof(int32_t));
+            hd.solver = VBA_SOLVER_LDLT; hd.reserved0 = 0;
+            std::memcpy(hd.K, h1.K, 22 * sizeof(double));
+        }
+    }
+    if (!hok || hd.n_kf < 0 || hd.n_pt < 0 || hd.n_obs < 0 || hd.n_imu < 0 || hd.n_kf_free < 0 || hd.n_kf_free > hd.n_kf || hd.reserved0 != 0 ||
+        (hd.solver != VBA_SOLVER_LDLT && hd.solver != VBA_SOLVER_PCG)) {
         std::fclose(f);
         return -3;
     }
     const std::vector<ArrSpec> arrs = problem_arrays(hd);
     {   // the header must describe exactly the bytes that follow it: nothing is allocated for a file that lies about its sizes
-        unsigned long long want = sizeof hd;
+        unsigned long long want = hd_bytes;
         for (const ArrSpec& a : arrs) want += a.bytes;
         const long here = std::ftell(f);
         if (here < 0 || std::fseek(f, 0, SEEK_END) != 0) { std::fclose(f); return -3; }
@@ -90,6 +114,7 @@ int vba_problem_load(const char* path, vba_problem** out) {
     vba_problem* p = reinterpret_cast<vba_problem*>(blk);
     p->variant = hd.variant; p->n_kf = hd.n_kf; p->n_kf_free = hd.n_kf_free; p->n_pt = hd.n_pt; p->n_obs = hd.n_obs; p->n_imu = hd.n_imu;
     p->algo = hd.algo; p->its_stage1 = hd.its_stage1; p->its_stage2 = hd.its_stage2; p->protocol = hd.protocol; p->robust = hd.robust;
+    p->solver = hd.solver;
     std::memcpy(p->K, hd.K, sizeof hd.K); std::memcpy(p->T_cb, hd.T_cb, sizeof hd.T_cb); std::memcpy(p->g_w, hd.g_w, sizeof hd.g_w);
     p->inv_bg_rw2 = hd.inv_bg_rw2; p->inv_ba_rw2 = hd.inv_ba_rw2; p->huber_vis = hd.huber_vis; p->huber_prv = hd.huber_prv;
     p->huber_bias = hd.huber_bias; p->chi2_th = hd.chi2_th; p->depth_min = hd.depth_min; p->rho_min = hd.rho_min;

@@ -14,6 +14,7 @@
 #include "vba_structure.h"
 #include "vba_pcg.h"
 
+#include <sched.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -205,6 +206,7 @@ struct Handle {
     int opt_ll_min = 0;        // test hook: batch size from which the left-looking factorisation kernels are used (0: VBA_LL_MIN / 256)
     int opt_chunk = 0, opt_lanes = 0;  // > 0: chunk size / lanes of vba_batch_solve (test hook; defaults from VBA_CHUNK, VBA_LANES)
     int opt_streams = 0;  // > 0: window groups / streams for GN batches (test hook; default from VBA_STREAMS, 1)
+    int opt_stop_after = -1;  // test hook: >= 0 -- every window reads the stop flag as 1 from that terminate() poll on (poll_stop)
     std::vector<ProfEvt> evts;
     std::vector<hipEvent_t> evt_pool;
     size_t evt_used = 0;
@@ -337,6 +339,27 @@ void quat_to_R_host(const double* q, double* R) {
 }
 
 
+// Host threads of one handle (packing, structure build, scatter).  One process per GPU: the ranks of a node share its cores, so
+// the pool is this rank's share -- cores / LOCAL_WORLD_SIZE, at most 16, at least 2 -- unless VBA_UPLOAD_THREADS says otherwise
+// (mc_slam_amd/launch.py exports it per rank).  The cores are those the process may run on (sched_getaffinity: a rank pinned to its
+// share by the launcher counts only that share).
+int host_threads() {
+    static const int n = [] {
+        if (const char* e = getenv("VBA_UPLOAD_THREADS")) return std::max(1, atoi(e));
+        int cores = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) cores = CPU_COUNT(&set);
+        int local_world = 1;
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, atoi(e));
+        else if (const char* e2 = getenv("WORLD_SIZE")) local_world = std::max(1, atoi(e2));
+        // a rank the launcher pinned already sees only its share
+        const bool pinned = cores < (int)std::thread::hardware_concurrency();
+        const int share = pinned ? cores : std::max(1, cores / local_world);
+        return std::max(std::min(2, std::max(1, cores)), std::min(16, share));
+    }();
+    return n;
+}
 // >= this many windows: left-looking factorisation kernels, which never modify S (measured: the right-looking pair is faster
 // up to ~256 windows)
 bool use_left_looking(const Handle* h, int n) {
@@ -388,8 +411,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     // Per chunk of windows: (1) the per-window structure (item lists, IMU lists, symbolic tile factorisation: 0.7 ms for a C3
     // window) on a pool of host threads, (2) descriptors and offsets in window order on this thread, (3) the concatenated
     // arrays grown once, (4) the pool again copies every window's arrays to its offsets (2.2 MB per C3 window).
-    static const int n_threads = std::max(1, std::min(getenv("VBA_UPLOAD_THREADS") ? atoi(getenv("VBA_UPLOAD_THREADS")) : 16,
-                                                      (int)std::thread::hardware_concurrency()));
+    static const int n_threads = host_threads();
     const int chunk = 8 * n_threads;
     {   // one allocation per concatenated array instead of the doubling growth of std::vector
         size_t skf = 0, spt = 0, sobs = 0, simu = 0, spair = 0;
@@ -429,7 +451,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         const double ts0 = now_ms();
         run_pool(cn, [&](int q) {
             const vba_problem* Q = probs[chunk0 + q];
-            if (Q->variant < 0 || Q->variant > 2 || Q->n_kf_free <= 0 || Q->n_kf_free > Q->n_kf || Q->n_pt <= 0 || Q->n_obs <= 0) return;  // reported below
+            if (Q->variant < 0 || Q->variant > 2 || Q->n_kf_free <= 0 || Q->n_kf_free > Q->n_kf || Q->n_pt <= 0 || Q->n_obs <= 0 || Q->n_imu < 0) return;  // reported below
             if (build_structure(h, Q, sts[q])) bad.store(1);
         });
         t_struct += now_ms() - ts0;
@@ -447,7 +469,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
                 return fail(h, "inverse-depth landmarks are solved with Gauss-Newton only (as the reference does, src/Optimizer.cpp:136)");
             if (P->variant != VBA_VARIANT_PRV_IDP && P->algo != VBA_ALGO_LM)
                 return fail(h, "XYZ landmarks are solved with Levenberg-Marquardt only (as the reference does, src/Optimizer.cpp:1028,3928)");
-            if (P->n_kf_free <= 0 || P->n_kf_free > P->n_kf || P->n_pt < 0 || P->n_obs < 0) return fail(h, "bad sizes");
+            if (P->n_kf_free <= 0 || P->n_kf_free > P->n_kf || P->n_pt < 0 || P->n_obs < 0 || P->n_imu < 0) return fail(h, "bad sizes");
+            if (P->variant != VBA_VARIANT_SE3_XYZ && P->n_imu > 0 && (!P->imu_kf_i || !P->imu_kf_j || !P->imu_meas || !P->imu_info_prv))
+                return fail(h, "n_imu > 0 but an IMU array is NULL");
             if (P->n_pt == 0 || P->n_obs == 0) return fail(h, "a window without landmarks or observations has nothing to optimise");
             if (w > 0 && (P->variant != probs[0]->variant || P->algo != probs[0]->algo || P->solver != probs[0]->solver)) return fail(h, "mixed batch");
             if (P->solver != VBA_SOLVER_LDLT && P->solver != VBA_SOLVER_PCG) return fail(h, "unknown solver");
@@ -527,7 +551,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             max_kf = std::max(max_kf, d.n_kf);
             vec0 += d.nS;
             const int obs_blk = (d.n_obs + 63) / 64;
-            part0 += std::max(3 * std::max(d.n_part_lin, (d.n_pt + 63) / 64), 2 * obs_blk) + 2;
+            // chi2 / computeScale / max-diagonal partials of the linearisation and update kernels, the per-block sums of the final edge
+            // pass -- and, with PCG, one p'Sp partial per PCG_ROWS rows of the reduced system (k_pcg_matvec), which grows with the
+            // KEYFRAMES of the window, not with its landmarks
+            part0 += std::max(std::max(3 * std::max(d.n_part_lin, (d.n_pt + 63) / 64), 2 * obs_blk), pcg ? (d.np + PCG_ROWS - 1) / PCG_ROWS : 0) + 2;
             S_tot += (size_t)d.nS * d.nS;
             h->max_pt_blk = std::max(h->max_pt_blk, (d.n_pt + 63) / 64);
             h->max_lin_blk = std::max(h->max_lin_blk, d.n_part_lin);
@@ -741,7 +768,21 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
 }
 
 // ---- the launch schedule ------------------------------------------------------------------------------
-void enqueue_solve_iteration(Handle* h) {
+// g2o polls forceStopFlag before every iteration (sparse_optimizer.cpp:376).  The device reads a pinned word; whoever enqueues or
+// waits on the host copies the caller's flag into it -- at every iteration it enqueues and while it waits for the device.
+inline void forward_stop(Handle* h, const volatile int* stop_flag) {
+    if (stop_flag && *stop_flag) *h->stop_host = 1;
+}
+hipError_t wait_event_forwarding(Handle* h, hipEvent_t ev, const volatile int* stop_flag) {
+    if (!stop_flag) return hipEventSynchronize(ev);
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        forward_stop(h, stop_flag);
+        std::this_thread::yield();
+    }
+}
+void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr) {
     const Batch& B = h->B;
     const int n = h->n_win;         // windows of this group: grid sizes
     const int rn = h->regime_n;     // windows of the batch: kernel choice
@@ -778,9 +819,10 @@ void enqueue_solve_iteration(Handle* h) {
         const int max_batches = (20 * h->max_nS + 50) / per_batch + 2;
         for (int b = 0; b < max_batches; b++) {
             if (b >= 2) {
-                (void)hipEventSynchronize(ev[b - 2]);
+                (void)wait_event_forwarding(h, ev[b - 2], stop_flag);
                 if (ring[(b - 2) % RING] == 0) break;   // every window had converged (or broken down) by the end of batch b-2
             }
+            forward_stop(h, stop_flag);
             ring[b % RING] = 0;
             for (int it = 0; it < per_batch; it++) {
                 hipLaunchKernelGGL(k_pcg_matvec, dim3(row_blocks, n), dim3(256), 0, h->stream, B);
@@ -895,7 +937,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
             ProfScope ps(h, VBA_PROF_MISC);
             hipLaunchKernelGGL(k_backup, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
         }
-        enqueue_solve_iteration(h);
+        enqueue_solve_iteration(h, stop_flag);
         enqueue_lin(h, LIN_ERR_TRIAL);
         {
             ProfScope ps(h, VBA_PROF_CONTROL);
@@ -934,12 +976,12 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
                     Group& g = groups[gi];
                     if (g.dead) continue;
                     if (j >= 2) {
-                        if (hipEventSynchronize(ev[gi][j - 2]) != hipSuccess) { rc = -1; break; }
+                        if (wait_event_forwarding(h, ev[gi][j - 2], stop_flag) != hipSuccess) { rc = -1; break; }
                         if (g.alive[(j - 2) % RING] == 0) { g.dead = true; continue; }   // nobody went on after slot group j-2
                     }
                     any = true;
                     use(g);
-                    if (stop_flag && *stop_flag) *h->stop_host = 1;
+                    forward_stop(h, stop_flag);
                     g.alive[j % RING] = 0;   // the word's previous user (group j - RING) was consumed long ago
                     int* alive_dev = h->stop_dev + (g.alive - h->stop_host) + (j % RING);
                     outer(g);
@@ -1002,11 +1044,12 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
                     Group& g = groups[gi];
                     if (g.dead) continue;
                     if (pace && it >= 2) {
-                        (void)hipEventSynchronize(ev[gi][it - 2]);
+                        (void)wait_event_forwarding(h, ev[gi][it - 2], stop_flag);
                         if (g.alive[stage * 32 + it - 2] == 0) { g.dead = true; continue; }
                     }
                     any = true;
                     use(g);
+                    forward_stop(h, stop_flag);   // InterruptBA raised while the host paces itself: the device sees it at its next poll
                     enqueue_lin(h, LIN_FULL);
                     {
                         ProfScope ps(h, VBA_PROF_CONTROL);
@@ -1017,7 +1060,7 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
                         ev[gi][it] = get_evt(h);
                         (void)hipEventRecord(ev[gi][it], g.stream);
                     }
-                    enqueue_solve_iteration(h);
+                    enqueue_solve_iteration(h, stop_flag);
                 }
                 if (!any) break;
             }
@@ -1053,6 +1096,7 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     const double t_run0 = timing ? now_ms() : 0.0;
     if (!h->uploaded) return fail(h, "vba_batch_run before vba_batch_upload");
     HIPCHK(h, hipSetDevice(h->device));
+    h->B.dbg_stop_after = h->opt_stop_after;
     const Batch B = h->B;
     const int n = h->n_win;
     *h->stop_host = (stop_flag && *stop_flag) ? 1 : 0;
@@ -1236,7 +1280,7 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
         }
     };
     {
-        const int nt = staged ? std::max(1, std::min(std::min(16, (int)std::thread::hardware_concurrency()), n / 8)) : 1;
+        const int nt = staged ? std::max(1, std::min(host_threads(), n / 8)) : 1;
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; t++) pool.emplace_back(work);
         work();
@@ -1420,6 +1464,7 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
         Handle* l = nullptr;
         if (make_handle(h->device, h, &l) != 0) return fail(h, "vba_batch_solve: could not create a lane");
         l->opt_ll_min = h->opt_ll_min;
+        l->opt_stop_after = h->opt_stop_after;
         h->lanes.push_back(l);
     }
     const int n_chunks2 = (int)cbeg.size() - 1;
@@ -1478,8 +1523,15 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
             if (!rc) rc = do_download(lane, cn, inout + w0, out ? out + w0 : nullptr);
             if (timing) fprintf(stderr, "[vba_batch_solve] chunk %d (%d windows): upload %.1f..%.1f  run ..%.1f  download ..%.1f ms\n", c, cn, t0 - t_call, t1 - t_call, t2 - t_call, now_ms() - t_call);
             if (rc) {
-                std::lock_guard<std::mutex> lk(mu);
-                if (!bad.exchange(1)) h->err = "vba_batch_solve, windows " + std::to_string(w0) + ".." + std::to_string(w0 + cn - 1) + ": " + lane->err;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!bad.load()) h->err = "vba_batch_solve, windows " + std::to_string(w0) + ".." + std::to_string(w0 + cn - 1) + ": " + lane->err;
+                }
+                {   // `bad` is set and announced under the mutex the waiting lanes evaluate their predicate under: a lane that has just
+                    // found `up_turn == c || bad` false cannot miss this wake-up
+                    std::lock_guard<std::mutex> lk(up_mu);
+                    bad.store(1);
+                }
                 up_cv.notify_all();   // lanes waiting for their upload turn see `bad`
                 return;
             }
@@ -1501,10 +1553,20 @@ int vba_debug_copy(void* handle, int32_t buf_id, uint64_t offset_bytes, void* ds
     (void)hipSetDevice(h->device);
     return hipMemcpy(dst, reinterpret_cast<char*>(b.ptr()) + offset_bytes, nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
+// test hook (ctypes): the size of the host thread pool of a handle in this process (cores of this rank's share, see host_threads)
+int vba_debug_host_threads() { return host_threads(); }
 int vba_debug_set_streams(void* handle, int32_t n) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
     h->opt_streams = n;
+    return 0;
+}
+// every window reads the stop flag as 1 from its n-th terminate() poll on (n < 0: off); the oracle's vba_oracle_solve_ex counts alike
+int vba_debug_set_stop_after(void* handle, int32_t n) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    h->opt_stop_after = n;
+    for (Handle* l : h->lanes) l->opt_stop_after = n;
     return 0;
 }
 int vba_debug_set_lin_fallback(void* handle, int32_t on) {
@@ -1681,7 +1743,7 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
         d.hub_bias = (double)(float)std::sqrt(16.812); d.hub_mono = (double)(float)std::sqrt(5.991);
     };
     {
-        const int nt = (n_frames >= 256) ? std::max(1, std::min(8, (int)std::thread::hardware_concurrency())) : 1;
+        const int nt = (n_frames >= 256) ? std::max(1, std::min(8, host_threads())) : 1;
         std::atomic<int> next(0);
         auto work = [&]() { for (int f = next.fetch_add(1); f < n_frames; f = next.fetch_add(1)) pack(f); };
         std::vector<std::thread> pool;

@@ -154,14 +154,16 @@ def prv_information(cov_pvphi):
 
 # ---------------------------------------------------------------- the generator
 def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_obs=30000, seed=3,
-                kf_dt=0.25, imu_dt=0.005, outlier_frac=0.05, algo=None, noise=True, init_scale=1.0):
+                kf_dt=0.25, imu_dt=0.005, outlier_frac=0.05, algo=None, noise=True, init_scale=1.0, pix_noise=1.0):
     """Build one synthetic local-BA window.
 
     n_kf keyframes in time order t0..; the FIRST n_fixed in time are fixed (the window's predecessor and,
     if n_fixed > 1, older co-observers).  In the returned Problem free keyframes come first (time order),
     fixed ones after.  n_obs counts reprojection EDGES (variant 2: the reference keyframe's own
     observation is not an edge, src/Optimizer.cpp:395-398).  init_scale multiplies the perturbation of the initial
-    guess (poses, velocities, depths / points): < 1 = a window that starts close to its optimum.
+    guess (poses, velocities, depths / points): < 1 = a window that starts close to its optimum.  pix_noise multiplies the
+    keypoint noise (1 = one pixel at octave 0, ORB-SLAM's model); the information matrices are not changed, so chi2 scales with
+    pix_noise^2 and the absolute |dchi2| < 1e-3 stop of Gauss-Newton is reached after fewer iterations for sharp features.
     """
     rng = np.random.default_rng(seed)
     R_bc, p_bc, T_cb = extrinsics()
@@ -276,7 +278,7 @@ def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_ob
         w = np.float32(1.0 / (1.2 ** (2 * octave))).astype(np.float64)
         out = np.zeros(n, dtype=bool)
         if noise:
-            uv = uv + rng.normal(0, 1, (n, 2)) * (1.2 ** octave)[:, None]
+            uv = uv + rng.normal(0, 1, (n, 2)) * (1.2 ** octave)[:, None] * pix_noise
             out = rng.uniform(size=n) < outlier_frac
             uv = uv + out[:, None] * rng.choice([-1.0, 1.0], (n, 2)) * rng.uniform(15, 25, (n, 2))
         return np.float32(uv).astype(np.float64), w, out, Pc[:, 2]
@@ -373,12 +375,23 @@ def config_c3(seed=3, n_kf=50, n_pt=5000, n_obs=30000):
 
 def config_c3_ragged(seed=3):
     """A LocalBAPRVIDP window whose size is drawn around BASELINE configs[2]: 40..60 keyframes (mean 50), 100 landmarks per
-    keyframe, 6 edges per landmark (mean 5 000 / 30 000), 2..8 % gross outliers -- so that the windows of a batch differ in
-    size, co-visibility and iteration counts the way the windows of a real session do (the sizes depend on the seed only)."""
+    keyframe, 6 edges per landmark (mean 5 000 / 30 000) -- so that the windows of a batch differ in size, co-visibility and
+    ITERATION COUNTS the way the windows of a real session do (everything depends on the seed only).  Three kinds of window:
+    60 %: one-pixel keypoint noise and 2..8 % gross outliers (the window still holds the mismatches of its newest keyframes):
+          Gauss-Newton runs 5 + 3 iterations;
+    20 %: no gross outliers left (earlier passes erased them), keypoint noise 0.3 px: 4..5 + 2;
+    20 %: no gross outliers, 0.1 px: 3..4 + 1 (the |dchi2| < 1e-3 stop is absolute, so it comes earlier where chi2 is small)."""
     r = np.random.default_rng(1000003 * seed + 17)
     n_kf = int(r.integers(40, 61))
+    outlier_frac = float(r.uniform(0.02, 0.08))
+    kind = float(r.uniform())
+    pix = 1.0
+    if kind >= 0.8:
+        outlier_frac, pix = 0.0, 0.1
+    elif kind >= 0.6:
+        outlier_frac, pix = 0.0, 0.3
     return make_window(abi.VARIANT_PRV_IDP, n_kf=n_kf, n_fixed=1, n_pt=100 * n_kf, n_obs=600 * n_kf, seed=seed,
-                       outlier_frac=float(r.uniform(0.02, 0.08)))
+                       outlier_frac=outlier_frac, pix_noise=pix)
 
 
 def config_c4(seed=4):

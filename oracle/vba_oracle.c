@@ -756,6 +756,7 @@ typedef struct {
     unsigned char *var_act; /* [np] pose scalar variable belongs to an active vertex */
     const unsigned char *fix; /* P->kf_fix or NULL: per-vertex setFixed() of listed-free keyframes */
     int imu_robust;         /* Huber on the PRV / bias edges (always, except bRobust = false in global BA) */
+    int polls, stop_after;  /* test hook (vba_oracle_solve_ex): terminate() polls so far; >= 0: the flag reads 1 from that poll on */
     int solver_perm;        /* 1: order V/Bias blocks first for the skyline LDLT */
     int *perm;              /* [np] */
     double *Lwork;          /* [np*np] */
@@ -1224,22 +1225,35 @@ static void trace(vba_result *out, double v) {
     if (out->n_trace < VBA_TRACE_MAX) out->chi2_trace[out->n_trace++] = v;
 }
 
+/* One read of g2o's forceStopFlag: SparseOptimizer::terminate() (sparse_optimizer.cpp:376, levenberg.cpp:149) and the
+ * bDoMore check between the stages (src/Optimizer.cpp:462-466).  The polls are counted from the first terminate() of the first
+ * optimize(); with stop_after >= 0 the flag reads 1 from poll number stop_after on -- the deterministic stand-in for
+ * LocalMapping::InterruptBA firing in the middle of a solve (the GPU backend has the same counter: vba_debug_set_stop_after). */
+static int stop_now(ctx *c, const volatile int *stop) {
+    const int n = c->polls++;
+    return (stop && *stop) || (c->stop_after >= 0 && n >= c->stop_after);
+}
+
 /* SparseOptimizer::optimize (sparse_optimizer.cpp:354-419) driving OptimizationAlgorithmGaussNewton::solve
  * (optimization_algorithm_gauss_newton.cpp:50-105).  Returns cjIterations; *failed set on solver Fail. */
 static int optimize_gn(ctx *c, int iterations, const volatile int *stop, vba_result *out, int *failed) {
     int cj = 0;
-    for (int i = 0; i < iterations && !(stop && *stop); i++) {
+    for (int i = 0; i < iterations && !stop_now(c, stop); i++) {
         const double pre = compute_errors(c);
         if (i == 0) trace(out, pre);
         build_system(c);
         const int ok = solve_system(c, 0.0);
-        /* on Fail g2o applies whatever x held before (stale); here the step is dropped (DESIGN.md deviation) */
+        /* on Fail (zero / non-finite pivot, linear_solver_eigen.h:105-111) g2o applies whatever x held before (stale); here the
+         * step is dropped (DESIGN.md deviation) -- the chi2 then cannot move, so the Terminate test below would hide the failure:
+         * it is recorded first (status VBA_SOLVER_FAILED), and this optimize() ends either way (Terminate or Fail: both leave the
+         * loop of sparse_optimizer.cpp:376) */
         if (ok) apply_update(c);
+        else *failed = 1;
         const double post = compute_errors(c);
         trace(out, post);
         ++cj;
         if (fabs(pre - post) < 1e-3) break; /* Terminate */
-        if (!ok) { *failed = 1; break; }
+        if (!ok) break;
     }
     return cj;
 }
@@ -1249,7 +1263,7 @@ static int optimize_lm(ctx *c, int iterations, const volatile int *stop, vba_res
     int cj = 0, nBad = 0;
     double lambda = 0, ni = 2;
     (void)failed;
-    for (int it = 0; it < iterations && !(stop && *stop); it++) {
+    for (int it = 0; it < iterations && !stop_now(c, stop); it++) {
         double cur = compute_errors(c);
         double tempChi = cur;
         const double iniChi = cur;
@@ -1292,7 +1306,7 @@ static int optimize_lm(ctx *c, int iterations, const volatile int *stop, vba_res
                 pop_state(c);
             }
             qmax++;
-        } while (rho < 0 && qmax < 10 && !(stop && *stop));
+        } while (rho < 0 && qmax < 10 && !stop_now(c, stop));
         trace(out, cur);
         ++cj;
         if (qmax == 10 || rho == 0) break;
@@ -1311,7 +1325,12 @@ static void *xcalloc(size_t n, size_t sz) {
 }
 
 /* solver_mode: 0 = LDL^T in natural (g2o vertex-id) order, 1 = V/Bias-first order (fewer flops; timed baseline) */
+int vba_oracle_solve_ex(vba_problem *P, vba_result *out, const volatile int *stop, int solver_mode, int stop_after);
 int vba_oracle_solve(vba_problem *P, vba_result *out, const volatile int *stop, int solver_mode) {
+    return vba_oracle_solve_ex(P, out, stop, solver_mode, -1);
+}
+/* stop_after: test hook, see stop_now (-1: only the caller's flag) */
+int vba_oracle_solve_ex(vba_problem *P, vba_result *out, const volatile int *stop, int solver_mode, int stop_after) {
     out->chi2_vis = out->chi2_prv = out->chi2_bias = 0;
     out->its_done[0] = out->its_done[1] = 0;
     out->n_outliers = 0;
@@ -1324,6 +1343,7 @@ int vba_oracle_solve(vba_problem *P, vba_result *out, const volatile int *stop, 
     memset(c, 0, sizeof C);
     c->P = P;
     c->variant = P->variant;
+    c->polls = 0; c->stop_after = stop_after;
     c->nkf = P->n_kf; c->nfree = P->n_kf_free; c->npt = P->n_pt; c->nobs = P->n_obs;
     c->fix = P->kf_fix; c->imu_robust = !(P->protocol == VBA_PROTO_SINGLE && !P->robust);
     c->nimu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
@@ -1374,7 +1394,7 @@ int vba_oracle_solve(vba_problem *P, vba_result *out, const volatile int *stop, 
     init_active(c);
     out->its_done[0] = (P->algo == VBA_ALGO_LM) ? optimize_lm(c, P->its_stage1, stop, out, &failed)
                                                  : optimize_gn(c, P->its_stage1, stop, out, &failed);
-    int do_more = !single && !(stop && *stop); /* :462-466 */
+    int do_more = !single && !stop_now(c, stop); /* :462-466 */
     if (!do_more && !single) out->status = VBA_ABORTED_AFTER_STAGE1;
     if (do_more) {
         /* outlier pass :475-490 (reads e->chi2() from the stored _error, recomputes the depth) */

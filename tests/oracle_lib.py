@@ -26,6 +26,8 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.vba_oracle_solve.argtypes = [C.POINTER(abi.vba_problem), C.POINTER(abi.vba_result), C.c_void_p, C.c_int]
         _lib.vba_oracle_solve.restype = C.c_int
+        _lib.vba_oracle_solve_ex.argtypes = [C.POINTER(abi.vba_problem), C.POINTER(abi.vba_result), C.c_void_p, C.c_int, C.c_int]
+        _lib.vba_oracle_solve_ex.restype = C.c_int
         _lib.vba_oracle_linearize.argtypes = [C.POINTER(abi.vba_problem), C.c_double, _pd, _pd, _pd, _pd]
         _lib.vba_oracle_linearize.restype = C.c_int
     return _lib
@@ -35,15 +37,64 @@ def P(a):
     return a.ctypes.data_as(_pd)
 
 
-def solve(prob: abi.Problem, solver_mode=0, stop=None):
-    """Runs the oracle on a COPY of prob; returns (solved problem copy, Result)."""
+_native = None
+
+
+def timing_lib():
+    """The oracle for bench.py's cpu_baseline leg: compiled ON THIS MACHINE with `-O3 -march=native`, the flags of the reference
+    (CMakeLists.txt:19, Thirdparty/g2o/CMakeLists.txt:61), into a temporary directory -- the in-tree
+    libvba_oracle.so is built `-march=x86-64-v3` so that it runs on whatever box the snapshot lands on.  Falls back to the portable
+    build when no compiler is at hand.  Returns (CDLL, "native" | "x86-64-v3")."""
+    global _native
+    if _native is not None:
+        return _native
+    import hashlib
+    import tempfile
+    src = os.path.join(_ROOT, "oracle", "vba_oracle.c")
+    tag = hashlib.sha256(open(src, "rb").read()).hexdigest()[:12]
+    out = os.path.join(tempfile.gettempdir(), "vba_oracle_native_%s_%d.so" % (tag, os.getuid()))
+    try:
+        if not os.path.exists(out):
+            tmp = out + ".%d.tmp" % os.getpid()
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-fno-fast-math", "-shared",
+                                   "-I", os.path.join(_ROOT, "include"), "-o", tmp, src, "-lm"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            os.replace(tmp, out)
+        l = C.CDLL(out)
+        l.vba_oracle_solve_ex.argtypes = [C.POINTER(abi.vba_problem), C.POINTER(abi.vba_result), C.c_void_p, C.c_int, C.c_int]
+        l.vba_oracle_solve_ex.restype = C.c_int
+        _native = (l, "native")
+    except Exception:
+        _native = (lib(), "x86-64-v3")
+    return _native
+
+
+def solve_timed(prob: abi.Problem, solver_mode=0):
+    """one solve with the timing build: (seconds, Result) -- the clock brackets the C call only"""
+    import time
+    l, _ = timing_lib()
+    q = prob.copy()
+    s = q.as_struct()
+    rb = abi.ResultBuf(q.n_obs)
+    t0 = time.perf_counter()
+    rc = l.vba_oracle_solve_ex(C.byref(s), C.byref(rb.s), None, solver_mode, -1)
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError("oracle failed rc=%d" % rc)
+    return dt, q, rb.get()
+
+
+def solve(prob: abi.Problem, solver_mode=0, stop=None, stop_after=-1):
+    """Runs the oracle on a COPY of prob; returns (solved problem copy, Result).
+    stop_after >= 0: the stop flag reads 1 from that terminate() poll on (counted from the first poll of the first optimize();
+    the bDoMore check between the stages counts) -- the twin of the backend's vba_debug_set_stop_after."""
     q = prob.copy()
     s = q.as_struct()
     rb = abi.ResultBuf(q.n_obs)
     stop_ptr = None
     if stop is not None:
         stop_ptr = C.cast(C.pointer(stop), C.c_void_p)
-    rc = lib().vba_oracle_solve(C.byref(s), C.byref(rb.s), stop_ptr, solver_mode)
+    rc = lib().vba_oracle_solve_ex(C.byref(s), C.byref(rb.s), stop_ptr, solver_mode, int(stop_after))
     if rc != 0:
         raise RuntimeError("oracle failed rc=%d" % rc)
     return q, rb.get()

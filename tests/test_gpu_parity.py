@@ -339,9 +339,9 @@ def test_empty_and_degenerate_inputs(ba):
 
 
 def test_c4_full_size_properties(ba, oracle):
-    """BASELINE configs[3]: 200 KF / 50k landmarks / 500k EdgePRIDP + IMU chain.  The oracle's dense solve would take
-    minutes at this size, so the full-size check uses size-independent properties, each against the oracle's
-    residual functions (cheap at any size):
+    """BASELINE configs[3]: 200 KF / 50k landmarks / 500k EdgePRIDP + IMU chain.  (The comparison with the oracle's own solve of
+    this window is tests/test_gpu_protocol_edges.py::test_c4_full_size_matches_oracle.)  Size-independent properties, each
+    against the oracle's residual functions:
       * the first traced value is the robust chi2 of the uploaded state;
       * every edge the backend keeps as an inlier carries the chi2 the oracle computes at the returned state;
       * the IMU chi2 sums match the oracle's at the returned state;
@@ -429,7 +429,7 @@ def test_global_ba_protocol_matches_oracle(ba, oracle, variant, robust, seed):
 
 
 def test_global_ba_map_scale_properties(ba, oracle):
-    """A 150-keyframe map (n_p = 2250: the oracle's dense solve would take minutes): size-independent properties --
+    """A 150-keyframe map (n_p = 2250; against the oracle's own solve: test_gpu_protocol_edges.py): size-independent properties --
     the robust cost the solver reports equals the oracle's residual evaluation at the returned state, it went down,
     the gauge keyframe did not move, reruns are bit-identical."""
     p = _gba(abi.VARIANT_PRV_XYZ, 1, n_kf=150, n_pt=12000, n_obs=80000, seed=60, its=10)

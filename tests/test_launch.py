@@ -38,6 +38,71 @@ def test_rank_env():
     assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_ranks_share_the_host_cores_and_never_oversubscribe_them():
+    """8 ranks on a 64-core node: disjoint contiguous shares of 8 cores, a host pool of 8 threads each (the backend's default of 16
+    per handle would put 128 packing threads on 64 cores); one rank keeps everything and gets no pinning variables"""
+    cores = list(range(64))
+    envs = [launch.rank_env({}, r, 8, 1, cpus=cores) for r in range(8)]
+    shares = [[int(c) for c in e["VBA_RANK_CPUS"].split(",")] for e in envs]
+    assert sorted(sum(shares, [])) == cores and all(len(s) == 8 and s == list(range(s[0], s[0] + 8)) for s in shares)
+    assert sum(int(e["VBA_UPLOAD_THREADS"]) for e in envs) <= len(cores)
+    assert all(e["LOCAL_WORLD_SIZE"] == "8" for e in envs)
+    e1 = launch.rank_env({}, 0, 1, 1, cpus=cores)
+    assert "VBA_RANK_CPUS" not in e1 and "VBA_UPLOAD_THREADS" not in e1
+    # the caller's own settings win
+    assert launch.rank_env({"VBA_UPLOAD_THREADS": "3"}, 1, 2, 1, cpus=cores)["VBA_UPLOAD_THREADS"] == "3"
+    # fewer cores than ranks: every rank still gets a core, at least two threads
+    tiny = [launch.rank_env({}, r, 8, 1, cpus=[0, 1, 2]) for r in range(8)]
+    assert all(len(e["VBA_RANK_CPUS"].split(",")) == 1 and e["VBA_UPLOAD_THREADS"] == "2" for e in tiny)
+    # a node with 192 cores: the pool stops at 16 threads per rank
+    assert launch.rank_env({}, 0, 8, 1, cpus=range(192))["VBA_UPLOAD_THREADS"] == "16"
+
+
+CHILD_PIN = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["REPO_ROOT"])
+from mc_slam_amd import launch
+cpus = launch.pin_rank(os.environ)
+import ctypes
+lib = ctypes.CDLL(os.path.join(os.environ["REPO_ROOT"], "mc_slam_amd", "csrc", "libvislam_ba.so"))
+sys.stderr.write(json.dumps({"rank": int(os.environ["RANK"]), "cpus": cpus, "affinity": sorted(os.sched_getaffinity(0)),
+                             "threads_env": os.environ.get("VBA_UPLOAD_THREADS"), "threads_lib": lib.vba_debug_host_threads()}) + "\n")
+print(json.dumps({"ok": 1}))
+"""
+
+
+def test_spawned_ranks_pin_themselves_and_the_library_sizes_its_pool(tmp_path):
+    """end to end on CPU: 2 ranks started by the launcher bind themselves to disjoint halves of the allowed cores before anything
+    else runs, and libvislam_ba.so (no GPU call: the hook only reads the environment) reports the pool the launcher asked for"""
+    f = tmp_path / "child.py"
+    f.write_text(CHILD_PIN)
+    env = dict(os.environ)
+    env["REPO_ROOT"] = ROOT
+    env.pop("VBA_UPLOAD_THREADS", None); env.pop("VBA_RANK_CPUS", None)
+    out, err = io.StringIO(), io.StringIO()
+    assert launch.spawn_ranks(2, [sys.executable, str(f)], env=env, out=out, err=err) == 0
+    rows = sorted((json.loads(l.split("] ", 1)[1]) for l in err.getvalue().splitlines() if l.startswith("[rank") and "{" in l), key=lambda r: r["rank"])
+    assert len(rows) == 2
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) >= 2:
+        assert not set(rows[0]["affinity"]) & set(rows[1]["affinity"])
+        assert sorted(rows[0]["affinity"] + rows[1]["affinity"]) == allowed[:2 * (len(allowed) // 2)]
+    for r in rows:
+        assert r["cpus"] == r["affinity"] and int(r["threads_env"]) == r["threads_lib"] == max(2, min(16, len(r["affinity"])))
+
+
+def test_library_pool_follows_local_world_size_without_the_launcher():
+    """under torchrun nobody exports VBA_UPLOAD_THREADS: the library divides the cores it may run on by LOCAL_WORLD_SIZE itself"""
+    code = ("import ctypes, os; l = ctypes.CDLL(os.path.join(%r, 'mc_slam_amd', 'csrc', 'libvislam_ba.so')); print(l.vba_debug_host_threads())" % ROOT)
+    n = len(os.sched_getaffinity(0))
+    for world, want in ((1, max(min(2, n), min(16, n))), (4, max(min(2, n), min(16, max(1, n // 4))))):
+        env = dict(os.environ)
+        env.pop("VBA_UPLOAD_THREADS", None)
+        env["LOCAL_WORLD_SIZE"] = str(world)
+        got = int(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip())
+        assert got == want, (world, got, want)
+
+
 def test_spawn_relays_rank0_and_forwards_stderr(tmp_path):
     f = tmp_path / "child.py"
     f.write_text(CHILD_OK)

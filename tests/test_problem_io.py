@@ -45,6 +45,32 @@ def test_c_and_numpy_writers_agree_and_round_trip(tmp_path, variant):
     assert (r.kf_fix is None) == (p.kf_fix is None)
 
 
+def test_solver_field_round_trips_and_v1_files_still_load(tmp_path):
+    """version 2 of the format carries vba_problem.solver; a version-1 file (no solver field) loads as VBA_SOLVER_LDLT"""
+    p = synth.make_window(2, n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31)
+    p.solver = abi.SOLVER_PCG
+    l = _lib()
+    a, b, v1 = str(tmp_path / "a.vbap"), str(tmp_path / "b.vbap"), str(tmp_path / "v1.vbap")
+    s = p.as_struct()
+    assert l.vba_problem_save(a.encode(), C.byref(s)) == 0
+    abi.save_problem(b, p)
+    assert filecmp.cmp(a, b, shallow=False)
+    q = C.POINTER(abi.vba_problem)()
+    assert l.vba_problem_load(a.encode(), C.byref(q)) == 0 and q.contents.solver == abi.SOLVER_PCG
+    l.vba_problem_free(q)
+    assert abi.load_problem(a).solver == abi.SOLVER_PCG
+    # the same window as a version-1 file: header without the two trailing ints
+    raw = open(a, "rb").read()
+    open(v1, "wb").write(raw[:4] + (1).to_bytes(4, "little") + raw[8:56] + raw[64:])
+    q = C.POINTER(abi.vba_problem)()
+    assert l.vba_problem_load(v1.encode(), C.byref(q)) == 0
+    assert q.contents.solver == abi.SOLVER_LDLT and q.contents.n_obs == p.n_obs and q.contents.huber_vis == p.huber_vis
+    l.vba_problem_free(q)
+    r = abi.load_problem(v1)
+    assert r.solver == abi.SOLVER_LDLT
+    np.testing.assert_array_equal(r.obs_uv, p.obs_uv)
+
+
 def test_reader_rejects_damaged_files(tmp_path):
     p = synth.make_window(2, n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31)
     l = _lib()
@@ -52,7 +78,7 @@ def test_reader_rejects_damaged_files(tmp_path):
     abi.save_problem(a, p)
     raw = open(a, "rb").read()
     q = C.POINTER(abi.vba_problem)()
-    for name, data in (("trunc", raw[:-9]), ("extra", raw + b"x"), ("magic", b"XBAP" + raw[4:]), ("ver", raw[:4] + b"\\x02\\x00\\x00\\x00" + raw[8:])):
+    for name, data in (("trunc", raw[:-9]), ("extra", raw + b"x"), ("magic", b"XBAP" + raw[4:]), ("ver", raw[:4] + b"\x03\x00\x00\x00" + raw[8:])):
         f = str(tmp_path / name)
         open(f, "wb").write(data)
         assert l.vba_problem_load(f.encode(), C.byref(q)) != 0 and not q
