@@ -178,14 +178,15 @@ __global__ void __launch_bounds__(64) k_stage_clear(Batch B, int stage) {
             if (c.aborted || stop) {  // :462-470 -- skip stage 2
                 if (!c.aborted) { c.aborted = 1; c.status = 1; }
                 c.active = 0;
-            } else
+            } else {
                 c.active = 1;
+                c.lambda = 0;  // the second optimize() starts its own lambda (computeLambdaInit at its iteration 0)
+            }
             c.robust_vis = 0;  // e->setRobustKernel(0) on every vision edge, :489
         }
         if (d.its[stage] <= 0) c.active = 0;  // optimize(0) runs nothing
         c.stage = stage; c.it = 0; c.chol_fail = 0;
         c.lm_trial = 0; c.lm_need_trial = 0; c.nbad = 0; c.ni = 2;
-        c.lambda = 0;   // each optimize() starts its own lambda (computeLambdaInit at its iteration 0)
     }
 }
 
@@ -1089,8 +1090,11 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
             for (int i = 0; i < 6 * LD; i++) UA[i] = UB[i];
             beta[0] = qa[6];
         } else {
+            // (the pass that opens an outer iteration reads no Sigma at all: the record may hold anything there -- after a failed
+            // solve of the window that occupied this place before, a NaN, and 0 * NaN would poison the whole keyframe block)
             const double* sg = B.prec + VBA_PREC * (size_t)(d.pt0 + (want_u ? B.slot_lm[d.obs0 + sa] : 0)) + 10;
-            const double s00 = sg[0], s01 = sg[1], s02 = sg[2], s11 = sg[3], s12 = sg[4], s22 = sg[5];
+            double s00 = 0.0, s01 = 0.0, s02 = 0.0, s11 = 0.0, s12 = 0.0, s22 = 0.0;
+            if (want_u) { s00 = sg[0]; s01 = sg[1]; s02 = sg[2]; s11 = sg[3]; s12 = sg[4]; s22 = sg[5]; }
 #pragma unroll
             for (int l = 0; l < LD; l++) beta[l] = want_u ? sg[6 + l] : 0.0;
 #pragma unroll
@@ -2002,16 +2006,21 @@ __global__ void __launch_bounds__(64) k_final_edges(Batch B) {
     const WinDesc& d = B.desc[w];
     const int o = blockIdx.x * 64 + threadIdx.x;
     if ((int)blockIdx.x * 64 >= d.n_obs) return;
+    // a window stopped at the very first terminate() of its first optimize() has evaluated nothing: e->chi2() then reads an _error
+    // no computeError() ever wrote (uninitialised in g2o; zero here and in the oracle) -- the launch schedule has linearised once
+    // before that poll, but those values do not exist for the protocol
+    const bool never = B.ctrl[w].n_trace == 0;
     double chi = 0.0, cnt = 0.0;
     if (o < d.n_obs) {
         const size_t go = d.obs0 + o;
-        const double s = B.chi2_e[go];
+        const double stored = B.chi2_e[go];   // written by the last linearisation, i.e. at the final estimates
+        const double s = never ? 0.0 : stored;
         bool bad = (s > d.chi2_th) || !(B.depth_e[go] > d.depth_min);
         if (d.variant == 2 && (B.pt[3 * (size_t)(d.pt0 + B.obs_pt[go])] < d.rho_min || B.lvl[go])) bad = true;
         if (d.protocol == 1) bad = false;  // global BA classifies nothing
         B.out_outlier[go] = bad ? 1 : 0;
         B.out_chi2[go] = s;
-        if (!B.lvl[go]) chi = B.chi2_f ? B.chi2_f[go] : s;
+        if (!B.lvl[go]) chi = B.chi2_f ? B.chi2_f[go] : stored;
         cnt = bad ? 1.0 : 0.0;
     }
     const double tc = block_sum<64>(chi, sm);
