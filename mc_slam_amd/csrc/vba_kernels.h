@@ -503,8 +503,7 @@ __global__ void __launch_bounds__(64) k_lin_imu_hess(Batch B) {
     lin_imu_hess(B, d, k, sm);
 }
 
-__global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode) {
-    extern __shared__ double lsm[];
+DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
     double* ER = lsm;                       // 256 x LIN2_ES
     double* PT = lsm + 256 * LIN2_ES;       // 64 x LIN2_PS
     double* red = PT + 64 * LIN2_PS;        // 4
@@ -751,6 +750,30 @@ __global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode
     }
     const double tot = block_sum256(chi, red);
     if (t == 0) B.part[d.part0 + lb] = tot;
+}
+__global__ void __launch_bounds__(256, 4) k_lin2(Batch B, int nblk_lin, int mode) {
+    extern __shared__ double lsm[];
+    lin2_body(B, nblk_lin, mode, lsm);
+}
+// Few windows: the IMU factors of the window in the SAME launch (the workgroups behind the edge workgroups, one keyframe pair
+// each, wave 0) -- one launch and its latency less per linearisation pass; no occupancy to protect here, so no register cap
+__global__ void __launch_bounds__(256) k_lin2_imu(Batch B, int nblk_lin, int mode) {
+    extern __shared__ double lsm[];
+    if ((int)blockIdx.x < nblk_lin) {
+        lin2_body(B, nblk_lin, mode, lsm);
+        return;
+    }
+    if (threadIdx.x >= 64) return;
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    if (!lin_imu_gate(d, B.ctrl[w], mode)) return;
+    const int k = blockIdx.x - nblk_lin;
+    if (k >= d.n_imu) return;
+    if (threadIdx.x == 0) lin_imu_res(B, d, k, (mode == LIN_FULL) ? LIN_FULL : LIN_ERR);
+    if (mode != LIN_FULL) return;
+    __threadfence_block();
+    __syncthreads();
+    lin_imu_hess(B, d, k, lsm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1215,6 +1238,15 @@ __global__ void __launch_bounds__(64, 3) k_schur_all(Batch B, int max_free, int 
     if (idx < max_free) schur_diag_body<1>(B, max_free, 0, blk, sh_r, sh_b, sh_h, w, idx);
     else schur_off_body<1, 16>(B, max_quads, blk, w, idx - max_free);
 }
+// the same for fewer than 8 windows: one off-diagonal pair per wave (latency), still one launch
+__global__ void __launch_bounds__(64, 3) k_schur_all_w(Batch B, int max_free, int max_offp) {
+    __shared__ double blk[15 * 15 + 16];
+    __shared__ double sh_r[6], sh_b[6], sh_h[6];
+    int w, idx;
+    if (!schur_map(B, max_free + max_offp, w, idx)) return;
+    if (idx < max_free) schur_diag_body<1>(B, max_free, 0, blk, sh_r, sh_b, sh_h, w, idx);
+    else schur_off_body<1, 64>(B, max_offp, blk, w, idx - max_free);
+}
 __global__ void __launch_bounds__(64) k_schur_diag3(Batch B, int max_free, int hd_pass) {
     __shared__ double blk[15 * 15 + 16];
     __shared__ double sh_r[6], sh_b[6], sh_h[6];
@@ -1372,6 +1404,193 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
 #pragma unroll
             for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = acc[i];
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same step for FEW windows (latency is everything: one window = a chain of nb dependent launches), built around `v_fmac_f64_dpp ... row_newbcast:n` (gfx90a+: the only DPP
+// control the FP64 pipe takes -- lane n of every 16-lane row is broadcast to the row).  In the forms above every element of a
+// rank-1 update costs three instructions: two v_readlane_b32 to bring u_{c2} (held by lane c2) into a scalar pair, one FMA; the
+// 32 x 32 elimination is ~1 500 of them per row set and the wave issues one every four cycles.  With the broadcast inside the
+// FMA an element costs ONE instruction.  What it needs is u replicated in every 16-lane row:
+//   lane L holds row r = L & 31 of the diagonal tile in a[] (both 32-lane halves hold a copy) and, in p[], row r of a panel tile --
+//   lanes 0..31 tile I, lanes 32..63 tile J: one wave carries BOTH panel tiles of its pair through the elimination;
+//   at step cc, u = a[cc] is u_{r}: the even rows (lanes 0..15, 32..47) hold u_0..u_15, the odd rows u_16..u_31; one ds_swizzle
+//   (lane ^ 16, crossbar only) gives every lane the other half, so uLow / uHigh = (u_{j}, u_{16+j}) sit at lane offset j of EVERY row
+//   and  a[c2] -= l * u_{c2}  is  v_fmac_f64_dpp a[c2], (c2 < 16 ? uLow : uHigh), -l  row_newbcast:(c2 & 15).
+// Per step: 2 (31 - cc) FMACs (diagonal rows, panel rows) + ~35 instructions of pivot / reciprocal / right-hand side / swizzle.
+// The hand-written instruction reads its broadcast operand through DPP: the two wait states a DPP read needs after a VALU write of
+// that register (the compiler does not look into inline assembly) are the s_nop in front of each step's first FMAC.
+// A second wave of the workgroup sits out the elimination at the barrier and then takes half of the trailing MFMA update.
+// Same arithmetic as k_chol_step up to the association of l = a / d: results agree to rounding.
+// ------------------------------------------------------------------------------------------------
+template <int N, bool NOP>
+DEVI void fmac_bcast(double& acc, double urep, double s) {   // acc += urep[lane N of this lane's row] * s
+    if (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(urep), "v"(s), "n"(N));
+    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(urep), "v"(s), "n"(N));
+}
+DEVI double swap16(double v) {   // the value of lane L ^ 16
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401f);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401f);
+    return __hiloint2double(hi, lo);
+}
+template <int C2, int CC>
+struct CholUpd {   // columns C2..31 of step CC
+    static DEVI void run(double (&a)[32], double (&p)[32], double uLow, double uHigh, double nl, double nlp) {
+        if constexpr (C2 < 32) {
+            fmac_bcast<(C2 & 15), C2 == CC + 1>(a[C2], (C2 < 16) ? uLow : uHigh, nl);
+            fmac_bcast<(C2 & 15), false>(p[C2], (C2 < 16) ? uLow : uHigh, nlp);
+            CholUpd<C2 + 1, CC>::run(a, p, uLow, uHigh, nl, nlp);
+        }
+    }
+};
+template <int LANE>
+DEVI double wl64(double old, double v) {  // old with lane LANE replaced by the wave-uniform value v (two v_writelane_b32)
+    int lo = __double2loint(old), hi = __double2hiint(old);
+    const int vlo = __builtin_amdgcn_readfirstlane(__double2loint(v)), vhi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"(vlo), "n"(LANE));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(vhi), "n"(LANE));
+    return __hiloint2double(hi, lo);
+}
+// One elimination step.  No per-lane masks anywhere: the entries of a[] above the diagonal are never read by another lane (u_{c2}
+// comes from lane c2 > CC, the pivot from lane CC) nor stored where anybody uses them, so they may hold anything -- lane CC's own
+// update with l = 1 and the lanes r < CC run through the same instructions; what a lane must KEEP from step CC (d_CC, z_CC) is
+// captured with v_writelane into lane CC of dout / zout before the unguarded updates overwrite it.
+template <int CC>
+struct CholStep {
+    static DEVI void run(double (&a)[32], double (&p)[32], double& rh, double& rp, double& dout, double& zout, bool& bad, bool even_row,
+                         double* Xrow) {
+        if constexpr (CC < 32) {
+            const double u = a[CC], up = p[CC];          // column CC before the division: l d
+            const double piv = rl64(u, CC);              // d_CC (lane CC holds row CC of the diagonal tile)
+            bad = bad || (piv == 0.0) || !isfinite(piv);
+            double y = __builtin_amdgcn_rcp(piv);        // v_rcp_f64 + two Newton steps: full double accuracy
+            y = y * (2.0 - piv * y);
+            y = y * (2.0 - piv * y);
+            const double l = u * y, lp = up * y;
+            const double zc = rl64(rh, CC);              // z_CC is final here
+            dout = wl64<CC>(dout, piv);
+            zout = wl64<CC>(zout, zc);
+            rh -= l * zc;
+            rp -= lp * zc;
+            Xrow[CC] = lp;                               // lanes 0..31: row r of L_Ik (XI), lanes 32..63: row r of L_Jk (XJ)
+            a[CC] = l;
+            p[CC] = lp;
+            if constexpr (CC < 31) {
+                const double us = swap16(u);
+                const double uLow = even_row ? u : us, uHigh = even_row ? us : u;
+                CholUpd<CC + 1, CC>::run(a, p, uLow, uHigh, -l, -lp);
+            }
+            CholStep<CC + 1>::run(a, p, rh, rp, dout, zout, bad, even_row, Xrow);
+        }
+    }
+};
+
+__global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
+    __shared__ double XI[32 * 34];   // rows of L_Ik            (A operand: -L_Ik)
+    __shared__ double XJ[32 * 34];   // rows of L_Jk            (B operand: L_Jk D_k, scaled when it is read)
+    __shared__ double dg[32];
+    const int w = blockIdx.y;
+    const WinDesc& d = B.desc[w];
+    WinCtrl& c = B.ctrl[w];
+    if (!win_on(d, c)) return;
+    if (k >= d.nb) return;
+    const int* sb = B.tl_step_begin + d.tl_step0;
+    const int npair = sb[k + 1] - sb[k];
+    const int bx = blockIdx.x;
+    if (bx >= (npair > 0 ? npair : 1)) return;
+    const bool has_pair = bx < npair;
+    int I = 0, J = 0;
+    if (has_pair) {
+        const int v = B.tl_pairs[d.tl_pair0 + sb[k] + bx];
+        I = v >> 16;
+        J = v & 0xffff;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
+    const int n = d.nS;
+    double* S = B.S + d.S0;
+    double* Lf = B.Lf + d.S0;
+    double* vec = B.vec + d.vec0;
+    double* yv = B.yv + d.vec0;
+    const size_t dk = (size_t)k * 32;
+    const bool diagp = has_pair && (I == J);
+    // this wave's half of the trailing tile C_IJ (rows 16 wave .. 16 wave + 15), requested now: it arrives while the elimination runs
+    const int l15 = lane & 15, l4 = lane >> 4;
+    d4_t cacc[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+        const double* C = S + ((size_t)I * 32 + 16 * wave) * n + (size_t)J * 32 + 16 * tj;
+#pragma unroll
+        for (int i = 0; i < 4; i++) cacc[tj][i] = has_pair ? C[(size_t)(l4 + 4 * i) * n + l15] : 0.0;
+    }
+    if (wave == 0) {
+    const int T = hi ? J : I;                        // the panel tile of this half of the wave
+    double a[32], p[32];
+    {   // whole rows, 32-byte pieces (rows start on 256-byte boundaries: nS is a multiple of 32); what lies above the diagonal of
+        // the diagonal tile is never used (see CholStep)
+        const double4* arow = reinterpret_cast<const double4*>(S + (dk + r) * n + dk);
+        const double4* prow = reinterpret_cast<const double4*>(S + ((size_t)T * 32 + r) * n + dk);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const double4 va = arow[q];
+            a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
+        }
+        if (has_pair) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const double4 vp = prow[q];
+                p[4 * q] = vp.x; p[4 * q + 1] = vp.y; p[4 * q + 2] = vp.z; p[4 * q + 3] = vp.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; q++) p[q] = 0.0;
+        }
+    }
+    // right-hand side: one more column.  The rhs rows of a panel tile are updated by ONE workgroup, the one of its diagonal pair
+    double rh = vec[dk + r];
+    double rp = (diagp && !hi) ? vec[(size_t)I * 32 + r] : 0.0;
+    bool bad = false;
+    double dout = 1.0, zout = 0.0;                   // lane r ends up with d_r and z_r
+    CholStep<0>::run(a, p, rh, rp, dout, zout, bad, ((lane >> 4) & 1) == 0, (hi ? XJ : XI) + r * 34);
+    if (bx == 0 && !hi) {                            // the factor's diagonal tile (whole rows: unit L below the diagonal, D on it,
+        a[0] = (r == 0) ? dout : a[0];               // nobody reads above it) and z_k = L_kk^-1 r_k
+        double4* lrow = reinterpret_cast<double4*>(Lf + (dk + r) * n + dk);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            double4 v;
+            v.x = (4 * q == r) ? dout : a[4 * q];
+            v.y = (4 * q + 1 == r) ? dout : a[4 * q + 1];
+            v.z = (4 * q + 2 == r) ? dout : a[4 * q + 2];
+            v.w = (4 * q + 3 == r) ? dout : a[4 * q + 3];
+            lrow[q] = v;
+        }
+        yv[dk + r] = zout;
+    }
+    if (bx == 0 && lane == 0 && bad) c.chol_fail = 1;
+    if (diagp && !hi) {                              // tile (I,k) of the factor and the rhs rows it has updated
+        double4* dst = reinterpret_cast<double4*>(Lf + ((size_t)I * 32 + r) * n + dk);
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = make_double4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
+        vec[(size_t)I * 32 + r] = rp;
+    }
+    if (!hi) dg[r] = dout;
+    }   // wave 0
+    if (!has_pair) return;                           // (the same for every thread of the workgroup)
+    // C_IJ -= L_Ik D_k L_Jk^T: XI / XJ hold the rows of L_Ik / L_Jk (written step by step above), D_k is dg; 16 rows per wave
+    __syncthreads();
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+        if (diagp && tj > wave) continue;
+        double* C = S + ((size_t)I * 32 + 16 * wave) * n + (size_t)J * 32 + 16 * tj;
+        d4_t acc = cacc[tj];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            const double av = -XI[(16 * wave + l15) * 34 + 4 * ks + l4];
+            const double bv = XJ[(16 * tj + l15) * 34 + 4 * ks + l4] * dg[4 * ks + l4];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = acc[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

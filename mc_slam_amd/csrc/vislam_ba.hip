@@ -794,6 +794,8 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
             static const int fused_schur = getenv("VBA_SCHUR_SPLIT") ? 0 : 1;
             if (rn >= 8 && fused_schur) {
                 hipLaunchKernelGGL(k_schur_all, dim3((h->max_free + h->max_quads) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_quads);
+            } else if (fused_schur) {
+                hipLaunchKernelGGL(k_schur_all_w, dim3((h->max_free + h->max_offp) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_offp);
             } else {
             hipLaunchKernelGGL(k_schur_diag, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free);
             if (rn >= 8) hipLaunchKernelGGL(k_schur_off, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
@@ -848,8 +850,12 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
                     hipLaunchKernelGGL(k_chol_update, dim3(h->step_npair_max[k], n), dim3(64), 0, h->stream, B, k);
             }
         } else {        // latency-bound: one fused launch per step
-            for (int k = 0; k < h->max_nb; k++)
-                hipLaunchKernelGGL(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
+            // VBA_CHOL_STEP=1 (A/B): the first form -- diagonal tile, then the panel solves, v_readlane broadcasts
+            static const int step_form = getenv("VBA_CHOL_STEP") ? atoi(getenv("VBA_CHOL_STEP")) : 3;
+            for (int k = 0; k < h->max_nb; k++) {
+                if (step_form == 1) hipLaunchKernelGGL(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
+                else hipLaunchKernelGGL(k_chol_step3, dim3(h->step_grid[k], n), dim3(128), 0, h->stream, B, k);
+            }
         }
     }
     {
@@ -869,6 +875,11 @@ void enqueue_lin(Handle* h, int mode) {
     ProfScope ps(h, VBA_PROF_LINEARIZE);
     if (h->variant == VBA_VARIANT_PRV_IDP) {
         const size_t shm = LIN2_LDS;
+        static const int fuse_imu = getenv("VBA_LIN_IMU_SPLIT") ? 0 : 1;
+        if (fuse_imu && h->max_imu > 0 && h->regime_n < 64) {   // few windows: edges and IMU factors in one launch
+            hipLaunchKernelGGL(k_lin2_imu, dim3(h->max_lin_blk + h->max_imu, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
+            return;
+        }
         hipLaunchKernelGGL(k_lin2, dim3(h->max_lin_blk, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
     } else {
         hipLaunchKernelGGL(k_lin_xyz_e, dim3(h->max_lin_blk, h->n_win), dim3(256), 0, h->stream, h->B, mode);
@@ -1037,15 +1048,20 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
             const int nit = h->max_its[stage];
             std::vector<std::vector<hipEvent_t>> ev(groups.size(), std::vector<hipEvent_t>(nit, nullptr));
             const bool pace = nit <= 32;  // also when profiling: the launch counts (and hence the per-launch averages) then equal those of a normal run
+            // how far ahead: two iterations for batches (the device must never wait for the host); ONE for a handful of windows,
+            // where an iteration is a chain of ~30 short launches that the host enqueues three times faster than the device runs
+            // them, and every launch enqueued for a window that has already converged (1.7 us each, 30 per iteration) is latency
+            static const int env_depth = getenv("VBA_PACE_DEPTH") ? atoi(getenv("VBA_PACE_DEPTH")) : 0;
+            const int depth = env_depth > 0 ? env_depth : (h->regime_n < 8 ? 1 : 2);
             for (auto& g : groups) g.dead = false;
             for (int it = 0; it < nit; it++) {
                 bool any = false;
                 for (size_t gi = 0; gi < groups.size(); gi++) {
                     Group& g = groups[gi];
                     if (g.dead) continue;
-                    if (pace && it >= 2) {
-                        (void)wait_event_forwarding(h, ev[gi][it - 2], stop_flag);
-                        if (g.alive[stage * 32 + it - 2] == 0) { g.dead = true; continue; }
+                    if (pace && it >= depth) {
+                        (void)wait_event_forwarding(h, ev[gi][it - depth], stop_flag);
+                        if (g.alive[stage * 32 + it - depth] == 0) { g.dead = true; continue; }
                     }
                     any = true;
                     use(g);
@@ -1337,6 +1353,10 @@ static int make_handle(int device, Handle* parent, Handle** out) {
     h->stop_dev = reinterpret_cast<int*>(dpw);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lin2), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)LIN2_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lin2_imu), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)LIN2_LDS);
+    // the back-substitution keeps x (nS doubles) in LDS: maps of more than ~5 600 pose dofs need more than the default 64 KiB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     memset(&h->prof, 0, sizeof h->prof);
     *out = h;
     return 0;
