@@ -268,6 +268,16 @@ DEVI double wave64_sum(double v) {  // every lane ends up with the wave's sum: r
     return ((rl64(v, 0) + rl64(v, 16)) + rl64(v, 32)) + rl64(v, 48);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence over every address space: it drains the wave's
+// global loads and stores (s_waitcnt vmcnt(0)) before the barrier, so nothing fetched for LATER can be in flight across it and
+// every store issued before it is paid for in full.  Where the barrier only hands LDS data from wave to wave, this form keeps the
+// vector-memory queue running.  (Global data written before and read after it by ANOTHER wave still needs __syncthreads().)
+DEVI void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Huber (robust_kernel_impl.cpp:78-91): returns rho(e), sets *w = rho'(e)
 DEVI double huber(double e, double delta, double* w) {
     const double dsqr = delta * delta;

@@ -1513,6 +1513,14 @@ __global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
     double* yv = B.yv + d.vec0;
     const size_t dk = (size_t)k * 32;
     const bool diagp = has_pair && (I == J);
+#ifdef VBA_STAMPS   // diagnostic build only (scripts/stamps.sh): shader-clock stamps of workgroup 1 of column 5 into B.dbg
+    unsigned long long st_[8];
+    const bool st_on = (k == 5 && bx == 1 && threadIdx.x == 0);
+#define STAMP(i) { if (k == 5 && bx == 1) { st_[i] = __builtin_amdgcn_s_memtime(); } }
+    STAMP(0)
+#else
+#define STAMP(i)
+#endif
     // this wave's half of the trailing tile C_IJ (rows 16 wave .. 16 wave + 15), requested now: it arrives while the elimination runs
     const int l15 = lane & 15, l4 = lane >> 4;
     d4_t cacc[2];
@@ -1550,7 +1558,12 @@ __global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
     double rp = (diagp && !hi) ? vec[(size_t)I * 32 + r] : 0.0;
     bool bad = false;
     double dout = 1.0, zout = 0.0;                   // lane r ends up with d_r and z_r
+#ifdef VBA_STAMPS
+    { double sink = a[0] + p[31] + rh; asm volatile("" :: "v"(sink)); }   // the loads have landed
+#endif
+    STAMP(1)
     CholStep<0>::run(a, p, rh, rp, dout, zout, bad, ((lane >> 4) & 1) == 0, (hi ? XJ : XI) + r * 34);
+    STAMP(2)
     if (bx == 0 && !hi) {                            // the factor's diagonal tile (whole rows: unit L below the diagonal, D on it,
         a[0] = (r == 0) ? dout : a[0];               // nobody reads above it) and z_k = L_kk^-1 r_k
         double4* lrow = reinterpret_cast<double4*>(Lf + (dk + r) * n + dk);
@@ -1573,10 +1586,12 @@ __global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
         vec[(size_t)I * 32 + r] = rp;
     }
     if (!hi) dg[r] = dout;
+    STAMP(3)
     }   // wave 0
     if (!has_pair) return;                           // (the same for every thread of the workgroup)
-    // C_IJ -= L_Ik D_k L_Jk^T: XI / XJ hold the rows of L_Ik / L_Jk (written step by step above), D_k is dg; 16 rows per wave
-    __syncthreads();
+    // C_IJ -= L_Ik D_k L_Jk^T: XI / XJ hold the rows of L_Ik / L_Jk (written step by step above), D_k is dg; 16 rows per wave.
+    // (LDS-only barrier: the stores of the factor tiles above drain while the MFMAs run)
+    lds_barrier();
 #pragma unroll
     for (int tj = 0; tj < 2; tj++) {
         if (diagp && tj > wave) continue;
@@ -1591,6 +1606,15 @@ __global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
 #pragma unroll
         for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = acc[i];
     }
+#ifdef VBA_STAMPS
+    STAMP(4)
+    if (wave == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(5) }
+    if (st_on) {
+        st_[6] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 7; i++) B.dbg[i] = (double)st_[i];
+    }
+#endif
+#undef STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2048,9 +2072,16 @@ __global__ void __launch_bounds__(256) k_trsv(Batch B) {
         }
     };
     diag_fetch(d.nb - 1);
+#ifdef VBA_STAMPS
+    unsigned long long st_[8];
+#define TSTAMP(i) { if (k == 10) st_[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define TSTAMP(i)
+#endif
     for (int k = d.nb - 1; k >= 0; k--) {
         const size_t dk = (size_t)k * 32;
         const int i0 = pb[k], m = pb[k + 1] - i0;
+        TSTAMP(0)
         if (pk) {
             // a wave per tile: 8 coalesced 16-byte loads per lane; the lane's 16 elements are rows l15 and 16 + l15 of the
             // columns 4 ks + l4 -- eight column sums per lane, reduced over the 16 lanes of a DPP row at the end
@@ -2092,8 +2123,10 @@ __global__ void __launch_bounds__(256) k_trsv(Batch B) {
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) Lt[dpos[u]] = nx[u];
+        TSTAMP(1)
         if (k > 0) diag_fetch(k - 1);
         __syncthreads();
+        TSTAMP(2)
         if (t < 64) {
             const int c = t & 31;
             double v;
@@ -2106,6 +2139,123 @@ __global__ void __launch_bounds__(256) k_trsv(Batch B) {
             v = xs[dk + c] / dgc;                                         // D^-1 z
 #pragma unroll
             for (int q = 0; q < 8; q++) v -= part[q * 32 + c];
+#ifdef VBA_STAMPS
+            asm volatile("" :: "v"(v));
+#endif
+            TSTAMP(3)
+#pragma unroll
+            for (int j = 31; j >= 0; j--) {                               // unit-diagonal L_kk^T x_k = v
+                const double xj = rl64(v, j);
+                v = (c < j) ? v - col[j] * xj : v;
+            }
+            if (t < 32) xs[dk + c] = v;
+            TSTAMP(4)
+        }
+        __syncthreads();
+        TSTAMP(5)
+#ifdef VBA_STAMPS
+        if (k == 10 && t == 0) for (int i = 0; i < 6; i++) B.dbg[16 + i] = (double)st_[i];
+#endif
+    }
+#undef TSTAMP
+    for (int q = t; q < n; q += 256) vec[q] = xs[q];
+}
+
+// The same back-substitution for the row-major factor of the few-window kernels, where its latency counts (one window: 8-10
+// calls per solve, 23 block columns each, every column a chain  tile indices -> tiles -> products -> barrier -> 32-step triangular
+// solve -> barrier).  In-kernel stamps of k_trsv at C3 size: 6.0 k of the 9.4 k cycles of a long column go into the gather, most of
+// it ISSUING it -- sixteen 8-byte loads per tile and lane, each with its own 64-bit address arithmetic (~55 cycles apiece) behind a
+// dependent fetch of the tile index.  Here
+//   * the tile lists of the window are copied into LDS once (no index -> tile dependency through memory per column),
+//   * a lane takes two neighbouring columns of eight rows of a tile: eight 16-byte loads whose addresses are one uniform tile base +
+//     a 32-bit lane offset + a multiple of the row pitch,
+//   * the tiles and the diagonal tile of column k-1 -- which depend on the tile lists only, not on x -- are requested BEFORE the
+//     barriers and the triangular solve of column k (barriers that do not drain the vector-memory queue: lds_barrier).  Six tiles
+//     per wave cover the 22 tiles of the longest column of a 50-keyframe window; longer columns fetch the rest on the fly.
+// Fixed summation order (16 partial rows in order).  Measured at C3 size: 60 us per call against 66 (a dedicated solving wave
+// that fetches its own column of the diagonal tile: no better; the 32-step triangular solve and the two barriers per column remain).
+#define TRSV_W_PF 6
+__global__ void __launch_bounds__(256) k_trsv_w(Batch B) {
+    extern __shared__ double xs[];  // nS doubles + 16*32 partials + 32*33 diagonal tile + (tile lists) ints
+    const int w = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    if (!win_on(d, B.ctrl[w])) return;
+    const int n = d.nS, t = threadIdx.x;
+    double* part = xs + n;
+    double* Lt = part + 512;
+    int* lpb = reinterpret_cast<int*>(Lt + 32 * 33);   // [nb + 1] column starts, then the tile rows
+    int* lpan = lpb + d.nb + 1;
+    const double* S = B.Lf + d.S0;
+    double* vec = B.vec + d.vec0;
+    const double* yv = B.yv + d.vec0;
+    {
+        const int* pb = B.tl_pan_begin + d.tl_step0;
+        const int* pan = B.tl_pan + d.tl_pan0;
+        const int np = pb[d.nb];
+        for (int q = t; q <= d.nb; q += 256) lpb[q] = pb[q];
+        for (int q = t; q < np; q += 256) lpan[q] = pan[q];
+    }
+    for (int q = t; q < n; q += 256) xs[q] = yv[q];
+    __syncthreads();
+    const int wave = t >> 6, lane = t & 63, cp = lane & 15, rg = lane >> 4;   // column pair, group of eight rows
+    const unsigned rowb = (unsigned)n * 8u;                                  // row pitch in bytes
+    const unsigned lane_off = (unsigned)(rg * 8) * rowb + (unsigned)cp * 16u;
+    double2 nlv[TRSV_W_PF][8];
+    double ndg[4];
+    int nI[TRSV_W_PF];
+    auto tile_load = [&](int I, size_t dk, double2 (&lv)[8]) {
+        const char* tb = reinterpret_cast<const char*>(S + (size_t)I * 32 * n + dk);   // wave-uniform
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) lv[rr] = *reinterpret_cast<const double2*>(tb + (lane_off + (unsigned)rr * rowb));
+    };
+    auto tile_dot = [&](int I, const double2 (&lv)[8], double& s0, double& s1) {
+        const double* x = xs + I * 32 + rg * 8;
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) { s0 += lv[rr].x * x[rr]; s1 += lv[rr].y * x[rr]; }
+    };
+    auto prefetch = [&](int k) {
+        const size_t dk = (size_t)k * 32;
+        const int i0 = lpb[k], m = lpb[k + 1] - i0;
+#pragma unroll
+        for (int s = 0; s < TRSV_W_PF; s++) {
+            const int i = wave + 4 * s;
+            nI[s] = (i < m) ? lpan[i0 + i] : -1;      // (wave-uniform)
+            if (nI[s] >= 0) tile_load(nI[s], dk, nlv[s]);
+        }
+        const char* db = reinterpret_cast<const char*>(S + dk * n + dk);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const unsigned q = t + 256 * u; ndg[u] = *reinterpret_cast<const double*>(db + ((q >> 5) * rowb + (q & 31) * 8u)); }
+    };
+    prefetch(d.nb - 1);
+    for (int k = d.nb - 1; k >= 0; k--) {
+        const size_t dk = (size_t)k * 32;
+        const int i0 = lpb[k], m = lpb[k + 1] - i0;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < TRSV_W_PF; q++)          // tile i of the column goes to wave i % 4
+            if (nI[q] >= 0) tile_dot(nI[q], nlv[q], s0, s1);
+        for (int i = wave + 4 * TRSV_W_PF; i < m; i += 4) {
+            const int I = lpan[i0 + i];
+            double2 lv[8];
+            tile_load(I, dk, lv);
+            tile_dot(I, lv, s0, s1);
+        }
+        *reinterpret_cast<double2*>(part + (wave * 4 + rg) * 32 + 2 * cp) = make_double2(s0, s1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = t + 256 * u; Lt[(q >> 5) * 33 + (q & 31)] = ndg[u]; }
+        if (k > 0) prefetch(k - 1);                  // in flight during the barriers and the triangular solve below
+        lds_barrier();
+        if (t < 64) {
+            const int c = t & 31;
+            double col[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) col[j] = Lt[j * 33 + c];  // column c of L_kk (rows j >= c are the factor)
+            double dgc = 1.0;
+#pragma unroll
+            for (int j = 0; j < 32; j++) dgc = (j == c) ? col[j] : dgc;  // d_c sits on the diagonal of the tile
+            double v = xs[dk + c] / dgc;                                  // D^-1 z
+#pragma unroll
+            for (int q = 0; q < 16; q++) v -= part[q * 32 + c];
 #pragma unroll
             for (int j = 31; j >= 0; j--) {                               // unit-diagonal L_kk^T x_k = v
                 const double xj = rl64(v, j);
@@ -2113,7 +2263,7 @@ __global__ void __launch_bounds__(256) k_trsv(Batch B) {
             }
             if (t < 32) xs[dk + c] = v;
         }
-        __syncthreads();
+        lds_barrier();
     }
     for (int q = t; q < n; q += 256) vec[q] = xs[q];
 }

@@ -193,7 +193,7 @@ struct Handle {
                        // cutting the batch into window groups never changes a summation order
     // launch geometry (maxima over the batch)
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
-    int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0, max_quads = 1, max_offp = 1;
+    int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0, max_quads = 1, max_offp = 1, max_pan = 0;
     std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
     std::vector<int> pan_grid, step_npair_max;  // panel tiles / tile pairs per step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
@@ -404,6 +404,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->max_free = 0;
     h->max_lin_blk = 0;
     h->max_quads = 1;
+    h->max_pan = 0;
     h->max_offp = 1;
     h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
     h->max_its[0] = h->max_its[1] = 0;
@@ -562,6 +563,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             h->max_pairs = std::max(h->max_pairs, d.n_pairs);
             h->max_free = std::max(h->max_free, d.n_free);
             h->max_quads = std::max(h->max_quads, (d.n_pairs - d.n_free + 3) / 4);
+            h->max_pan = std::max(h->max_pan, (int)st.pan.size());
             h->max_offp = std::max(h->max_offp, d.n_pairs - d.n_free);
             h->max_nb = std::max(h->max_nb, d.nb);
             h->max_obs_blk = std::max(h->max_obs_blk, obs_blk);
@@ -860,8 +862,14 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
     }
     {
         ProfScope ps(h, VBA_PROF_TRSV);
-        const size_t shm = ((size_t)h->max_nS + 256 + 32 * 33) * sizeof(double);
-        hipLaunchKernelGGL(k_trsv, dim3(n), dim3(256), shm, h->stream, B);
+        static const int trsv_old = getenv("VBA_TRSV_OLD") ? 1 : 0;
+        if (h->ll_mode || trsv_old) {
+            const size_t shm = ((size_t)h->max_nS + 256 + 32 * 33) * sizeof(double);
+            hipLaunchKernelGGL(k_trsv, dim3(n), dim3(256), shm, h->stream, B);
+        } else {   // row-major factor: the next column's tiles prefetched, tile lists in LDS
+            const size_t shm = ((size_t)h->max_nS + 512 + 32 * 33) * sizeof(double) + ((size_t)h->max_pan + h->max_nb + 2) * sizeof(int);
+            hipLaunchKernelGGL(k_trsv_w, dim3(n), dim3(256), shm, h->stream, B);
+        }
     }
     }
     {
@@ -1357,6 +1365,7 @@ static int make_handle(int device, Handle* parent, Handle** out) {
                               (int)LIN2_LDS);
     // the back-substitution keeps x (nS doubles) in LDS: maps of more than ~5 600 pose dofs need more than the default 64 KiB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_w), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     memset(&h->prof, 0, sizeof h->prof);
     *out = h;
     return 0;
