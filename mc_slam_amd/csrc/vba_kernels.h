@@ -1455,7 +1455,7 @@ DEVI double wl64(double old, double v) {  // old with lane LANE replaced by the 
 // comes from lane c2 > CC, the pivot from lane CC) nor stored where anybody uses them, so they may hold anything -- lane CC's own
 // update with l = 1 and the lanes r < CC run through the same instructions; what a lane must KEEP from step CC (d_CC, z_CC) is
 // captured with v_writelane into lane CC of dout / zout before the unguarded updates overwrite it.
-template <int CC>
+template <int CC, bool WRITE_X = true>
 struct CholStep {
     static DEVI void run(double (&a)[32], double (&p)[32], double& rh, double& rp, double& dout, double& zout, bool& bad, bool even_row,
                          double* Xrow) {
@@ -1472,7 +1472,7 @@ struct CholStep {
             zout = wl64<CC>(zout, zc);
             rh -= l * zc;
             rp -= lp * zc;
-            Xrow[CC] = lp;                               // lanes 0..31: row r of L_Ik (XI), lanes 32..63: row r of L_Jk (XJ)
+            if constexpr (WRITE_X) Xrow[CC] = lp;        // lanes 0..31: row r of L_Ik (XI), lanes 32..63: row r of L_Jk (XJ)
             a[CC] = l;
             p[CC] = lp;
             if constexpr (CC < 31) {
@@ -1480,7 +1480,7 @@ struct CholStep {
                 const double uLow = even_row ? u : us, uHigh = even_row ? us : u;
                 CholUpd<CC + 1, CC>::run(a, p, uLow, uHigh, -l, -lp);
             }
-            CholStep<CC + 1>::run(a, p, rh, rp, dout, zout, bad, even_row, Xrow);
+            CholStep<CC + 1, WRITE_X>::run(a, p, rh, rp, dout, zout, bad, even_row, Xrow);
         }
     }
 };
@@ -1915,6 +1915,62 @@ DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, do
     }
 }
 
+// The same with the elimination of k_chol_step3 (v_fmac_f64_dpp row_newbcast: one instruction per element of a rank-1 update
+// instead of two v_readlane + one FMA).  The rows that ride along with the diagonal tile are the rows of the IDENTITY: a row P of a
+// panel comes out of the elimination as P L^-T D^-1, so the identity comes out as L_JJ^-T D_J^-1 -- W_J itself, for the price of the
+// ride (496 FMACs) instead of a 32-column forward substitution against L_JJ in LDS (in-kernel stamps of ll_diag: 12-18 k cycles
+// LDL^T + 5 k y_J + 13 k W_J per column; here ~10 k for all three).  The right-hand side rides along as one more column (y_J).
+// Both tiles leave through LDS in 16-byte pieces of the packed order (ll_diag: 64 scattered 8-byte stores per lane).
+DEVI void ll_diag2(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, double* CT, double* WT) {
+    const int* pb = B.tl_pan_begin + d.tl_step0;
+    const int* klb = B.tl_kl_begin + d.tl_kb0;
+    const int ent = pb[J] + J;  // column entry of (J,J)
+    const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    d4_t acc[2][2];
+    double sdot = 0.0;
+    ll_diag_accumulate(B, d, J, klb[ent], klb[ent + 1], acc, sdot);
+    // C_JJ through LDS into one row per lane (both halves of the wave hold a copy; what lies above the diagonal is never used)
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) CT[(16 * ti + l4 + 4 * i) * 34 + 16 * tj + l15] = acc[ti][tj][i];
+    lds_barrier();
+    double a[32], p[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) { a[q] = CT[r * 34 + q]; p[q] = (q == r) ? 1.0 : 0.0; }
+    const size_t dk = (size_t)J * 32;
+    double rh = (B.vec + d.vec0)[dk + r] - __shfl(sdot, r, 64);   // b_J - sum_k L_Jk y_k
+    double rp = 0.0, dout = 1.0, zout = 0.0;
+    bool bad = false;
+    lds_barrier();                                    // every lane has its row: CT is free
+    CholStep<0, false>::run(a, p, rh, rp, dout, zout, bad, ((lane >> 4) & 1) == 0, nullptr);
+    if (lane == 0 && bad) c.chol_fail = 1;
+    if (!hi) {
+        B.dvec[d.vec0 + dk + r] = dout;
+        (B.yv + d.vec0)[dk + r] = zout;
+        // rows of L_JJ (unit lower, D on the diagonal, zeros above) and of W_J^T into LDS: CT[r][c] = L[r][c], WT[c][r] = W[c][r]
+        // with W[c][r] = (L^-T D^-1)[r][c] = p_r[c]
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            CT[r * 34 + q] = (q < r) ? a[q] : ((q == r) ? dout : 0.0);
+            WT[q * 34 + r] = p[q];
+        }
+    }
+    lds_barrier();
+    // packed order (ll_pk): piece (q, lane) = { M[row][c0], M[row][c0 + 4] }, row = 16 (q >> 2) + (lane & 15), c0 = 8 (q & 3) + (lane >> 4)
+    double2* Ljj = reinterpret_cast<double2*>(B.Lf + d.S0 + ll_tile(d, J, J)) + lane;
+    double2* Wd = reinterpret_cast<double2*>(B.winv + 1024 * (size_t)d.win) + lane;   // d.win: the batch-wide window index
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int row = 16 * (q >> 2) + l15, c0 = 8 * (q & 3) + l4;
+        Ljj[64 * q] = make_double2(CT[row * 34 + c0], CT[row * 34 + c0 + 4]);
+        Wd[64 * q] = make_double2(WT[row * 34 + c0], WT[row * 34 + c0 + 4]);
+    }
+}
+
 // (A fused variant -- the wave that owns tile (J+1,J) going on to factor diagonal tile J+1 -- was measured: no gain at 512
 // windows)
 __global__ void __launch_bounds__(64) k_chol_diag_ll(Batch B, int J) {
@@ -1927,6 +1983,17 @@ __global__ void __launch_bounds__(64) k_chol_diag_ll(Batch B, int J) {
     if (!win_on(d, c)) return;
     if (J >= d.nb) return;
     ll_diag(B, d, c, w, J, CT, rd);
+}
+__global__ void __launch_bounds__(64) k_chol_diag_ll2(Batch B, int J) {
+    __shared__ double CT[32 * 34];
+    __shared__ double WT[32 * 34];
+    const int w = blockIdx.x;
+    if (w >= B.n_win) return;
+    const WinDesc& d = B.desc[w];
+    WinCtrl& c = B.ctrl[w];
+    if (!win_on(d, c)) return;
+    if (J >= d.nb) return;
+    ll_diag2(B, d, c, w, J, CT, WT);
 }
 
 // panel tile (I,J): C_IJ = S_IJ - sum_k L_Ik D_k L_Jk^T, then L_IJ = C_IJ W_J.  The wave accumulates the TRANSPOSED tile

@@ -842,8 +842,10 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
         static const int split_min = getenv("VBA_SPLIT_MIN") ? atoi(getenv("VBA_SPLIT_MIN")) : 64;
         const bool ll = h->ll_mode;  // decided for the whole batch at upload (S stays pristine, pair masks), also for its window groups
         if (rn >= split_min || ll) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
+            static const int diag_old = getenv("VBA_LL_DIAG_OLD") ? 1 : 0;   // A/B: LDL^T by v_readlane broadcasts + explicit W_J
             for (int k = 0; k < h->max_nb && ll; k++) {  // every tile read once, updated in registers, written once
-                hipLaunchKernelGGL(k_chol_diag_ll, dim3(n), dim3(64), 0, h->stream, B, k);
+                if (diag_old) hipLaunchKernelGGL(k_chol_diag_ll, dim3(n), dim3(64), 0, h->stream, B, k);
+                else hipLaunchKernelGGL(k_chol_diag_ll2, dim3(n), dim3(64), 0, h->stream, B, k);
                 if (h->pan_grid[k] > 0) hipLaunchKernelGGL(k_chol_panel_ll, dim3(h->pan_grid[k] * ngrp), dim3(64), 0, h->stream, B, k, h->pan_grid[k]);
             }
             for (int k = 0; k < h->max_nb && !ll; k++) {
