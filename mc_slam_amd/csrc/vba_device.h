@@ -109,18 +109,27 @@ DEVI void R2q(const double* m, double* q) {  // Eigen quaternion-from-matrix
         t = 0.5 / t;
         q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
     } else {
+        // Eigen: i = 0; if (m(1,1) > m(0,0)) i = 1; if (m(2,2) > m(i,i)) i = 2; j = (i+1)%3; k = (j+1)%3 -- spelled out per case with
+        // constant indices (indexing m / q with the run-time i, j, k put the callers' matrices into scratch memory); same arithmetic
         int i = 0;
         if (m[4] > m[0]) i = 1;
-        if (m[8] > m[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
-        double qq[3];
-        qq[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
-        qq[j] = (m[3 * j + i] + m[3 * i + j]) * t;
-        qq[k] = (m[3 * k + i] + m[3 * i + k]) * t;
-        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2];
+        if (m[8] > ((i == 1) ? m[4] : m[0])) i = 2;
+        if (i == 0) {           // j = 1, k = 2
+            t = sqrt(m[0] - m[4] - m[8] + 1.0);
+            q[0] = 0.5 * t;
+            t = 0.5 / t;
+            q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+        } else if (i == 1) {    // j = 2, k = 0
+            t = sqrt(m[4] - m[8] - m[0] + 1.0);
+            q[1] = 0.5 * t;
+            t = 0.5 / t;
+            q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+        } else {                // j = 0, k = 1
+            t = sqrt(m[8] - m[0] - m[4] + 1.0);
+            q[2] = 0.5 * t;
+            t = 0.5 / t;
+            q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
+        }
     }
 }
 DEVI void qmul(const double* a, const double* b, double* o) {

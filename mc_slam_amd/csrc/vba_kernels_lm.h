@@ -408,8 +408,11 @@ __global__ void __launch_bounds__(64) k_update_xyz(Batch B, int nblk_pt) {
         const int a = (blockIdx.x - nblk_pt) * 64 + threadIdx.x;
         if (a >= d.n_free) return;
         const int* va = B.var_act + d.vec0;
-        double dx[15];
-        for (int i = 0; i < P; i++) dx[i] = x[vpos(d, a, i)];
+        double dx[15];   // (constant indices only: a loop up to the run-time P put the array into scratch memory)
+#pragma unroll
+        for (int i = 0; i < 6; i++) dx[i] = x[vpos(d, a, i)];
+#pragma unroll
+        for (int i = 6; i < 15; i++) dx[i] = (P == 15) ? x[vpos(d, a, i)] : 0.0;
         const size_t gk = d.kf0 + a;
         if (va[vpos(d, a, 0)]) {
             double* T = B.pose + 7 * gk;

@@ -22,32 +22,56 @@
 
 #define PCG_TOL 1e-10
 
-// Cholesky-based inverse of one SPD pdim x pdim block (pdim <= 15), by one thread; returns false if not positive definite
-DEVI bool pcg_block_inverse(int P, const double* A, int lda, double* Ai) {
-    double L[15 * 15], Li[15 * 15];
-    for (int i = 0; i < P; i++)
-        for (int j = 0; j <= i; j++) {
-            double s = A[i * lda + j];
-            for (int k = 0; k < j; k++) s -= L[i * 15 + k] * L[j * 15 + k];
-            if (i == j) {
-                if (!(s > 0.0)) return false;
-                L[i * 15 + i] = sqrt(s);
-            } else
-                L[i * 15 + j] = s / L[j * 15 + j];
+// Cholesky-based inverse of the SPD pdim x pdim diagonal blocks (pdim <= 15) of one window: sixteen lanes per block -- a lane per
+// row of L, then per column of L^-1, then per row of the inverse -- with the block, L (in place) and L^-1 in LDS.  (First version: one
+// thread per block with the three 15 x 15 arrays as locals: 5.4 KB of scratch per lane.)  The sums run in the order a scalar
+// left-looking Cholesky takes them.  Sets *bad when a block is not positive definite.
+#define PCG_BI_STRIDE 16
+DEVI void pcg_block_inverses(const Batch& B, const WinDesc& d, double (*sA)[15 * PCG_BI_STRIDE], double (*sLi)[15 * PCG_BI_STRIDE], int* bad) {
+    const int t = threadIdx.x, g = t >> 4, i = t & 15, P = d.pdim, nf = d.n_free, n = d.nS;
+    const double* S = B.S + d.S0;
+    double* Mi = B.pcg_m + 225 * (size_t)d.kf0;
+    for (int a0 = 0; a0 < nf; a0 += 16) {
+        const int a = a0 + g;
+        const bool act = a < nf && i < P;
+        double* A = sA[g];
+        double* Li = sLi[g];
+        if (act)
+            for (int j = 0; j < P; j++) A[i * PCG_BI_STRIDE + j] = S[(size_t)vpos(d, a, i) * n + vpos(d, a, j)];
+        __syncthreads();
+        for (int j = 0; j < P; j++) {   // column j of L
+            if (act && i == j) {
+                double s = A[j * PCG_BI_STRIDE + j];
+                for (int k = 0; k < j; k++) s -= A[j * PCG_BI_STRIDE + k] * A[j * PCG_BI_STRIDE + k];
+                if (!(s > 0.0)) *bad = 1;
+                A[j * PCG_BI_STRIDE + j] = sqrt(s);
+            }
+            __syncthreads();
+            if (act && i > j) {
+                double s = A[i * PCG_BI_STRIDE + j];
+                for (int k = 0; k < j; k++) s -= A[i * PCG_BI_STRIDE + k] * A[j * PCG_BI_STRIDE + k];
+                A[i * PCG_BI_STRIDE + j] = s / A[j * PCG_BI_STRIDE + j];
+            }
+            __syncthreads();
         }
-    for (int j = 0; j < P; j++)   // Li = L^-1 (lower)
-        for (int i = j; i < P; i++) {
-            double s = (i == j) ? 1.0 : 0.0;
-            for (int k = j; k < i; k++) s -= L[i * 15 + k] * Li[k * 15 + j];
-            Li[i * 15 + j] = s / L[i * 15 + i];
+        if (act) {   // column i of L^-1 (lower)
+            for (int r = i; r < P; r++) {
+                double s = (r == i) ? 1.0 : 0.0;
+                for (int k = i; k < r; k++) s -= A[r * PCG_BI_STRIDE + k] * Li[k * PCG_BI_STRIDE + i];
+                Li[r * PCG_BI_STRIDE + i] = s / A[r * PCG_BI_STRIDE + r];
+            }
         }
-    for (int i = 0; i < P; i++)   // A^-1 = Li^T Li
-        for (int j = 0; j < P; j++) {
-            double s = 0.0;
-            for (int k = (i > j ? i : j); k < P; k++) s += Li[k * 15 + i] * Li[k * 15 + j];
-            Ai[i * P + j] = s;
+        __syncthreads();
+        if (act) {   // row i of A^-1 = L^-T L^-1
+            double* out = Mi + 225 * (size_t)a + i * P;
+            for (int j = 0; j < P; j++) {
+                double s = 0.0;
+                for (int k = (i > j ? i : j); k < P; k++) s += Li[k * PCG_BI_STRIDE + i] * Li[k * PCG_BI_STRIDE + j];
+                out[j] = s;
+            }
         }
-    return true;
+        __syncthreads();
+    }
 }
 
 // per-window CG state lives in WinCtrl-independent scratch: pcg_s[8 * win + ..] = rz, rz0, done, iterations, bad
@@ -80,6 +104,7 @@ DEVI void pcg_precond(const Batch& B, const WinDesc& d, int t, int nt) {
 __global__ void __launch_bounds__(256) k_pcg_init(Batch B) {
     __shared__ double red[4];
     __shared__ int sh_bad;
+    __shared__ double sA[16][15 * PCG_BI_STRIDE], sLi[16][15 * PCG_BI_STRIDE];
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
@@ -104,13 +129,7 @@ __global__ void __launch_bounds__(256) k_pcg_init(Batch B) {
         }
     }
     __syncthreads();
-    double* Mi = B.pcg_m + 225 * (size_t)d.kf0;
-    for (int a = t; a < nf; a += 256) {
-        double blk[225];
-        for (int i = 0; i < P; i++)
-            for (int j = 0; j < P; j++) blk[i * P + j] = S[(size_t)vpos(d, a, i) * n + vpos(d, a, j)];
-        if (!pcg_block_inverse(P, blk, P, Mi + 225 * (size_t)a)) sh_bad = 1;
-    }
+    pcg_block_inverses(B, d, sA, sLi, &sh_bad);
     double *xs = pcg_vec(B, d, 0), *rs = pcg_vec(B, d, 1), *zs = pcg_vec(B, d, 2), *ps = pcg_vec(B, d, 3);
     const double* rhs = B.vec + d.vec0;
     for (int i = t; i < np; i += 256) { xs[i] = 0.0; rs[i] = rhs[i]; }

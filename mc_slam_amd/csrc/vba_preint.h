@@ -10,6 +10,7 @@ __global__ void __launch_bounds__(128) k_preint(int n_edges, const int* sample_b
                                                 double* cov_out, double* info_out) {
     __shared__ double A[81], Sg[81], T1[81], BgCa[54];  // Bg (9x3: rows 6..8 used) and Ca (9x3: rows 0..5 used)
     __shared__ double st[61];                            // dt, dP, dV, dR, JPg, JPa, JVg, JVa, JRg
+    __shared__ double Ms[9 * 18];                        // [Sigma' | I] of the final inverse (row pivoting indexes it dynamically: LDS, not registers)
     const int e = blockIdx.x, t = threadIdx.x;
     if (e >= n_edges) return;
     if (t < 61) st[t] = 0.0;
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(128) k_preint(int n_edges, const int* sample_b
     if (info_out && t == 0) {
         // Matrix9d::inverse() of the V/phi-swapped covariance (src/Optimizer.cpp:273-280): Gauss-Jordan, partial pivoting
         const int perm[9] = {0, 1, 2, 6, 7, 8, 3, 4, 5};
-        double M[9][18];
+        double (*M)[18] = reinterpret_cast<double (*)[18]>(Ms);
         for (int i = 0; i < 9; i++)
             for (int j = 0; j < 9; j++) { M[i][j] = Sg[9 * perm[i] + perm[j]]; M[i][9 + j] = (i == j) ? 1.0 : 0.0; }
         for (int c = 0; c < 9; c++) {

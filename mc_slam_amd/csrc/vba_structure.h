@@ -51,29 +51,27 @@ DEVI int st_slot_of(const StBuild& T, const WinDesc& d, const u64_t* LM, const i
 
 // The first eight slots of a landmark's row, fetched together BEFORE the walk over the partner keyframes: the lookups inside
 // that walk then cost no memory round trip (tracks longer than eight fall back to the table)
-struct SlotRow {
-    int v[8];
-    DEVI void load(const StBuild& T, const WinDesc& d, int q, bool valid) {   // q: lm_order rank of the landmark
-        const int4* row = reinterpret_cast<const int4*>(T.tsq + 8 * (size_t)(d.pt0 + (valid ? q : 0)));
-        const int4 lo = row[0], hi = row[1];   // entries beyond the track length are never selected
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+// The first eight record positions of a landmark (rank-major, tsq), as two vector registers passed by value: position r of the
+// landmark's track is picked by name.  (A struct with an int[8] member, and later one with two int4 members, was kept in scratch memory.)
+DEVI void slot_row_load(const StBuild& T, const WinDesc& d, int q, bool valid, int4& lo, int4& hi) {   // q: lm_order rank of the landmark
+    const int4* row = reinterpret_cast<const int4*>(T.tsq + 8 * (size_t)(d.pt0 + (valid ? q : 0)));
+    lo = row[0]; hi = row[1];   // entries beyond the track length are never selected
+}
+// m0: word 0 of the landmark's mask, already in a register (windows of <= 64 keyframes need nothing else)
+DEVI int slot_row_at(int4 lo, int4 hi, const StBuild& T, const WinDesc& d, const u64_t* LM, const int* ob, int p, int b, u64_t m0) {
+    int r;
+    if (d.mwords == 1) r = __popcll(m0 & ((1ull << (b & 63)) - 1ull));
+    else {
+        const u64_t* M = LM + (size_t)p * d.mwords;
+        r = __popcll(M[b >> 6] & ((1ull << (b & 63)) - 1ull));
+        for (int wd = 0; wd < (b >> 6); wd++) r += __popcll(M[wd]);
     }
-    // m0: word 0 of the landmark's mask, already in a register (windows of <= 64 keyframes need nothing else)
-    DEVI int at(const StBuild& T, const WinDesc& d, const u64_t* LM, const int* ob, int p, int b, u64_t m0) const {
-        int r;
-        if (d.mwords == 1) r = __popcll(m0 & ((1ull << (b & 63)) - 1ull));
-        else {
-            const u64_t* M = LM + (size_t)p * d.mwords;
-            r = __popcll(M[b >> 6] & ((1ull << (b & 63)) - 1ull));
-            for (int wd = 0; wd < (b >> 6); wd++) r += __popcll(M[wd]);
-        }
-        if (r >= 8) return T.tslot[d.obs0 + ob[p] + r];
-        int x = v[0];
-#pragma unroll
-        for (int i = 1; i < 8; i++) x = (r == i) ? v[i] : x;
-        return x;
-    }
-};
+    if (r >= 8) return T.tslot[d.obs0 + ob[p] + r];
+    int x = lo.x;
+    x = (r == 1) ? lo.y : x; x = (r == 2) ? lo.z : x; x = (r == 3) ? lo.w : x;
+    x = (r == 4) ? hi.x : x; x = (r == 5) ? hi.y : x; x = (r == 6) ? hi.z : x; x = (r == 7) ? hi.w : x;
+    return x;
+}
 
 // 1. One workgroup per window: first keyframe of every track, observation -> landmark, and the three histograms with their
 //    prefix sums = the segment starts (landmarks per first keyframe, observations per observer, landmarks per reference).
@@ -326,8 +324,8 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
         const bool valid = slot < kseg[a + 1];
         const int p = (FILL && valid) ? T.slot_obs[d.obs0 + slot] : 0;
         const int r = (valid && idp) ? T.slot_ref[d.obs0 + slot] : -1;
-        SlotRow sr;
-        if (FILL) sr.load(T, d, valid ? T.slot_q[d.obs0 + slot] : 0, valid);
+        int4 sr_lo = make_int4(0, 0, 0, 0), sr_hi = make_int4(0, 0, 0, 0);
+        if (FILL) slot_row_load(T, d, valid ? T.slot_q[d.obs0 + slot] : 0, valid, sr_lo, sr_hi);
         const u64_t lmw0 = valid ? T.slot_mask[(size_t)(d.obs0 + slot) * T.smw] : 0ull;   // word 0 of the landmark's mask
         for (int wd = a >> 6; wd < mw; wd++) {
             const u64_t rg = range(wd);
@@ -342,7 +340,7 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
                 const bool h0 = (Mr >> bb) & 1ull, h1 = (rb >> bb) & 1ull;
                 const u64_t m0 = __ballot(h0), m1 = __ballot(h1);
                 if (FILL) {
-                    if (h0) items[c0[b] + __popcll(m0 & lt)] = make_int2(slot, sr.at(T, d, LM, ob, p, b, lmw0));
+                    if (h0) items[c0[b] + __popcll(m0 & lt)] = make_int2(slot, slot_row_at(sr_lo, sr_hi, T, d, LM, ob, p, b, lmw0));
                     if (h1) items[c1[b] + __popcll(m1 & lt)] = make_int2(slot, d.n_obs + T.pt_perm[d.pt0 + p]);
                 }
                 __syncthreads();   // one wave: orders the LDS reads above before lane 0's update
@@ -359,8 +357,8 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
             const int p = (FILL && valid) ? T.pt_inv[d.pt0 + rec] : 0;
             const int q = valid ? T.rec_q[d.pt0 + rec] : 0;
             const u64_t* MQ = T.mask_q + d.mask0 + (size_t)q * mw;   // the landmark's mask, stored in lm_order
-            SlotRow sr;
-            if (FILL) sr.load(T, d, q, valid);
+            int4 sr_lo = make_int4(0, 0, 0, 0), sr_hi = make_int4(0, 0, 0, 0);
+            if (FILL) slot_row_load(T, d, q, valid, sr_lo, sr_hi);
             const u64_t lmw0 = valid ? MQ[0] : 0ull;
             for (int wd = a >> 6; wd < mw; wd++) {
                 const u64_t rg = range(wd);
@@ -373,7 +371,7 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
                     const int b = 64 * wd + bb;
                     const bool h1 = (Mr >> bb) & 1ull;
                     const u64_t m1 = __ballot(h1);
-                    if (FILL && h1) items[c1[b] + __popcll(m1 & lt)] = make_int2(d.n_obs + rec, sr.at(T, d, LM, ob, p, b, lmw0));
+                    if (FILL && h1) items[c1[b] + __popcll(m1 & lt)] = make_int2(d.n_obs + rec, slot_row_at(sr_lo, sr_hi, T, d, LM, ob, p, b, lmw0));
                     __syncthreads();
                     if (lane == 0) c1[b] += __popcll(m1);
                     __syncthreads();
