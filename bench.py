@@ -49,7 +49,7 @@ def _gen_window(spec):
     wl, seed, uniform = spec
     if wl == "c3":
         return synth.config_c3(seed=seed) if uniform else synth.config_c3_ragged(seed=seed)
-    return {"c2": synth.config_c2, "c4": synth.config_c4, "gba": synth.config_gba}[wl](seed=seed)
+    return {"c2": synth.config_c2, "c4": synth.config_c4, "gba": synth.config_gba, "c3s": synth.config_c3s, "c2s": synth.config_c2s}[wl](seed=seed)
 
 
 def make_windows(specs, n_proc):
@@ -130,8 +130,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default: 4096 for c3, 2048 for c2, 16 for c4, 4 for gba, 4096 frames for pose)")
     ap.add_argument("--distinct", type=int, default=None, help="distinct seeded windows generated per rank and replicated to fill the batch (default: 256 for c3, 16 for c2, 2 for c4 / gba)")
     ap.add_argument("--uniform", action="store_true", help="c3: every window exactly 50 KF / 5 000 landmarks / 30 000 edges instead of sizes drawn around it")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose"],
-                    help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, pose = IMU-aided per-frame pose optimisation: extra measurements")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose", "c3s", "c2s"],
+                    help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, pose = IMU-aided per-frame pose "
+                         "optimisation, c3s / c2s = configs[2] / configs[1] with scattered co-visibility (tracks with gaps, fixed co-observers): extra measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcg", action="store_true", help="c4 / gba: skip the second run of the batch with the PCG solver")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -140,9 +141,9 @@ def main():
     ap.add_argument("--single-reps", type=int, default=21, help="vba_solve repetitions behind single_window_ms (0: skip)")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = {"c2": 2048, "c3": 4096, "c4": 16, "gba": 4, "pose": 4096}[args.workload]
+        args.batch = {"c2": 2048, "c3": 4096, "c4": 16, "gba": 4, "pose": 4096, "c3s": 4096, "c2s": 2048}[args.workload]
     if args.distinct is None:
-        args.distinct = {"c2": 16, "c3": 256, "c4": 2, "gba": 2, "pose": 16}[args.workload]
+        args.distinct = {"c2": 64, "c3": 256, "c4": 2, "gba": 2, "pose": 16, "c3s": 64, "c2s": 64}[args.workload]
 
     # `python bench.py --gpus N` (no torchrun): start the N ranks ourselves, before this process touches torch or the GPU
     from mc_slam_amd import launch
@@ -225,7 +226,7 @@ def main():
     check_twins(sol, res, "resident")
     verified = "every window finished both stages; replicas agree bit for bit"
     oracle_res, oracle_ms = None, None
-    full_oracle = args.workload in ("c2", "c3")   # every distinct window; C4 / GBA (5-10 s per oracle solve): the first window, below
+    full_oracle = args.workload in ("c2", "c3", "c3s", "c2s")   # every distinct window; C4 / GBA (5-10 s per oracle solve): the first window, below
     big_oracle = None
     if rank == 0 and not args.no_cpu_baseline and not full_oracle:
         import oracle_lib
@@ -286,7 +287,7 @@ def main():
         # ---- (3) one window at a time, the way LocalMapping calls the reference (src/LocalMapping.cpp:1026-1037) ----
         single = None
         oracle_mode = 1 if args.workload == "c4" else 0
-        if args.single_reps > 0 and args.workload in ("c2", "c3"):
+        if args.single_reps > 0 and args.workload in ("c2", "c3", "c3s", "c2s"):
             import ctypes as C
             from mc_slam_amd import abi, synth
             w1 = synth.config_c3(seed=3) if args.workload == "c3" else wins[0]
@@ -304,7 +305,7 @@ def main():
             ts = sorted(ts[3:])
             single = {"ms": ts[len(ts) // 2] * 1e3, "min_ms": ts[0] * 1e3, "reps": len(ts),
                       "what": "median wall time of vba_solve (H2D + structure + two-stage solve + D2H) on one fresh window, BASELINE configs[%d] seed %s" % (
-                          2 if args.workload == "c3" else 1, "3" if args.workload == "c3" else str(specs[0][1]))}
+                          2 if args.workload in ("c3", "c3s") else 1, "3" if args.workload == "c3" else str(specs[0][1]))}
             if not args.no_cpu_baseline:
                 import oracle_lib
                 # ONE baseline for the whole line: both elimination orders of the oracle are timed on this window (best of 3
@@ -426,9 +427,20 @@ def main():
                    "what": "same batch, vba_problem.solver = VBA_SOLVER_PCG (block-Jacobi PCG on the reduced system, tolerance 1e-10); "
                            "iteration counts, chi2 (1e-4) and translations (1e-6 m) equal to the LDL^T run"}
             bp.close()
+        tile_products = None
+        if batch[0].variant != 0:   # visual-inertial windows: tile products of the symbolic factorisation under both elimination orders
+            import ctypes as C
+            tp = np.zeros((len(wins), 4), dtype=np.int64)
+            for i in range(len(wins)):
+                ba.lib.vba_debug_tile_products(ba.h, i, tp[i].ctypes.data_as(C.c_void_p))
+            if (tp[:, 0] >= 0).all():
+                tile_products = {"vbias_first_mean": float(tp[:, 0].mean()), "keyframe_order_mean": float(tp[:, 1].mean()),
+                                 "windows_in_keyframe_order": int(tp[:, 2].sum()), "chosen_mean": float(tp[:, 3].mean())}
         rng = lambda f: [int(min(f(w) for w in wins)), int(max(f(w) for w in wins))]
         out = {
             "metric": {"c3": "LocalBA windows/sec (50 KF, 5k pts, 30k obs, IMU edges)",
+                       "c3s": "LocalBA windows/sec, scattered co-visibility (50 free + 8 fixed KF, 5k pts, 30k obs, IMU edges) [extra measurement]",
+                       "c2s": "vision-only LocalBundleAdjustment windows/sec, scattered co-visibility (20 KF, 2k pts, 12k obs) [extra measurement]",
                        "c2": "vision-only LocalBundleAdjustment windows/sec (20 KF, 2k pts, 12k obs) [extra measurement]",
                        "c4": "synthetic VI graph solves/sec (200 KF, 50k pts, 500k obs) [extra measurement]",
                        "gba": "global BA solves/sec (300 KF, 30k pts, 180k obs, IMU chain) [extra measurement]"}[args.workload],
@@ -446,6 +458,10 @@ def main():
                                           "; sizes drawn per seed around it: 40..60 KF (mean 50), 100 landmarks per KF, 6 edges per landmark"),
                                     "c2": "BASELINE configs[1]: vision-only LocalBundleAdjustment, 20 KF (18 free) / 2000 XYZ landmarks / "
                                           "12000 EdgeSE3ProjectXYZ, LM 5+10",
+                                    "c3s": "BASELINE configs[2] with scattered co-visibility: 50 free + 8 fixed co-observer KF / 5000 IDP landmarks / 30000 "
+                                           "EdgePRIDP whose tracks are random subsets of the keyframes in view (gaps), ~20 % of the landmarks with a fixed "
+                                           "reference keyframe, GN 5+10",
+                                    "c2s": "BASELINE configs[1] with scattered co-visibility (tracks = random subsets of the keyframes in view), LM 5+10",
                                     "c4": "BASELINE configs[3]: synthetic VI graph, 200 KF / 50000 IDP landmarks / 500000 EdgePRIDP + IMU "
                                           "chain, GN 5+10",
                                     "gba": "GlobalBundleAdjustmentNavStatePRV, 300 KF / 30000 XYZ landmarks / 180000 EdgeNavStatePRPointXYZ "
@@ -453,7 +469,7 @@ def main():
                        "windows_per_gpu_per_step": args.batch, "distinct_windows": len(wins),
                        "n_kf_range": rng(lambda w: w.n_kf), "n_pt_range": rng(lambda w: w.n_pt), "n_obs_range": rng(lambda w: w.n_obs),
                        "mean_n_kf": float(np.mean([w.n_kf for w in batch])), "mean_n_obs": float(np.mean([w.n_obs for w in batch])),
-                       "its_done_histogram": its_hist,
+                       "its_done_histogram": its_hist, "tile_products_per_factorisation": tile_products,
                        "parallelism": "independent windows sharded %d per GPU, no data-path collective" % args.batch,
                        "value_is": "kernel-only (windows resident in HBM, no PCIe in the timed region); value_end_to_end includes H2D + D2H",
                        "host_threads": int(ba.lib.vba_debug_host_threads()), "cpu_affinity": {"cores": len(my_cpus), "first": my_cpus[0], "last": my_cpus[-1]},

@@ -34,6 +34,7 @@ struct Structure {
     int mwords = 1;
     long long item_cap = 0;            // upper bound of the off-diagonal items (exact when every keyframe is free)
     int order = 0;                     // elimination order of the reduced system (see below)
+    long long prod_order[2] = {-1, -1}; // tile products of the symbolic factorisation under order 0 / order 1 (-1: not evaluated)
     std::vector<int> kl_begin, klist;  // left-looking factorisation: per column entry the steps k < J that update it
 };
 
@@ -261,6 +262,7 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
         if (env_order >= 0) st.order = env_order ? 1 : 0;
         else {
             const long long c0 = symbolic(0, false), c1 = symbolic(1, false);
+            st.prod_order[0] = c0; st.prod_order[1] = c1;
             st.order = (10 * c1 < 7 * c0) ? 1 : 0;  // only a clear win: a batch that mixes both orders pays for both patterns
             if (timing) fprintf(stderr, "[vba] tile products of the factorisation: V/Bias-first %lld, keyframe order %lld (nb %d)\n", c0, c1, nb);
         }

@@ -198,6 +198,7 @@ struct Handle {
     std::vector<int> pan_grid, step_npair_max;  // panel tiles / tile pairs per step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
     std::vector<int> win_tiles;  // tile products of one factorisation of window w
+    std::vector<long long> win_prod_order;  // per window: tile products under the V/Bias-first and the keyframe order (-1: not evaluated)
     int algo = 0, variant = 2, solver = 0;
     volatile int* stop_host = nullptr;  // pinned, device-visible
     int* stop_dev = nullptr;
@@ -383,6 +384,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     h->arena_on = n <= arena_max;
     h->desc.assign(n, WinDesc());
     h->win_tiles.assign(n, 0);
+    h->win_prod_order.assign(2 * (size_t)n, -1);
     Staging& G = h->stg;
     auto &pose = G.pose, &vel = G.vel, &bias = G.bias, &pt = G.pt, &uv = G.uv, &ow = G.ow, &meas = G.meas, &info = G.info;
     auto& kffix = G.kffix;
@@ -537,6 +539,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             }
             h->tile_updates += (double)st.tpairs.size();
             h->win_tiles[w] = (int)st.tpairs.size();
+            h->win_prod_order[2 * (size_t)w] = st.prod_order[0]; h->win_prod_order[2 * (size_t)w + 1] = st.prod_order[1];
             if ((int)st.pair_a.size() != d.n_pairs || (int)st.off_pair.size() != d.n_pairs || (int)st.pair_mask.size() != d.n_pairs ||
                 (int)st.pimu_begin.size() != d.n_pairs + 1 || st.lmask.size() != (size_t)d.n_pt * st.mwords)
                 return fail(h, "internal: structure sizes");
@@ -1583,6 +1586,15 @@ int vba_debug_copy(void* handle, int32_t buf_id, uint64_t offset_bytes, void* ds
     if (offset_bytes + nbytes > (b.view ? b.view_bytes : b.cap)) return -1;
     (void)hipSetDevice(h->device);
     return hipMemcpy(dst, reinterpret_cast<char*>(b.ptr()) + offset_bytes, nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+// diagnostic (bench.py --workload c3s): tile products of window w's symbolic factorisation under both elimination orders and the
+// order chosen: out = {V/Bias-first, keyframe by keyframe, chosen order, products of the chosen lists}
+int vba_debug_tile_products(void* handle, int32_t w, int64_t* out) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h || !out || w < 0 || w >= h->n_win || (size_t)w >= h->win_tiles.size()) return -1;
+    out[0] = h->win_prod_order[2 * (size_t)w]; out[1] = h->win_prod_order[2 * (size_t)w + 1];
+    out[2] = h->desc[w].order; out[3] = h->win_tiles[w];
+    return 0;
 }
 // test hook (ctypes): the size of the host thread pool of a handle in this process (cores of this rank's share, see host_threads)
 int vba_debug_host_threads() { return host_threads(); }

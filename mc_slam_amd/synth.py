@@ -154,7 +154,8 @@ def prv_information(cov_pvphi):
 
 # ---------------------------------------------------------------- the generator
 def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_obs=30000, seed=3,
-                kf_dt=0.25, imu_dt=0.005, outlier_frac=0.05, algo=None, noise=True, init_scale=1.0, pix_noise=1.0):
+                kf_dt=0.25, imu_dt=0.005, outlier_frac=0.05, algo=None, noise=True, init_scale=1.0, pix_noise=1.0,
+                tracks="nearest"):
     """Build one synthetic local-BA window.
 
     n_kf keyframes in time order t0..; the FIRST n_fixed in time are fixed (the window's predecessor and,
@@ -164,6 +165,9 @@ def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_ob
     guess (poses, velocities, depths / points): < 1 = a window that starts close to its optimum.  pix_noise multiplies the
     keypoint noise (1 = one pixel at octave 0, ORB-SLAM's model); the information matrices are not changed, so chi2 scales with
     pix_noise^2 and the absolute |dchi2| < 1e-3 stop of Gauss-Newton is reached after fewer iterations for sharp features.
+    tracks: which of the keyframes that see a landmark observe it -- "nearest" = the ones closest in time to the keyframe it was
+    created from (tracks are runs of consecutive keyframes: a sliding window), "random" = a random subset of them (tracks with
+    gaps, co-visibility scattered over the whole span in which the point is in view: a co-visibility window).
     """
     rng = np.random.default_rng(seed)
     R_bc, p_bc, T_cb = extrinsics()
@@ -250,7 +254,10 @@ def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_ob
             cand = kf_ids[ok]
             if cand.size < need:
                 continue
-            vis = cand[np.argsort(np.abs(cand - c), kind="stable")[:need]]
+            if tracks == "random":
+                vis = rng.choice(cand, need, replace=False)
+            else:
+                vis = cand[np.argsort(np.abs(cand - c), kind="stable")[:need]]
             if (vis >= n_fixed).any():
                 break
         else:
@@ -392,6 +399,20 @@ def config_c3_ragged(seed=3):
         outlier_frac, pix = 0.0, 0.3
     return make_window(abi.VARIANT_PRV_IDP, n_kf=n_kf, n_fixed=1, n_pt=100 * n_kf, n_obs=600 * n_kf, seed=seed,
                        outlier_frac=outlier_frac, pix_noise=pix)
+
+
+def config_c3s(seed=3):
+    """The LocalBAPRVIDP window of configs[2] with SCATTERED co-visibility: 50 free keyframes + 8 fixed older
+    co-observers (src/Optimizer.cpp:199-232: every keyframe outside the window that sees a window landmark is added as a fixed
+    vertex), 5 000 landmarks / 30 000 edges whose tracks are random subsets of the keyframes that see them (gaps instead of runs of
+    consecutive keyframes), 10-20 % of the landmarks anchored in a fixed reference keyframe."""
+    return make_window(abi.VARIANT_PRV_IDP, n_kf=58, n_fixed=8, n_pt=5000, n_obs=30000, seed=seed, tracks="random")
+
+
+def config_c2s(seed=2):
+    """configs[1] with scattered co-visibility: the vision-only LocalBundleAdjustment(KeyFrame*, bool*, Map*, LocalMapping*) takes the
+    co-visibility set of the current keyframe as its window (src/Optimizer.cpp:3861-3875), not a run of consecutive keyframes"""
+    return make_window(abi.VARIANT_SE3_XYZ, n_kf=20, n_fixed=2, n_pt=2000, n_obs=12000, seed=seed, tracks="random")
 
 
 def config_c4(seed=4):

@@ -146,6 +146,26 @@ def test_c3_full_size_matches_oracle(ba, oracle):
     _check(p, q, r, qo, ro)
 
 
+@pytest.mark.parametrize("make", [
+    lambda: synth.make_window(abi.VARIANT_PRV_IDP, n_kf=16, n_fixed=4, n_pt=600, n_obs=3600, seed=90, tracks="random"),
+    lambda: synth.make_window(abi.VARIANT_PRV_XYZ, algo=abi.ALGO_LM, n_kf=14, n_fixed=3, n_pt=500, n_obs=3000, seed=91, tracks="random"),
+    lambda: synth.config_c3s(),
+    lambda: synth.config_c2s(),
+])
+def test_scattered_covisibility_windows_match_oracle(ba, oracle, make):
+    """co-visibility windows (LocalBundleAdjustment(KeyFrame*, bool*, Map*, LocalMapping*), src/Optimizer.cpp:3861-3875): tracks are
+    random subsets of the keyframes that see a landmark (gaps), several fixed co-observers, a fifth of the landmarks anchored in a
+    fixed reference keyframe -- none of the layout assumptions of the sliding window hold; alone and inside a batch"""
+    p = make()
+    q, r = ba.solve(p)
+    qo, ro = oracle.solve(p)
+    _check(p, q, r, qo, ro)
+    if p.n_pt <= 1000:
+        ba.upload([p] * 9); ba.run(); qs, rs = ba.download()
+        for qq, rr in zip(qs, rs):
+            assert rr.its_done == r.its_done and np.abs(qq.kf_pose - q.kf_pose).max() < 1e-9
+
+
 def test_noise_free_window_terminates_immediately(ba, oracle):
     p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=8, n_fixed=1, n_pt=200, n_obs=900, seed=41, noise=False)
     q, r = ba.solve(p)
