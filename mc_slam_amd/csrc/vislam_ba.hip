@@ -1147,7 +1147,9 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     int want = h->opt_streams > 0 ? h->opt_streams : env_streams;
     static const int lane_streams = getenv("VBA_LANE_STREAMS") ? atoi(getenv("VBA_LANE_STREAMS")) : 2;
     if (want <= 0 && h->is_lane) want = lane_streams;   // several lanes share the chip: fewer window groups each
-    if (want <= 0) want = (n >= 2048 && h->algo == VBA_ALGO_GN) ? 2 : (n >= 64) ? 4 : (n >= 16) ? 2 : 1;   // default policy (16..48 windows: 2 groups +5..10 %, 4 groups -40 %)
+    // default policy (16..48 windows: 2 groups +5..10 %, 4 groups -40 %; from 64 windows on 4 groups -- round 3, 16 distinct ragged
+    // windows with 3+1 .. 5+3 iterations: 4096 windows 14.0-14.2 k/s with 2 groups, 14.6-14.8 k with 4; 2048 windows 13.7 k either way)
+    if (want <= 0) want = (n >= 64) ? 4 : (n >= 16) ? 2 : 1;
     const int max_streams = std::min(std::min(14, want), (int)h->xstreams.size() + (h->owns_streams ? 11 : 1));
     int ngroups = 1;
     if (!h->profile && max_streams > 1 && n >= 8)
