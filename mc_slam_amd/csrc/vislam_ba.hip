@@ -375,6 +375,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     double t_struct = 0;
     if (n <= 0) return fail(h, "empty batch");
     HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->up_stream));   // (an upload that failed half way may still have copies out of the staging in flight)
     h->uploaded = false;
     h->n_win = n;
     h->regime_n = n;
@@ -416,16 +417,19 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     // arrays grown once, (4) the pool again copies every window's arrays to its offsets (2.2 MB per C3 window).
     static const int n_threads = host_threads();
     const int chunk = 8 * n_threads;
+    size_t tot_kf = 0, tot_pt = 0, tot_obs = 0, tot_mask = 0;
     {   // one allocation per concatenated array instead of the doubling growth of std::vector
-        size_t skf = 0, spt = 0, sobs = 0, simu = 0, spair = 0;
+        size_t skf = 0, spt = 0, sobs = 0, simu = 0, spair = 0, smask = 0;
         for (int w = 0; w < n; w++) {
             const vba_problem* P = probs[w];
             if (!P || P->n_kf < 0 || P->n_pt < 0 || P->n_obs < 0 || P->n_imu < 0 || P->n_kf_free < 0) continue;
             skf += P->n_kf; spt += P->n_pt; sobs += P->n_obs; simu += P->n_imu;
             spair += (size_t)P->n_kf_free * (P->n_kf_free + 1) / 2;
+            smask += (size_t)P->n_pt * (size_t)((P->n_kf + 63) / 64);
         }
+        tot_kf = skf; tot_pt = spt; tot_obs = sobs; tot_mask = smask;
         pose.reserve(7 * skf); vel.reserve(3 * skf); bias.reserve(12 * skf); kffix.reserve(skf);
-        pt.reserve(3 * spt); ptref.reserve(spt); ptobs.reserve(spt + n); lmask.reserve(spt);
+        pt.reserve(3 * spt); ptref.reserve(spt); ptobs.reserve(spt + n); lmask.reserve(smask);
         obskf.reserve(sobs); uv.reserve(2 * sobs); ow.reserve(sobs);
         imui.reserve(simu); imuj.reserve(simu); meas.reserve(61 * simu); info.reserve(81 * simu);
         pair_a.reserve(spair); pair_b.reserve(spair); offpair.reserve(spair); pairmask.reserve(spair);
@@ -443,6 +447,37 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         for (int t = 1; t < std::min(n_threads, cn); t++) pool.emplace_back(work);
         work();
         for (auto& t : pool) t.join();
+    };
+    // The bulk of a window (observations, landmarks, masks: 1 MB of the 1.06 MB of a C3 window) crosses PCIe WHILE the host works on the
+    // next windows: after every packing pass the freshly packed tail of these arrays is copied (their final sizes are known from
+    // the pre-pass above, the pinned staging is never re-allocated under a copy).  Before: validate + symbolic (5.4 ms per 384
+    // windows), pack (5.0), then ONE copy per array (7.5) one after the other -- the link idle for the first half, the host for the second.
+    struct IncCopy { int id; const char* base; size_t esz, total, done; };
+    static const int inc_off = getenv("VBA_UPLOAD_NO_OVERLAP") ? 1 : 0;
+    const bool inc_on = !h->arena_on && !inc_off;
+    std::vector<IncCopy> inc;
+    if (inc_on) {
+        auto reg = [&](int id, const void* base, size_t esz, size_t total) -> int {
+            if (dalloc(h, id, total * esz)) return -1;
+            inc.push_back({id, reinterpret_cast<const char*>(base), esz, total, 0});
+            return 0;
+        };
+        if (reg(BUF_OBSUV, uv.data(), 16, tot_obs) || reg(BUF_OBSW, ow.data(), 8, tot_obs) || reg(BUF_OBSKF, obskf.data(), 4, tot_obs) ||
+            reg(BUF_PT0, pt.data(), 24, tot_pt) || reg(BUF_PTREF, ptref.data(), 4, tot_pt) || reg(BUF_LMASK, lmask.data(), 8, tot_mask) ||
+            reg(BUF_POSE0, pose.data(), 56, tot_kf) || reg(BUF_BIAS0, bias.data(), 96, tot_kf) || reg(BUF_VEL0, vel.data(), 24, tot_kf)) return -1;
+    }
+    auto inc_push = [&](size_t kf_now, size_t pt_now, size_t obs_now, size_t mask_now) -> int {
+        for (auto& a : inc) {
+            const size_t now = (a.id == BUF_OBSUV || a.id == BUF_OBSW || a.id == BUF_OBSKF) ? obs_now
+                             : (a.id == BUF_PT0 || a.id == BUF_PTREF) ? pt_now : (a.id == BUF_LMASK) ? mask_now : kf_now;
+            if (now > a.done) {
+                if (now > a.total) return fail(h, "internal: incremental upload past the reserved size");
+                HIPCHK(h, hipMemcpyAsync(reinterpret_cast<char*>(h->buf[a.id].p) + a.done * a.esz, a.base + a.done * a.esz, (now - a.done) * a.esz,
+                                         hipMemcpyHostToDevice, h->up_stream));
+                a.done = now;
+            }
+        }
+        return 0;
     };
     for (int chunk0 = 0; chunk0 < n; chunk0 += chunk) {
         const int cn = std::min(chunk, n - chunk0);
@@ -627,19 +662,23 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             put(pimu_begin.data() + d.pair0 + w, st.pimu_begin.data(), (size_t)d.n_pairs + 1);
             put(pimu.data() + 2 * (size_t)d.pimu0, st.pimu.data(), st.pimu.size());
         });
+        if (inc_on && inc_push((size_t)kf0, (size_t)pt0, (size_t)obs0, (size_t)mask0)) return -1;
     }
+    if (inc_on && (uv.data() != reinterpret_cast<const double*>(inc[0].base) || pt.data() != reinterpret_cast<const double*>(inc[3].base)))
+        return fail(h, "internal: the upload staging moved under an incremental copy");
     h->algo = probs[0]->algo;
     h->variant = probs[0]->variant;
     const double t_pack = now_ms();
     // pads of S: identity on the padded diagonal, written once (the solve never touches them)
     if (h2d_vec(h, BUF_DESC, h->desc, G.s_desc)) return -1;
     if (dalloc(h, BUF_CTRL, sizeof(WinCtrl) * n)) return -1;
-    if (h2d(h, BUF_POSE0, pose) || h2d(h, BUF_VEL0, vel) || h2d(h, BUF_BIAS0, bias) || h2d(h, BUF_PT0, pt)) return -1;
+    if (!inc_on && (h2d(h, BUF_POSE0, pose) || h2d(h, BUF_VEL0, vel) || h2d(h, BUF_BIAS0, bias) || h2d(h, BUF_PT0, pt))) return -1;
     if (h2d(h, BUF_KFFIX, kffix)) return -1;
     if (dalloc(h, BUF_POSE, pose.size() * 8) || dalloc(h, BUF_VEL, vel.size() * 8) || dalloc(h, BUF_BIAS, bias.size() * 8)) return -1;
     if (dalloc(h, BUF_POSEBK, pose.size() * 8) || dalloc(h, BUF_VELBK, vel.size() * 8) || dalloc(h, BUF_BIASBK, bias.size() * 8)) return -1;
     if (dalloc(h, BUF_KFR, (size_t)kf0 * 12 * 8) || dalloc(h, BUF_PT, pt.size() * 8) || dalloc(h, BUF_PTBK, pt.size() * 8)) return -1;
-    if (h2d(h, BUF_PTREF, ptref) || h2d(h, BUF_PTOBS, ptobs) || h2d(h, BUF_OBSKF, obskf) || h2d(h, BUF_LMASK, lmask)) return -1;
+    if (h2d(h, BUF_PTOBS, ptobs)) return -1;
+    if (!inc_on && (h2d(h, BUF_PTREF, ptref) || h2d(h, BUF_OBSKF, obskf) || h2d(h, BUF_LMASK, lmask))) return -1;
     // built on the device (vba_structure.h): record orders, keyframe segments, item lists; + the scratch of the build
     if (dalloc(h, BUF_OBSPT, (size_t)obs0 * 4) || dalloc(h, BUF_SLOTPERM, (size_t)obs0 * 4) || dalloc(h, BUF_PTPERM, (size_t)pt0 * 4)) return -1;
     if (dalloc(h, BUF_KFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_REFSEG, ((size_t)kf0 + n) * 4) || dalloc(h, BUF_KEYSEG, ((size_t)kf0 + n) * 4)) return -1;
@@ -653,7 +692,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     if (dalloc(h, BUF_SLOTREF, (size_t)obs0 * 4) || dalloc(h, BUF_SLOTQ, (size_t)obs0 * 4) || dalloc(h, BUF_RECQ, (size_t)pt0 * 4) || dalloc(h, BUF_TSQ, (size_t)pt0 * 8 * 4)) return -1;
     if (dalloc(h, BUF_ITEMBEG, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMMID, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMS, (size_t)item0 * 8)) return -1;
     if (dalloc(h, BUF_STKEY, (size_t)pt0 * 4) || dalloc(h, BUF_LMORDER, (size_t)pt0 * 4) || dalloc(h, BUF_SLOTOBS, (size_t)obs0 * 4) || dalloc(h, BUF_PTINV, (size_t)pt0 * 4)) return -1;
-    if (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow)) return -1;
+    if (!inc_on && (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow))) return -1;
     if (dalloc(h, BUF_LVL, (size_t)obs0) || dalloc(h, BUF_CHI2E, (size_t)obs0 * 8) || dalloc(h, BUF_DEPTH, (size_t)obs0 * 8)) return -1;
     const bool idp = probs[0]->variant == VBA_VARIANT_PRV_IDP;
     if (dalloc(h, BUF_EREC, (size_t)obs0 * (idp ? VBA_EREC1 : VBA_EREC) * 8) || dalloc(h, BUF_PREC, (size_t)pt0 * VBA_PREC * 8)) return -1;
@@ -1477,6 +1516,17 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
     {
         static const int ramp = getenv("VBA_NO_RAMP") ? 0 : 1;
         int left = n;
+        if (const char* e = getenv("VBA_CHUNKS")) {   // experiment: explicit chunk sizes "384,1024,1664" (the rest goes into one last chunk)
+            for (const char* q = e; *q && left > 0;) {
+                const int c = std::min(left, std::max(1, atoi(q)));
+                cbeg.push_back(cbeg.back() + c);
+                left -= c;
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+            if (left > 0) cbeg.push_back(cbeg.back() + left);
+            left = 0;
+        }
         const int c = std::max(256, chunk_max / 4);
         const int steps[4] = {c, 2 * c, 13 * c / 4, 9 * c / 2};
         int cap = chunk_max;
@@ -1487,7 +1537,7 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
                 left -= steps[i];
             }
         }
-        const int rest = std::max(1, (left + cap - 1) / cap);
+        const int rest = (left > 0) ? std::max(1, (left + cap - 1) / cap) : 0;
         const int base = cbeg.back();
         for (int q = 1; q <= rest; q++) cbeg.push_back(base + (int)((long long)left * q / rest));
     }

@@ -6,7 +6,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 seq = collections.defaultdict(list)   # kernel -> durations in launch order
 for r in rows:
     n = r["Kernel_Name"].split("(")[0]
-    if n in ("k_chol_panel_ll", "k_chol_diag_ll"):
+    if n in ("k_chol_panel_ll", "k_chol_diag_ll", "k_chol_diag_ll2"):
         seq[n].append(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0))))
 for n, v in seq.items():
     # one factorisation = a run of launches until the grid size pattern repeats; print the second factorisation seen (warm)
