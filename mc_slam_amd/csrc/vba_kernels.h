@@ -1618,162 +1618,6 @@ __global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Split form of one factorisation step for LARGE batches: the fused k_chol_step redoes the diagonal-tile
-// factorisation and both panel solves in every tile-pair workgroup, which is free when the launch is
-// latency-bound (few windows) but ~2x the arithmetic when the chip is full.  k_chol_panel solves every
-// panel tile once (two tiles per wave), k_chol_update only does the MFMA update.
-// ------------------------------------------------------------------------------------------------
-DEVI void ldl32_regs(double (&a)[32], int r, double& rdiag, bool& bad) {
-    bad = false;
-    rdiag = 1.0;
-#pragma unroll
-    for (int cc = 0; cc < 32; cc++) {
-        const double piv = rl64(a[cc], cc);
-        bad = bad || (piv == 0.0) || !isfinite(piv);
-        double y = __builtin_amdgcn_rcp(piv);
-        y = y * (2.0 - piv * y);
-        y = y * (2.0 - piv * y);
-        const double u = a[cc];
-        const double l = u * y;
-        rdiag = (r == cc) ? y : rdiag;
-        a[cc] = (r == cc) ? piv : l;
-#pragma unroll
-        for (int c2 = cc + 1; c2 < 32; c2++) a[c2] -= l * rl64(u, c2);
-    }
-}
-
-__global__ void __launch_bounds__(64) k_chol_panel(Batch B, int k) {
-    __shared__ double Lk[32 * 33];
-    __shared__ double rd[32];
-    const int w = blockIdx.y;
-    const WinDesc& d = B.desc[w];
-    WinCtrl& c = B.ctrl[w];
-    if (!win_on(d, c)) return;
-    if (k >= d.nb) return;
-    const int* pb = B.tl_pan_begin + d.tl_step0;
-    const int* pan = B.tl_pan + d.tl_pan0;
-    const int npan = pb[k + 1] - pb[k];
-    const int bx = blockIdx.x;
-    if (bx > 0 && 2 * bx >= npan) return;
-    const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
-    const int n = d.nS;
-    const double* S = B.S + d.S0;
-    double* Lf = B.Lf + d.S0;
-    double* vec = B.vec + d.vec0;
-    double* yv = B.yv + d.vec0;
-    const size_t dk = (size_t)k * 32;
-    const int pi = 2 * bx + hi;
-    const bool row_act = pi < npan;
-    const int I = row_act ? pan[pb[k] + pi] : 0;
-    double x[32];
-    {
-        const double* src = S + ((size_t)I * 32 + r) * n + dk;
-#pragma unroll
-        for (int q = 0; q < 32; q++) x[q] = row_act ? src[q] : 0.0;
-    }
-    double a[32];
-    const double* arow = S + (dk + r) * n + dk;
-#pragma unroll
-    for (int q = 0; q < 32; q++) a[q] = (q <= r) ? arow[q] : 0.0;
-    double rdiag;
-    bool bad;
-    ldl32_regs(a, r, rdiag, bad);
-    double zr = vec[dk + r];  // lane r (both halves) carries r_k[r]
-    if (hi == 0) {
-#pragma unroll
-        for (int q = 0; q < 32; q++) Lk[r * 33 + q] = (q <= r) ? a[q] : 0.0;
-        rd[r] = rdiag;
-        if (bx == 0) {
-            double* lrow = Lf + (dk + r) * n + dk;
-#pragma unroll
-            for (int q = 0; q < 32; q++)
-                if (q <= r) lrow[q] = a[q];
-        }
-    }
-    if (bx == 0 && lane == 0 && bad) c.chol_fail = 1;
-    __syncthreads();
-    // z_k = L_kk^-1 r_k (unit lower), column-oriented over the wave; afterwards lane q holds z_q
-#pragma unroll
-    for (int q = 0; q < 32; q++) {
-        const double zq = rl64(zr, q);
-        zr = (r > q) ? zr - Lk[r * 33 + q] * zq : zr;
-    }
-    if (bx == 0 && hi == 0) yv[dk + r] = zr;
-    // panel rows: X' L_kk^T = A (unit diagonal), L_Ik = X' D^-1
-#pragma unroll
-    for (int q = 0; q < 32; q++) {
-        const double xq = x[q];
-#pragma unroll
-        for (int c2 = q + 1; c2 < 32; c2++) x[c2] -= xq * Lk[c2 * 33 + q];
-    }
-    double sy = 0.0;
-#pragma unroll
-    for (int q = 0; q < 32; q++) {
-        x[q] *= rd[q];
-        sy += x[q] * rl64(zr, q);
-    }
-    if (row_act) {
-        double* dst = Lf + ((size_t)I * 32 + r) * n + dk;
-#pragma unroll
-        for (int q = 0; q < 32; q++) dst[q] = x[q];
-        vec[(size_t)I * 32 + r] -= sy;
-    }
-}
-
-__global__ void __launch_bounds__(64) k_chol_update(Batch B, int k) {
-    __shared__ double XI[32 * 34];
-    __shared__ double XJ[32 * 34];
-    __shared__ double dg[32];
-    const int w = blockIdx.y;
-    const WinDesc& d = B.desc[w];
-    if (!win_on(d, B.ctrl[w])) return;
-    if (k >= d.nb) return;
-    const int* sb = B.tl_step_begin + d.tl_step0;
-    const int npair = sb[k + 1] - sb[k];
-    const int bx = blockIdx.x;
-    if (bx >= npair) return;
-    const int v = B.tl_pairs[d.tl_pair0 + sb[k] + bx];
-    const int I = v >> 16, J = v & 0xffff;
-    const int lane = threadIdx.x, n = d.nS;
-    double* S = B.S + d.S0;
-    const double* Lf = B.Lf + d.S0;
-    const size_t dk = (size_t)k * 32;
-    if (lane < 32) dg[lane] = Lf[(dk + lane) * n + dk + lane];  // d_k
-    __syncthreads();
-    {   // L_Ik as stored; X'_J = L_Jk D.  16 consecutive doubles per lane.
-        const int row = lane >> 1, c0 = (lane & 1) * 16;
-        const double* si = Lf + ((size_t)I * 32 + row) * n + dk + c0;
-        const double* sj = Lf + ((size_t)J * 32 + row) * n + dk + c0;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            XI[row * 34 + c0 + q] = si[q];
-            XJ[row * 34 + c0 + q] = sj[q] * dg[c0 + q];
-        }
-    }
-    __syncthreads();
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const bool diagp = (I == J);
-#pragma unroll
-    for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++) {
-            if (diagp && tj > ti) continue;
-            double* C = S + ((size_t)I * 32 + 16 * ti) * n + (size_t)J * 32 + 16 * tj;
-            d4_t acc;
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] = C[(size_t)(l4 + 4 * i) * n + l15];
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-                const double av = -XI[(16 * ti + l15) * 34 + 4 * ks + l4];
-                const double bv = XJ[(16 * tj + l15) * 34 + 4 * ks + l4];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = acc[i];
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Left-looking form of the tile factorisation for LARGE batches.  The right-looking kernels above re-read and
 // re-write every trailing tile once per step (~19 MB of HBM traffic per C3 factorisation); here a tile is read from S
 // once, accumulates ALL its updates C_IJ = S_IJ - sum_k L_Ik D_k L_Jk^T in MFMA registers (same k order, hence the same
@@ -1848,75 +1692,9 @@ DEVI void ll_diag_accumulate(const Batch& B, const WinDesc& d, int J, int kb, in
     sdot_out = (lane & 16) ? p1 : p0;   // lane r < 32 holds the sum of row r (lanes 32..63 mirror them)
 }
 
-// diagonal tile of block column J: C_JJ, its L D L^T, y_J, D_J and W_J = (L_JJ^-T D_J^-1)^T (packed like a factor tile)
-DEVI void ll_diag(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, double* CT, double* rd) {
-    const int* pb = B.tl_pan_begin + d.tl_step0;
-    const int* klb = B.tl_kl_begin + d.tl_kb0;
-    const int ent = pb[J] + J;  // column entry of (J,J)
-    const int lane = threadIdx.x, r = lane & 31, hi = lane >> 5;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    d4_t acc[2][2];
-    double sdot = 0.0;
-    ll_diag_accumulate(B, d, J, klb[ent], klb[ent + 1], acc, sdot);
-    // C_JJ through LDS into one row per lane
-#pragma unroll
-    for (int ti = 0; ti < 2; ti++)
-#pragma unroll
-        for (int tj = 0; tj < 2; tj++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) CT[(16 * ti + l4 + 4 * i) * 34 + 16 * tj + l15] = acc[ti][tj][i];
-    __syncthreads();
-    double a[32];
-#pragma unroll
-    for (int q = 0; q < 32; q++) a[q] = (q <= r) ? CT[r * 34 + q] : 0.0;
-    double rdiag;
-    bool bad;
-    ldl32_regs(a, r, rdiag, bad);
-    double* Ljj = B.Lf + d.S0 + ll_tile(d, J, J);
-    const size_t dk = (size_t)J * 32;
-    double* Lk = CT;  // 32 x 33, over the tile every lane has taken its row of
-    __syncthreads();
-    if (hi == 0) {
-#pragma unroll
-        for (int q = 0; q < 32; q++) Lk[r * 33 + q] = (q <= r) ? a[q] : 0.0;
-        rd[r] = rdiag;
-#pragma unroll
-        for (int q = 0; q < 32; q++)
-            if (q <= r) Ljj[ll_pk(r, q)] = a[q];
-        double dr = 0.0;  // a[r] without a dynamic register index
-#pragma unroll
-        for (int q = 0; q < 32; q++) dr = (q == r) ? a[q] : dr;
-        B.dvec[d.vec0 + dk + r] = dr;
-    }
-    if (lane == 0 && bad) c.chol_fail = 1;
-    __syncthreads();
-    // y_J = L_JJ^-1 (b_J - sum_k L_Jk y_k)
-    double zr = (B.vec + d.vec0)[dk + r] - __shfl(sdot, r, 64);
-#pragma unroll
-    for (int q = 0; q < 32; q++) {
-        const double zq = rl64(zr, q);
-        zr = (r > q) ? zr - Lk[r * 33 + q] * zq : zr;
-    }
-    if (hi == 0) (B.yv + d.vec0)[dk + r] = zr;
-    // Z = L_JJ^-1 (unit lower) by columns: the two halves of the wave share a column, rows split even / odd is not
-    // possible (each row needs all earlier ones), so lanes 0..31 own one column each; W[j][k] = Z[j][k] / d_j
-    if (hi == 0) {
-        double z[32];
-#pragma unroll
-        for (int rr = 0; rr < 32; rr++) {
-            double sacc = (rr == r) ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < rr; q++) sacc -= Lk[rr * 33 + q] * z[q];
-            z[rr] = (rr >= r) ? sacc : 0.0;
-        }
-        double* W = B.winv + 1024 * (size_t)d.win;  // d.win: the batch-wide window index (w is relative to the window group)
-#pragma unroll
-        for (int j = 0; j < 32; j++) W[ll_pk(j, r)] = z[j] * rd[j];
-    }
-}
-
-// The same with the elimination of k_chol_step3 (v_fmac_f64_dpp row_newbcast: one instruction per element of a rank-1 update
-// instead of two v_readlane + one FMA).  The rows that ride along with the diagonal tile are the rows of the IDENTITY: a row P of a
+// Diagonal tile of block column J: C_JJ, its L D L^T, y_J, D_J and W_J = (L_JJ^-T D_J^-1)^T (packed like a factor tile), with the
+// elimination of k_chol_step3 (v_fmac_f64_dpp row_newbcast: one instruction per element of a rank-1 update instead of two
+// v_readlane + one FMA: the first form of this kernel, 6 054 instructions, now 2 954).  The rows that ride along with the diagonal tile are the rows of the IDENTITY: a row P of a
 // panel comes out of the elimination as P L^-T D^-1, so the identity comes out as L_JJ^-T D_J^-1 -- W_J itself, for the price of the
 // ride (496 FMACs) instead of a 32-column forward substitution against L_JJ in LDS (in-kernel stamps of ll_diag: 12-18 k cycles
 // LDL^T + 5 k y_J + 13 k W_J per column; here ~10 k for all three).  The right-hand side rides along as one more column (y_J).
@@ -1973,17 +1751,6 @@ DEVI void ll_diag2(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, d
 
 // (A fused variant -- the wave that owns tile (J+1,J) going on to factor diagonal tile J+1 -- was measured: no gain at 512
 // windows)
-__global__ void __launch_bounds__(64) k_chol_diag_ll(Batch B, int J) {
-    __shared__ double CT[32 * 34];
-    __shared__ double rd[32];
-    const int w = blockIdx.x;
-    if (w >= B.n_win) return;
-    const WinDesc& d = B.desc[w];
-    WinCtrl& c = B.ctrl[w];
-    if (!win_on(d, c)) return;
-    if (J >= d.nb) return;
-    ll_diag(B, d, c, w, J, CT, rd);
-}
 __global__ void __launch_bounds__(64) k_chol_diag_ll2(Batch B, int J) {
     __shared__ double CT[32 * 34];
     __shared__ double WT[32 * 34];

@@ -195,7 +195,7 @@ struct Handle {
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
     int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0, max_quads = 1, max_offp = 1, max_pan = 0;
     std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
-    std::vector<int> pan_grid, step_npair_max;  // panel tiles / tile pairs per step (max over the batch)
+    std::vector<int> pan_grid;   // panel tiles per step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
     std::vector<int> win_tiles;  // tile products of one factorisation of window w
     std::vector<long long> win_prod_order;  // per window: tile products under the V/Bias-first and the keyframe order (-1: not evaluated)
@@ -207,6 +207,7 @@ struct Handle {
     int opt_ll_min = 0;        // test hook: batch size from which the left-looking factorisation kernels are used (0: VBA_LL_MIN / 256)
     int opt_chunk = 0, opt_lanes = 0;  // > 0: chunk size / lanes of vba_batch_solve (test hook; defaults from VBA_CHUNK, VBA_LANES)
     int opt_streams = 0;  // > 0: window groups / streams for GN batches (test hook; default from VBA_STREAMS, 1)
+    int opt_chol_step = 0;    // test hook: 1 = the first form of the fused factorisation step (k_chol_step) instead of k_chol_step3
     int opt_stop_after = -1;  // test hook: >= 0 -- every window reads the stop flag as 1 from that terminate() poll on (poll_stop)
     std::vector<ProfEvt> evts;
     std::vector<hipEvent_t> evt_pool;
@@ -398,7 +399,6 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
     const bool pcg = probs[0] && probs[0]->solver == VBA_SOLVER_PCG;
     h->step_grid.clear();
     h->pan_grid.clear();
-    h->step_npair_max.clear();
     h->tile_updates = 0;
     size_t S_tot = 0;
     int kf0 = 0, pt0 = 0, obs0 = 0, imu0 = 0, pair0 = 0, pimu0 = 0, vec0 = 0, part0 = 0;
@@ -566,11 +566,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             d.tl_kb0 = (int)tlkb.size(); d.tl_k0 = (int)tlk.size();
             tlkb.insert(tlkb.end(), st.kl_begin.begin(), st.kl_begin.end());
             tlk.insert(tlk.end(), st.klist.begin(), st.klist.end());
-            if ((int)h->step_grid.size() < d.nb) { h->step_grid.resize(d.nb, 1); h->pan_grid.resize(d.nb, 0); h->step_npair_max.resize(d.nb, 0); }
+            if ((int)h->step_grid.size() < d.nb) { h->step_grid.resize(d.nb, 1); h->pan_grid.resize(d.nb, 0); }
             for (int k = 0; k < d.nb; k++) {
                 h->step_grid[k] = std::max(h->step_grid[k], std::max(1, st.step_npairs[k]));
                 h->pan_grid[k] = std::max(h->pan_grid[k], st.pan_begin[k + 1] - st.pan_begin[k]);
-                h->step_npair_max[k] = std::max(h->step_npair_max[k], st.step_npairs[k]);
             }
             h->tile_updates += (double)st.tpairs.size();
             h->win_tiles[w] = (int)st.tpairs.size();
@@ -881,23 +880,22 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
     } else {
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
-        static const int split_min = getenv("VBA_SPLIT_MIN") ? atoi(getenv("VBA_SPLIT_MIN")) : 64;
-        const bool ll = h->ll_mode;  // decided for the whole batch at upload (S stays pristine, pair masks), also for its window groups
-        if (rn >= split_min || ll) {  // chip full: solve every panel tile once, then the MFMA updates (2 launches per step)
-            static const int diag_old = getenv("VBA_LL_DIAG_OLD") ? 1 : 0;   // A/B: LDL^T by v_readlane broadcasts + explicit W_J
-            for (int k = 0; k < h->max_nb && ll; k++) {  // every tile read once, updated in registers, written once
-                if (diag_old) hipLaunchKernelGGL(k_chol_diag_ll, dim3(n), dim3(64), 0, h->stream, B, k);
-                else hipLaunchKernelGGL(k_chol_diag_ll2, dim3(n), dim3(64), 0, h->stream, B, k);
+        // Two regimes (decided for the whole batch at upload, also for its window groups): from VBA_LL_MIN = 256 windows on the
+        // left-looking tile kernels (S stays pristine, the factor is tile-packed), below that one fused right-looking launch per block
+        // column.  (Until round 3 there was a third one in between, 64..255 windows: the panel solves and the MFMA updates of a
+        // column in two launches, because the fused kernel redid the diagonal tile and two panel solves in every tile-pair workgroup.
+        // With the DPP elimination of k_chol_step3 the fused launch wins up to the left-looking threshold -- 64 windows 9.2 ms per step
+        // against 12.7, 128: 15.1 / 17.7, 200: 21.8 / 23.1, left-looking at 200: 21.7 -- and the split kernels are gone.)
+        if (h->ll_mode) {
+            for (int k = 0; k < h->max_nb; k++) {  // every tile read once, updated in registers, written once
+                hipLaunchKernelGGL(k_chol_diag_ll2, dim3(n), dim3(64), 0, h->stream, B, k);
                 if (h->pan_grid[k] > 0) hipLaunchKernelGGL(k_chol_panel_ll, dim3(h->pan_grid[k] * ngrp), dim3(64), 0, h->stream, B, k, h->pan_grid[k]);
             }
-            for (int k = 0; k < h->max_nb && !ll; k++) {
-                hipLaunchKernelGGL(k_chol_panel, dim3(std::max(1, (h->pan_grid[k] + 1) / 2), n), dim3(64), 0, h->stream, B, k);
-                if (h->step_npair_max[k] > 0)
-                    hipLaunchKernelGGL(k_chol_update, dim3(h->step_npair_max[k], n), dim3(64), 0, h->stream, B, k);
-            }
-        } else {        // latency-bound: one fused launch per step
-            // VBA_CHOL_STEP=1 (A/B): the first form -- diagonal tile, then the panel solves, v_readlane broadcasts
-            static const int step_form = getenv("VBA_CHOL_STEP") ? atoi(getenv("VBA_CHOL_STEP")) : 3;
+        } else {
+            // form 1 (test hook vba_debug_set_chol_step / VBA_CHOL_STEP=1): the first version of the step -- diagonal tile, then the
+            // panel solves, v_readlane broadcasts; kept as the cross-check of the hand-written DPP instruction stream
+            static const int env_form = getenv("VBA_CHOL_STEP") ? atoi(getenv("VBA_CHOL_STEP")) : 0;
+            const int step_form = h->opt_chol_step > 0 ? h->opt_chol_step : (env_form > 0 ? env_form : 3);
             for (int k = 0; k < h->max_nb; k++) {
                 if (step_form == 1) hipLaunchKernelGGL(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
                 else hipLaunchKernelGGL(k_chol_step3, dim3(h->step_grid[k], n), dim3(128), 0, h->stream, B, k);
@@ -1662,6 +1660,13 @@ int vba_debug_set_stop_after(void* handle, int32_t n) {
     if (!h) return -1;
     h->opt_stop_after = n;
     for (Handle* l : h->lanes) l->opt_stop_after = n;
+    return 0;
+}
+// 1: the first form of the fused factorisation step (v_readlane broadcasts, panel solves after the diagonal tile); 0 / 3: k_chol_step3
+int vba_debug_set_chol_step(void* handle, int32_t form) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    h->opt_chol_step = form;
     return 0;
 }
 int vba_debug_set_lin_fallback(void* handle, int32_t on) {

@@ -328,6 +328,27 @@ def test_xyz_linearisation_fallback_equals_edge_parallel(ba, oracle, variant):
     assert r0.its_done == r1.its_done and np.abs(q0.kf_pose - q1.kf_pose).max() < 1e-10 and abs(r0.chi2_vis - r1.chi2_vis) <= 1e-10 * r1.chi2_vis
 
 
+def test_first_form_of_the_factorisation_step_agrees_with_the_dpp_form(ba, oracle):
+    """k_chol_step3 eliminates with hand-written v_fmac_f64_dpp row_newbcast instructions and carries the panel rows along; the first
+    form of the step (k_chol_step: v_readlane broadcasts, panel solves behind the diagonal tile) stays as its cross-check: both
+    against the oracle and against each other (same arithmetic up to the association of l = a / d)."""
+    ba.lib.vba_debug_set_chol_step.argtypes = [C.c_void_p, C.c_int32]
+    ps = [synth.config_c3_ragged(100 + s) for s in (3, 4)] + [synth.make_window(abi.VARIANT_PRV_XYZ, algo=abi.ALGO_LM, n_kf=12, n_fixed=1, n_pt=500, n_obs=3000, seed=35)]
+    new = [ba.solve(p) for p in ps]
+    try:
+        ba.lib.vba_debug_set_chol_step(ba.h, 1)
+        old = [ba.solve(p) for p in ps]
+    finally:
+        ba.lib.vba_debug_set_chol_step(ba.h, 0)
+    for p, (q, r), (q1, r1) in zip(ps, new, old):
+        qo, ro = oracle.solve(p)
+        _check(p, q, r, qo, ro)
+        _check(p, q1, r1, qo, ro)
+        assert r.its_done == r1.its_done and (r.obs_outlier == r1.obs_outlier).all()
+        np.testing.assert_allclose(r.chi2_trace, r1.chi2_trace, rtol=1e-9)
+        assert np.abs(q.kf_pose - q1.kf_pose).max() < 1e-9
+
+
 def test_rerun_is_bit_reproducible(ba):
     p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=10, n_fixed=1, n_pt=400, n_obs=2000, seed=7)
     ba.upload([p]); ba.run(); q1, r1 = ba.download()
@@ -467,9 +488,9 @@ def test_global_ba_map_scale_properties(ba, oracle):
 @pytest.mark.parametrize("variant,nwin", [(abi.VARIANT_PRV_IDP, 66), (abi.VARIANT_PRV_IDP, 388), (abi.VARIANT_PRV_XYZ, 388),
                                           (abi.VARIANT_SE3_XYZ, 66), (abi.VARIANT_SE3_XYZ, 388)])
 def test_large_batches_switch_factorisation_kernels(ba, oracle, variant, nwin):
-    """>= 64 windows: split right-looking kernels (k_chol_panel / k_chol_update); >= 256 windows: left-looking tile
-    kernels (k_chol_diag_ll / k_chol_panel_ll).  Same results as the single-window path (fused right-looking kernel)
-    up to rounding, and the oracle's bars."""
+    """>= 64 windows: the many-window launch organisation (device mirror of the stop word, IMU factors in launches of their own);
+    >= 256 windows: left-looking tile kernels (k_chol_diag_ll2 / k_chol_panel_ll) instead of the fused right-looking step
+    (k_chol_step3).  Same results as the single-window path up to rounding, and the oracle's bars."""
     kw = [dict(n_kf=8, n_pt=200, n_obs=1000), dict(n_kf=13, n_pt=400, n_obs=2200), dict(n_kf=23, n_pt=900, n_obs=5200),
           dict(n_kf=6, n_pt=60, n_obs=300)]
     algo = abi.ALGO_GN if variant == abi.VARIANT_PRV_IDP else abi.ALGO_LM
