@@ -359,6 +359,14 @@ def main():
                 n_cls = max(k["active_launches"] for k in ks)
                 roofline["traffic"] = sum((k["fetch_corrected"] + k["write"]) * k["active_launches"] for k in ks) / n_cls
                 roofline["traffic_source"] = os.path.basename(tj)
+                roofline["traffic_over_algorithmic"] = roofline["traffic"] / (alg_bytes / launches) if alg_bytes > 0 else None
+                # what the class really writes (the Schur kernels are credited with n_p^2 * 8 per solve but write only the blocks of
+                # S that are ever read -- 15 % of it): the same fraction against the bytes written
+                wr = sum(k["write"] * k["active_launches"] for k in ks) / n_cls
+                roofline["written_bytes_per_launch"] = wr
+                roofline["frac_by_written_bytes"] = wr / (classes[dom]["ms"] / launches * 1e-3) / 8e12
+                roofline["fetch_correction"] = ("x2 (FETCH_SIZE = TCC_EA0_RDREQ x 64 B; every fabric read request of these kernels is a 128-B "
+                                                "request: TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ, profiles/round3_tcc_request_sizes.txt)")
             else:
                 roofline["traffic_note"] = "no PMC profile of these kernel sources (csrc %s) at this batch size is committed" % csrc_sha()
         except Exception:
