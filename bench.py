@@ -359,7 +359,15 @@ def main():
                 n_cls = max(k["active_launches"] for k in ks)
                 roofline["traffic"] = sum((k["fetch_corrected"] + k["write"]) * k["active_launches"] for k in ks) / n_cls
                 roofline["traffic_source"] = os.path.basename(tj)
-                roofline["traffic_over_algorithmic"] = roofline["traffic"] / (alg_bytes / launches) if alg_bytes > 0 else None
+                # algorithmic bytes of ONE launch that covers every window of the batch (the PMC figures are per such launch; the
+                # class average above also counts the launches in which part of the windows have already converged)
+                npw = lambda w_: (6 if w_.variant == 0 else 15) * w_.n_kf_free
+                full = {"schur": sum(8.0 * npw(w_) ** 2 for w_ in batch), "factor": sum(16.0 * npw(w_) ** 2 for w_ in batch),
+                        "trsv": sum(8.0 * npw(w_) ** 2 for w_ in batch),
+                        "linearize": sum(32.0 * w_.n_obs + 36.0 * w_.n_pt + 432.0 * w_.n_kf_free for w_ in batch),
+                        "update": sum(36.0 * w_.n_pt + 432.0 * w_.n_kf_free for w_ in batch)}.get(dom)
+                roofline["algorithmic_bytes_full_launch"] = full
+                roofline["traffic_over_algorithmic"] = roofline["traffic"] / full if full else None
                 # what the class really writes (the Schur kernels are credited with n_p^2 * 8 per solve but write only the blocks of
                 # S that are ever read -- 15 % of it): the same fraction against the bytes written
                 wr = sum(k["write"] * k["active_launches"] for k in ks) / n_cls
