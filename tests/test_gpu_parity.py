@@ -121,6 +121,23 @@ def test_empty_window_is_refused_with_a_message(ba):
         ba.solve(q)
 
 
+def test_malformed_imu_arguments_are_refused(ba):
+    """a negative n_imu, or n_imu > 0 with a NULL IMU array, is an error message, not a memcpy with a huge size"""
+    p = synth.make_window(abi.VARIANT_PRV_IDP, n_kf=6, n_fixed=1, n_pt=60, n_obs=240, seed=31)
+    q = p.copy()
+    s = q.as_struct()
+    rb = abi.ResultBuf(q.n_obs)
+    s.n_imu = -3
+    assert ba.lib.vba_solve(ba.h, C.byref(s), C.byref(rb.s), None) != 0
+    assert b"bad sizes" in ba.lib.vba_last_error(ba.h)
+    s = q.as_struct()
+    s.imu_meas = None
+    assert ba.lib.vba_solve(ba.h, C.byref(s), C.byref(rb.s), None) != 0
+    assert b"IMU array is NULL" in ba.lib.vba_last_error(ba.h)
+    q2, r2 = ba.solve(p)          # the handle is still usable
+    assert r2.status == 0
+
+
 def test_unsupported_combinations_fail_loudly(ba):
     # the reference never runs GN on XYZ landmarks nor LM on inverse-depth ones; the backend says so instead of guessing
     p = synth.make_window(abi.VARIANT_SE3_XYZ, algo=abi.ALGO_GN, n_kf=6, n_fixed=2, n_pt=60, n_obs=300, seed=33)

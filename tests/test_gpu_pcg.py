@@ -70,3 +70,21 @@ def test_global_ba_150kf_pcg_equals_ldlt(ba):
     assert abs(r.lambda_final - r1.lambda_final) <= 1e-6 * r1.lambda_final
     assert np.abs(q.kf_pose[:, :3] - q1.kf_pose[:, :3]).max() <= 1e-6
     assert (q.kf_pose[0] == p.kf_pose[0]).all()        # the gauge keyframe did not move
+
+
+def test_pcg_window_with_many_keyframes_and_few_landmarks(ba, oracle):
+    """k_pcg_matvec leaves one partial per 64 rows of the reduced system in the window's slice of the partial-sum array; that slice
+    used to be sized by landmarks and observations only, so a window with many keyframes but few landmarks (here 600 rows = 10
+    partials against 3 * ceil(64 / 64) + 2 = 5 doubles) ran into its neighbour's slice.  A batch of such windows must
+    solve like each of them alone, and like the direct solver."""
+    ps = [_with_pcg(synth.make_window(abi.VARIANT_PRV_IDP, n_kf=41, n_fixed=1, n_pt=64, n_obs=400, seed=180 + i)) for i in range(3)]
+    assert 15 * ps[0].n_kf_free // 64 > 3 * ((ps[0].n_pt + 63) // 64) + 2
+    ba.upload(ps * 3); ba.run(); qs, rs = ba.download()
+    qs = [x.copy() for x in qs]
+    for i, p in enumerate(ps):
+        q1, r1 = ba.solve(p)
+        qd, rd = ba.solve(synth.make_window(abi.VARIANT_PRV_IDP, n_kf=41, n_fixed=1, n_pt=64, n_obs=400, seed=180 + i))
+        for j in (i, i + 3, i + 6):
+            assert rs[j].status == r1.status == 0 and rs[j].its_done == r1.its_done == rd.its_done
+            assert np.abs(qs[j].kf_pose - q1.kf_pose).max() < 1e-9
+        assert abs(r1.chi2_vis - rd.chi2_vis) <= 1e-6 * rd.chi2_vis and np.abs(q1.kf_pose[:, :3] - qd.kf_pose[:, :3]).max() <= 1e-6
