@@ -1407,42 +1407,26 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same step for FEW windows (latency is everything: one window = a chain of nb dependent launches), built around `v_fmac_f64_dpp ... row_newbcast:n` (gfx90a+: the only DPP
-// control the FP64 pipe takes -- lane n of every 16-lane row is broadcast to the row).  In the forms above every element of a
-// rank-1 update costs three instructions: two v_readlane_b32 to bring u_{c2} (held by lane c2) into a scalar pair, one FMA; the
-// 32 x 32 elimination is ~1 500 of them per row set and the wave issues one every four cycles.  With the broadcast inside the
-// FMA an element costs ONE instruction.  What it needs is u replicated in every 16-lane row:
-//   lane L holds row r = L & 31 of the diagonal tile in a[] (both 32-lane halves hold a copy) and, in p[], row r of a panel tile --
-//   lanes 0..31 tile I, lanes 32..63 tile J: one wave carries BOTH panel tiles of its pair through the elimination;
-//   at step cc, u = a[cc] is u_{r}: the even rows (lanes 0..15, 32..47) hold u_0..u_15, the odd rows u_16..u_31; one ds_swizzle
-//   (lane ^ 16, crossbar only) gives every lane the other half, so uLow / uHigh = (u_{j}, u_{16+j}) sit at lane offset j of EVERY row
-//   and  a[c2] -= l * u_{c2}  is  v_fmac_f64_dpp a[c2], (c2 < 16 ? uLow : uHigh), -l  row_newbcast:(c2 & 15).
-// Per step: 2 (31 - cc) FMACs (diagonal rows, panel rows) + ~35 instructions of pivot / reciprocal / right-hand side / swizzle.
+// The same step for FEW windows (latency is everything: one window = a chain of nb dependent launches), built around
+// `v_fmac_f64_dpp ... row_newbcast:n` (gfx90a+: the only DPP control the FP64 pipe takes -- lane n of every 16-lane row is
+// broadcast to the row).  In the form above every element of a rank-1 update costs three instructions: two v_readlane_b32 to bring
+// u_{c2} (held by lane c2) into a scalar pair, one FMA; the 32 x 32 elimination is ~1 500 of them per row set and a lone wave
+// issues one every four to six cycles.  With the broadcast inside the FMA an element costs ONE instruction.  Layout:
+//   lanes 0..31 of a wave hold the 32 rows of the diagonal tile, lanes 32..63 the rows of ONE panel tile, in the same 32 registers
+//   t[] (t[c] = column c of the lane's row); wave 0 of the workgroup takes tile (I,k), wave 1 tile (J,k) -- both eliminate the
+//   diagonal tile (the same instructions, hence the same bits) on their own SIMD, so a pivot costs 31 - cc FMACs for diagonal and
+//   panel rows together (round 3's first DPP form, k_chol_step3, kept the panel rows of both tiles in a second array in one wave:
+//   2 (31 - cc) FMACs per pivot, ~66 instructions; 9.8 k cycles per elimination against 7.0 k here);
+//   at pivot cc, u = t[cc] of lanes 0..31 is u_0..u_31; the broadcast operand must sit in every 16-lane row, so u_0..15 / u_16..31
+//   are replicated with ds_bpermute (crossbar only, no LDS memory) into uLow / uHigh and
+//   t[c2] -= l * u_{c2}  is  v_fmac_f64_dpp t[c2], -(c2 < 16 ? uLow : uHigh), l  row_newbcast:(c2 & 15)
+//   (the sign rides in the DPP word's source modifier: no negated copy of l).
 // The hand-written instruction reads its broadcast operand through DPP: the two wait states a DPP read needs after a VALU write of
-// that register (the compiler does not look into inline assembly) are the s_nop in front of each step's first FMAC.
-// A second wave of the workgroup sits out the elimination at the barrier and then takes half of the trailing MFMA update.
-// Same arithmetic as k_chol_step up to the association of l = a / d: results agree to rounding.
+// that register (the compiler does not look into inline assembly) are the s_nop in front of each pivot's first FMAC.
+// Zero / non-finite pivots are looked for once, in the d vector, after the elimination.
+// Same arithmetic as k_chol_step up to the association of l = a / d: results agree to rounding (and bit for bit with k_chol_step3,
+// checked before that kernel was removed: scripts/step_forms.py).
 // ------------------------------------------------------------------------------------------------
-template <int N, bool NOP>
-DEVI void fmac_bcast(double& acc, double urep, double s) {   // acc += urep[lane N of this lane's row] * s
-    if (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(urep), "v"(s), "n"(N));
-    else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(urep), "v"(s), "n"(N));
-}
-DEVI double swap16(double v) {   // the value of lane L ^ 16
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401f);
-    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401f);
-    return __hiloint2double(hi, lo);
-}
-template <int C2, int CC>
-struct CholUpd {   // columns C2..31 of step CC
-    static DEVI void run(double (&a)[32], double (&p)[32], double uLow, double uHigh, double nl, double nlp) {
-        if constexpr (C2 < 32) {
-            fmac_bcast<(C2 & 15), C2 == CC + 1>(a[C2], (C2 < 16) ? uLow : uHigh, nl);
-            fmac_bcast<(C2 & 15), false>(p[C2], (C2 < 16) ? uLow : uHigh, nlp);
-            CholUpd<C2 + 1, CC>::run(a, p, uLow, uHigh, nl, nlp);
-        }
-    }
-};
 template <int LANE>
 DEVI double wl64(double old, double v) {  // old with lane LANE replaced by the wave-uniform value v (two v_writelane_b32)
     int lo = __double2loint(old), hi = __double2hiint(old);
@@ -1451,43 +1435,69 @@ DEVI double wl64(double old, double v) {  // old with lane LANE replaced by the 
     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(vhi), "n"(LANE));
     return __hiloint2double(hi, lo);
 }
-// One elimination step.  No per-lane masks anywhere: the entries of a[] above the diagonal are never read by another lane (u_{c2}
-// comes from lane c2 > CC, the pivot from lane CC) nor stored where anybody uses them, so they may hold anything -- lane CC's own
-// update with l = 1 and the lanes r < CC run through the same instructions; what a lane must KEEP from step CC (d_CC, z_CC) is
-// captured with v_writelane into lane CC of dout / zout before the unguarded updates overwrite it.
-template <int CC, bool WRITE_X = true>
-struct CholStep {
-    static DEVI void run(double (&a)[32], double (&p)[32], double& rh, double& rp, double& dout, double& zout, bool& bad, bool even_row,
-                         double* Xrow) {
-        if constexpr (CC < 32) {
-            const double u = a[CC], up = p[CC];          // column CC before the division: l d
-            const double piv = rl64(u, CC);              // d_CC (lane CC holds row CC of the diagonal tile)
-            bad = bad || (piv == 0.0) || !isfinite(piv);
-            double y = __builtin_amdgcn_rcp(piv);        // v_rcp_f64 + two Newton steps: full double accuracy
-            y = y * (2.0 - piv * y);
-            y = y * (2.0 - piv * y);
-            const double l = u * y, lp = up * y;
-            const double zc = rl64(rh, CC);              // z_CC is final here
-            dout = wl64<CC>(dout, piv);
-            zout = wl64<CC>(zout, zc);
-            rh -= l * zc;
-            rp -= lp * zc;
-            if constexpr (WRITE_X) Xrow[CC] = lp;        // lanes 0..31: row r of L_Ik (XI), lanes 32..63: row r of L_Jk (XJ)
-            a[CC] = l;
-            p[CC] = lp;
-            if constexpr (CC < 31) {
-                const double us = swap16(u);
-                const double uLow = even_row ? u : us, uHigh = even_row ? us : u;
-                CholUpd<CC + 1, CC>::run(a, p, uLow, uHigh, -l, -lp);
-            }
-            CholStep<CC + 1, WRITE_X>::run(a, p, rh, rp, dout, zout, bad, even_row, Xrow);
+template <int N, bool NOP>
+DEVI void fnmac_bcast(double& acc, double urep, double s) {   // acc -= urep[lane N of this lane's row] * s
+    if (NOP) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(urep), "v"(s), "n"(N));
+    else asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(urep), "v"(s), "n"(N));
+}
+DEVI double bperm64(double v, int byte_addr) {   // the value of lane byte_addr / 4
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int C2, int CC>
+struct ElimUpd {   // columns C2..31 of pivot CC
+    static DEVI void run(double (&t)[32], double uLow, double uHigh, double l) {
+        if constexpr (C2 < 32) {
+            fnmac_bcast<(C2 & 15), false>(t[C2], (C2 < 16) ? uLow : uHigh, l);
+            ElimUpd<C2 + 1, CC>::run(t, uLow, uHigh, l);
         }
     }
 };
+// One pivot.  No per-lane masks anywhere: the entries of a diagonal row above the diagonal are never read by another lane (u_{c2}
+// comes from lane c2 > CC, the pivot from lane CC) nor stored where anybody uses them, so they may hold anything -- lane CC's own
+// update with l = 1 and the lanes r < CC run through the same instructions; what a lane must KEEP from pivot CC (d_CC, z_CC) is
+// captured with v_writelane into lane CC of dout / zout before the unguarded updates overwrite it.
+// uLow / uHigh are column CC replicated into every 16-lane row; those of the NEXT pivot are requested as soon as its column is
+// final (after the first FMAC) so that the crossbar round trip hides behind the remaining FMACs of this one.  (A fully hand-
+// scheduled variant -- the reciprocal, l, z and the captures of the next pivot slotted between the FMACs -- measured the same.)
+template <int CC, bool WRITE_X>
+struct ElimStep {
+    static DEVI void run(double (&t)[32], double& rr, double& dout, double& zout, double uLow, double uHigh, int aLow, int aHigh, double* Xrow) {
+        if constexpr (CC < 32) {
+            const double u = t[CC];                      // column CC before the division: l d
+            const double piv = rl64(u, CC);              // d_CC (lane CC holds row CC of the diagonal tile)
+            double y = __builtin_amdgcn_rcp(piv);        // v_rcp_f64 + two Newton steps: full double accuracy
+            y = y * (2.0 - piv * y);
+            y = y * (2.0 - piv * y);
+            const double l = u * y;
+            const double zc = rl64(rr, CC);              // z_CC is final here
+            dout = wl64<CC>(dout, piv);
+            zout = wl64<CC>(zout, zc);
+            rr -= l * zc;
+            if constexpr (WRITE_X) Xrow[CC] = l;         // lanes 32..63: row r of L_Tk for the MFMA update (lanes 0..31: a scratch row)
+            t[CC] = l;
+            double nLow = 0.0, nHigh = 0.0;
+            if constexpr (CC < 31) {
+                fnmac_bcast<((CC + 1) & 15), true>(t[CC + 1], (CC + 1 < 16) ? uLow : uHigh, l);
+                if constexpr (CC + 1 < 15) nLow = bperm64(t[CC + 1], aLow);
+                if constexpr (CC + 1 < 31) nHigh = bperm64(t[CC + 1], aHigh);
+                __builtin_amdgcn_sched_barrier(0);       // (the requests stay in front of the remaining FMACs)
+                ElimUpd<CC + 2, CC>::run(t, uLow, uHigh, l);
+            }
+            ElimStep<CC + 1, WRITE_X>::run(t, rr, dout, zout, nLow, nHigh, aLow, aHigh, Xrow);
+        }
+    }
+};
+template <bool WRITE_X>
+DEVI void elim_tile(double (&t)[32], double& rr, double& dout, double& zout, int aLow, int aHigh, double* Xrow) {
+    ElimStep<0, WRITE_X>::run(t, rr, dout, zout, bperm64(t[0], aLow), bperm64(t[0], aHigh), aLow, aHigh, Xrow);
+}
 
-__global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
+__global__ void __launch_bounds__(128) k_chol_step4(Batch B, int k) {
     __shared__ double XI[32 * 34];   // rows of L_Ik            (A operand: -L_Ik)
     __shared__ double XJ[32 * 34];   // rows of L_Jk            (B operand: L_Jk D_k, scaled when it is read)
+    __shared__ double XD[32 * 34];   // where the diagonal lanes' Xrow stores go (never read)
     __shared__ double dg[32];
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
@@ -1513,10 +1523,9 @@ __global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
     double* yv = B.yv + d.vec0;
     const size_t dk = (size_t)k * 32;
     const bool diagp = has_pair && (I == J);
-#ifdef VBA_STAMPS   // diagnostic build only (scripts/stamps.sh): shader-clock stamps of workgroup 1 of column 5 into B.dbg
+#ifdef VBA_STAMPS   // diagnostic build only (scripts/stamps.sh): shader-clock stamps of wave 0 of workgroup 1 of column 5 into B.dbg
     unsigned long long st_[8];
-    const bool st_on = (k == 5 && bx == 1 && threadIdx.x == 0);
-#define STAMP(i) { if (k == 5 && bx == 1) { st_[i] = __builtin_amdgcn_s_memtime(); } }
+#define STAMP(i) { if (k == 5 && bx == 1 && wave == 0) { st_[i] = __builtin_amdgcn_s_memtime(); } }
     STAMP(0)
 #else
 #define STAMP(i)
@@ -1530,68 +1539,64 @@ __global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
 #pragma unroll
         for (int i = 0; i < 4; i++) cacc[tj][i] = has_pair ? C[(size_t)(l4 + 4 * i) * n + l15] : 0.0;
     }
-    if (wave == 0) {
-    const int T = hi ? J : I;                        // the panel tile of this half of the wave
-    double a[32], p[32];
-    {   // whole rows, 32-byte pieces (rows start on 256-byte boundaries: nS is a multiple of 32); what lies above the diagonal of
-        // the diagonal tile is never used (see CholStep)
-        const double4* arow = reinterpret_cast<const double4*>(S + (dk + r) * n + dk);
-        const double4* prow = reinterpret_cast<const double4*>(S + ((size_t)T * 32 + r) * n + dk);
+    if (wave == 0 || (has_pair && !diagp)) {
+        const int T = wave ? J : I;                  // this wave's panel tile
+        double t[32];
+        {   // whole rows, 32-byte pieces (rows start on 256-byte boundaries: nS is a multiple of 32)
+            const double4* row = reinterpret_cast<const double4*>(S + (hi ? (size_t)T * 32 + r : dk + r) * n + dk);
+            if (!hi || has_pair) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const double4 va = arow[q];
-            a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
-        }
-        if (has_pair) {
+                for (int q = 0; q < 8; q++) {
+                    const double4 v = row[q];
+                    t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+                }
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const double4 vp = prow[q];
-                p[4 * q] = vp.x; p[4 * q + 1] = vp.y; p[4 * q + 2] = vp.z; p[4 * q + 3] = vp.w;
+                for (int q = 0; q < 32; q++) t[q] = 0.0;
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 32; q++) p[q] = 0.0;
         }
-    }
-    // right-hand side: one more column.  The rhs rows of a panel tile are updated by ONE workgroup, the one of its diagonal pair
-    double rh = vec[dk + r];
-    double rp = (diagp && !hi) ? vec[(size_t)I * 32 + r] : 0.0;
-    bool bad = false;
-    double dout = 1.0, zout = 0.0;                   // lane r ends up with d_r and z_r
+        // right-hand side: one more column.  The rhs rows of a panel tile are updated by ONE workgroup, the one of its diagonal pair
+        double rr = hi ? ((diagp && wave == 0) ? vec[(size_t)I * 32 + r] : 0.0) : vec[dk + r];
+        double dout = 1.0, zout = 0.0;               // lane r < 32 ends up with d_r and z_r
 #ifdef VBA_STAMPS
-    { double sink = a[0] + p[31] + rh; asm volatile("" :: "v"(sink)); }   // the loads have landed
+        { double sink = t[0] + t[31] + rr; asm volatile("" :: "v"(sink)); }   // the loads have landed
 #endif
-    STAMP(1)
-    CholStep<0>::run(a, p, rh, rp, dout, zout, bad, ((lane >> 4) & 1) == 0, (hi ? XJ : XI) + r * 34);
-    STAMP(2)
-    if (bx == 0 && !hi) {                            // the factor's diagonal tile (whole rows: unit L below the diagonal, D on it,
-        a[0] = (r == 0) ? dout : a[0];               // nobody reads above it) and z_k = L_kk^-1 r_k
-        double4* lrow = reinterpret_cast<double4*>(Lf + (dk + r) * n + dk);
+        STAMP(1)
+        elim_tile<true>(t, rr, dout, zout, 4 * l15, 4 * (16 + l15), (hi ? (wave ? XJ : XI) : XD) + r * 34);
+        STAMP(2)
+        if (wave == 0) {
+            if (bx == 0 && !hi) {                    // the factor's diagonal tile (unit L below the diagonal, D on it) and z_k = L_kk^-1 r_k
+                double4* lrow = reinterpret_cast<double4*>(Lf + (dk + r) * n + dk);
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            double4 v;
-            v.x = (4 * q == r) ? dout : a[4 * q];
-            v.y = (4 * q + 1 == r) ? dout : a[4 * q + 1];
-            v.z = (4 * q + 2 == r) ? dout : a[4 * q + 2];
-            v.w = (4 * q + 3 == r) ? dout : a[4 * q + 3];
-            lrow[q] = v;
+                for (int q = 0; q < 8; q++) {
+                    double4 v;
+                    v.x = (4 * q == r) ? dout : t[4 * q];
+                    v.y = (4 * q + 1 == r) ? dout : t[4 * q + 1];
+                    v.z = (4 * q + 2 == r) ? dout : t[4 * q + 2];
+                    v.w = (4 * q + 3 == r) ? dout : t[4 * q + 3];
+                    lrow[q] = v;
+                }
+                yv[dk + r] = zout;
+            }
+            if (bx == 0) {
+                const bool badl = !hi && (dout == 0.0 || !isfinite(dout));
+                if (__ballot(badl) != 0ull && lane == 0) c.chol_fail = 1;
+            }
+            if (diagp && hi) {                       // tile (I,k) of the factor and the rhs rows it has updated
+                double4* dst = reinterpret_cast<double4*>(Lf + ((size_t)I * 32 + r) * n + dk);
+#pragma unroll
+                for (int q = 0; q < 8; q++) dst[q] = make_double4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+                vec[(size_t)I * 32 + r] = rr;
+            }
+            if (!hi) dg[r] = dout;
         }
-        yv[dk + r] = zout;
+        STAMP(3)
     }
-    if (bx == 0 && lane == 0 && bad) c.chol_fail = 1;
-    if (diagp && !hi) {                              // tile (I,k) of the factor and the rhs rows it has updated
-        double4* dst = reinterpret_cast<double4*>(Lf + ((size_t)I * 32 + r) * n + dk);
-#pragma unroll
-        for (int q = 0; q < 8; q++) dst[q] = make_double4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
-        vec[(size_t)I * 32 + r] = rp;
-    }
-    if (!hi) dg[r] = dout;
-    STAMP(3)
-    }   // wave 0
     if (!has_pair) return;                           // (the same for every thread of the workgroup)
-    // C_IJ -= L_Ik D_k L_Jk^T: XI / XJ hold the rows of L_Ik / L_Jk (written step by step above), D_k is dg; 16 rows per wave.
+    // C_IJ -= L_Ik D_k L_Jk^T: XI / XJ hold the rows of L_Ik / L_Jk (written pivot by pivot above), D_k is dg; 16 rows per wave.
     // (LDS-only barrier: the stores of the factor tiles above drain while the MFMAs run)
     lds_barrier();
+    const double* XJp = diagp ? XI : XJ;
 #pragma unroll
     for (int tj = 0; tj < 2; tj++) {
         if (diagp && tj > wave) continue;
@@ -1600,7 +1605,7 @@ __global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             const double av = -XI[(16 * wave + l15) * 34 + 4 * ks + l4];
-            const double bv = XJ[(16 * tj + l15) * 34 + 4 * ks + l4] * dg[4 * ks + l4];
+            const double bv = XJp[(16 * tj + l15) * 34 + 4 * ks + l4] * dg[4 * ks + l4];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
 #pragma unroll
@@ -1609,10 +1614,8 @@ __global__ void __launch_bounds__(128) k_chol_step3(Batch B, int k) {
 #ifdef VBA_STAMPS
     STAMP(4)
     if (wave == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(5) }
-    if (st_on) {
-        st_[6] = __builtin_amdgcn_s_memrealtime();
-        for (int i = 0; i < 7; i++) B.dbg[i] = (double)st_[i];
-    }
+    if (k == 5 && bx == 1 && threadIdx.x == 0)
+        for (int i = 0; i < 6; i++) B.dbg[i] = (double)st_[i];
 #endif
 #undef STAMP
 }
@@ -1693,8 +1696,9 @@ DEVI void ll_diag_accumulate(const Batch& B, const WinDesc& d, int J, int kb, in
 }
 
 // Diagonal tile of block column J: C_JJ, its L D L^T, y_J, D_J and W_J = (L_JJ^-T D_J^-1)^T (packed like a factor tile), with the
-// elimination of k_chol_step3 (v_fmac_f64_dpp row_newbcast: one instruction per element of a rank-1 update instead of two
-// v_readlane + one FMA: the first form of this kernel, 6 054 instructions, now 2 954).  The rows that ride along with the diagonal tile are the rows of the IDENTITY: a row P of a
+// elimination of k_chol_step4 (v_fmac_f64_dpp row_newbcast: one instruction per element of a rank-1 update instead of two
+// v_readlane + one FMA: the first form of this kernel, 6 054 instructions; diagonal rows in lanes 0..31 and the rows that ride
+// along in lanes 32..63 of ONE register array).  The rows that ride along with the diagonal tile are the rows of the IDENTITY: a row P of a
 // panel comes out of the elimination as P L^-T D^-1, so the identity comes out as L_JJ^-T D_J^-1 -- W_J itself, for the price of the
 // ride (496 FMACs) instead of a 32-column forward substitution against L_JJ in LDS (in-kernel stamps of ll_diag: 12-18 k cycles
 // LDL^T + 5 k y_J + 13 k W_J per column; here ~10 k for all three).  The right-hand side rides along as one more column (y_J).
@@ -1708,7 +1712,8 @@ DEVI void ll_diag2(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, d
     d4_t acc[2][2];
     double sdot = 0.0;
     ll_diag_accumulate(B, d, J, klb[ent], klb[ent + 1], acc, sdot);
-    // C_JJ through LDS into one row per lane (both halves of the wave hold a copy; what lies above the diagonal is never used)
+    // C_JJ through LDS into one row per lane of the lower half of the wave (what lies above the diagonal is never used); the upper
+    // half holds the rows of the identity
 #pragma unroll
     for (int ti = 0; ti < 2; ti++)
 #pragma unroll
@@ -1716,27 +1721,30 @@ DEVI void ll_diag2(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, d
 #pragma unroll
             for (int i = 0; i < 4; i++) CT[(16 * ti + l4 + 4 * i) * 34 + 16 * tj + l15] = acc[ti][tj][i];
     lds_barrier();
-    double a[32], p[32];
+    double t[32];
 #pragma unroll
-    for (int q = 0; q < 32; q++) { a[q] = CT[r * 34 + q]; p[q] = (q == r) ? 1.0 : 0.0; }
+    for (int q = 0; q < 32; q++) {
+        const double cv = CT[r * 34 + q];
+        t[q] = hi ? ((q == r) ? 1.0 : 0.0) : cv;
+    }
     const size_t dk = (size_t)J * 32;
-    double rh = (B.vec + d.vec0)[dk + r] - __shfl(sdot, r, 64);   // b_J - sum_k L_Jk y_k
-    double rp = 0.0, dout = 1.0, zout = 0.0;
-    bool bad = false;
+    const double rh = (B.vec + d.vec0)[dk + r] - __shfl(sdot, r, 64);   // b_J - sum_k L_Jk y_k
+    double rr = hi ? 0.0 : rh, dout = 1.0, zout = 0.0;
     lds_barrier();                                    // every lane has its row: CT is free
-    CholStep<0, false>::run(a, p, rh, rp, dout, zout, bad, ((lane >> 4) & 1) == 0, nullptr);
-    if (lane == 0 && bad) c.chol_fail = 1;
+    elim_tile<false>(t, rr, dout, zout, 4 * l15, 4 * (16 + l15), nullptr);
+    {
+        const bool badl = !hi && (dout == 0.0 || !isfinite(dout));
+        if (__ballot(badl) != 0ull && lane == 0) c.chol_fail = 1;
+    }
     if (!hi) {
         B.dvec[d.vec0 + dk + r] = dout;
         (B.yv + d.vec0)[dk + r] = zout;
-        // rows of L_JJ (unit lower, D on the diagonal, zeros above) and of W_J^T into LDS: CT[r][c] = L[r][c], WT[c][r] = W[c][r]
-        // with W[c][r] = (L^-T D^-1)[r][c] = p_r[c]
-#pragma unroll
-        for (int q = 0; q < 32; q++) {
-            CT[r * 34 + q] = (q < r) ? a[q] : ((q == r) ? dout : 0.0);
-            WT[q * 34 + r] = p[q];
-        }
     }
+    // rows of L_JJ (unit lower, D on the diagonal, zeros above) into CT and the identity rows -- row r of L^-T D^-1 = column r of W_J^T --
+    // into WT, one row per lane, no divergence: CT[r][c] = L[r][c], WT[r][c] = W^T[c][r]
+    double* rowp = (hi ? WT : CT) + r * 34;
+#pragma unroll
+    for (int q = 0; q < 32; q++) rowp[q] = (hi || q < r) ? t[q] : ((q == r) ? dout : 0.0);
     lds_barrier();
     // packed order (ll_pk): piece (q, lane) = { M[row][c0], M[row][c0 + 4] }, row = 16 (q >> 2) + (lane & 15), c0 = 8 (q & 3) + (lane >> 4)
     double2* Ljj = reinterpret_cast<double2*>(B.Lf + d.S0 + ll_tile(d, J, J)) + lane;
@@ -1745,7 +1753,7 @@ DEVI void ll_diag2(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, d
     for (int q = 0; q < 8; q++) {
         const int row = 16 * (q >> 2) + l15, c0 = 8 * (q & 3) + l4;
         Ljj[64 * q] = make_double2(CT[row * 34 + c0], CT[row * 34 + c0 + 4]);
-        Wd[64 * q] = make_double2(WT[row * 34 + c0], WT[row * 34 + c0 + 4]);
+        Wd[64 * q] = make_double2(WT[c0 * 34 + row], WT[(c0 + 4) * 34 + row]);
     }
 }
 

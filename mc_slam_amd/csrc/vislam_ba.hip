@@ -207,7 +207,7 @@ struct Handle {
     int opt_ll_min = 0;        // test hook: batch size from which the left-looking factorisation kernels are used (0: VBA_LL_MIN / 256)
     int opt_chunk = 0, opt_lanes = 0;  // > 0: chunk size / lanes of vba_batch_solve (test hook; defaults from VBA_CHUNK, VBA_LANES)
     int opt_streams = 0;  // > 0: window groups / streams for GN batches (test hook; default from VBA_STREAMS, 1)
-    int opt_chol_step = 0;    // test hook: 1 = the first form of the fused factorisation step (k_chol_step) instead of k_chol_step3
+    int opt_chol_step = 0;    // test hook: 1 = the first form of the fused factorisation step (k_chol_step) instead of k_chol_step4
     int opt_stop_after = -1;  // test hook: >= 0 -- every window reads the stop flag as 1 from that terminate() poll on (poll_stop)
     std::vector<ProfEvt> evts;
     std::vector<hipEvent_t> evt_pool;
@@ -884,7 +884,7 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
         // left-looking tile kernels (S stays pristine, the factor is tile-packed), below that one fused right-looking launch per block
         // column.  (Until round 3 there was a third one in between, 64..255 windows: the panel solves and the MFMA updates of a
         // column in two launches, because the fused kernel redid the diagonal tile and two panel solves in every tile-pair workgroup.
-        // With the DPP elimination of k_chol_step3 the fused launch wins up to the left-looking threshold -- 64 windows 9.2 ms per step
+        // With the DPP elimination of k_chol_step4 (then: its first form, k_chol_step3) the fused launch wins up to the left-looking threshold -- 64 windows 9.2 ms per step
         // against 12.7, 128: 15.1 / 17.7, 200: 21.8 / 23.1, left-looking at 200: 21.7 -- and the split kernels are gone.)
         if (h->ll_mode) {
             for (int k = 0; k < h->max_nb; k++) {  // every tile read once, updated in registers, written once
@@ -895,10 +895,10 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
             // form 1 (test hook vba_debug_set_chol_step / VBA_CHOL_STEP=1): the first version of the step -- diagonal tile, then the
             // panel solves, v_readlane broadcasts; kept as the cross-check of the hand-written DPP instruction stream
             static const int env_form = getenv("VBA_CHOL_STEP") ? atoi(getenv("VBA_CHOL_STEP")) : 0;
-            const int step_form = h->opt_chol_step > 0 ? h->opt_chol_step : (env_form > 0 ? env_form : 3);
+            const int step_form = h->opt_chol_step > 0 ? h->opt_chol_step : (env_form > 0 ? env_form : 4);
             for (int k = 0; k < h->max_nb; k++) {
                 if (step_form == 1) hipLaunchKernelGGL(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
-                else hipLaunchKernelGGL(k_chol_step3, dim3(h->step_grid[k], n), dim3(128), 0, h->stream, B, k);
+                else hipLaunchKernelGGL(k_chol_step4, dim3(h->step_grid[k], n), dim3(128), 0, h->stream, B, k);
             }
         }
     }
@@ -1662,7 +1662,7 @@ int vba_debug_set_stop_after(void* handle, int32_t n) {
     for (Handle* l : h->lanes) l->opt_stop_after = n;
     return 0;
 }
-// 1: the first form of the fused factorisation step (v_readlane broadcasts, panel solves after the diagonal tile); 0 / 3: k_chol_step3
+// 1: the first form of the fused factorisation step (v_readlane broadcasts, panel solves after the diagonal tile); anything else: k_chol_step4
 int vba_debug_set_chol_step(void* handle, int32_t form) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;

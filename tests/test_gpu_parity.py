@@ -346,7 +346,7 @@ def test_xyz_linearisation_fallback_equals_edge_parallel(ba, oracle, variant):
 
 
 def test_first_form_of_the_factorisation_step_agrees_with_the_dpp_form(ba, oracle):
-    """k_chol_step3 eliminates with hand-written v_fmac_f64_dpp row_newbcast instructions and carries the panel rows along; the first
+    """k_chol_step4 eliminates with hand-written v_fmac_f64_dpp row_newbcast instructions and carries the panel rows along; the first
     form of the step (k_chol_step: v_readlane broadcasts, panel solves behind the diagonal tile) stays as its cross-check: both
     against the oracle and against each other (same arithmetic up to the association of l = a / d)."""
     ba.lib.vba_debug_set_chol_step.argtypes = [C.c_void_p, C.c_int32]
@@ -507,7 +507,7 @@ def test_global_ba_map_scale_properties(ba, oracle):
 def test_large_batches_switch_factorisation_kernels(ba, oracle, variant, nwin):
     """>= 64 windows: the many-window launch organisation (device mirror of the stop word, IMU factors in launches of their own);
     >= 256 windows: left-looking tile kernels (k_chol_diag_ll2 / k_chol_panel_ll) instead of the fused right-looking step
-    (k_chol_step3).  Same results as the single-window path up to rounding, and the oracle's bars."""
+    (k_chol_step4).  Same results as the single-window path up to rounding, and the oracle's bars."""
     kw = [dict(n_kf=8, n_pt=200, n_obs=1000), dict(n_kf=13, n_pt=400, n_obs=2200), dict(n_kf=23, n_pt=900, n_obs=5200),
           dict(n_kf=6, n_pt=60, n_obs=300)]
     algo = abi.ALGO_GN if variant == abi.VARIANT_PRV_IDP else abi.ALGO_LM
