@@ -354,7 +354,7 @@ def main():
             if tr.get("batch") == args.batch and tr.get("csrc_sha") == csrc_sha() and tr.get("workload", "c3") == args.workload:
                 kmap = {"schur": ["k_schur_all", "k_schur_all_w", "k_schur_diag", "k_schur_off", "k_schur_ref"], "linearize": ["k_lin2", "k_lin2_imu", "k_lin_imu"],
                         "factor": ["k_chol_step", "k_chol_step3", "k_chol_step4", "k_chol_panel", "k_chol_update", "k_chol_diag_ll", "k_chol_diag_ll2", "k_chol_panel_ll"],
-                        "trsv": ["k_trsv", "k_trsv_w"], "update": ["k_update"]}
+                        "trsv": ["k_trsv", "k_trsv_w", "k_trsv_p"], "update": ["k_update"]}
                 ks = [tr["kernels"][k] for k in kmap.get(dom, []) if k in tr["kernels"]]
                 n_cls = max(k["active_launches"] for k in ks)
                 roofline["traffic"] = sum((k["fetch_corrected"] + k["write"]) * k["active_launches"] for k in ks) / n_cls

@@ -1494,33 +1494,48 @@ DEVI void elim_tile(double (&t)[32], double& rr, double& dout, double& zout, int
     ElimStep<0, WRITE_X>::run(t, rr, dout, zout, bperm64(t[0], aLow), bperm64(t[0], aHigh), aLow, aHigh, Xrow);
 }
 
-__global__ void __launch_bounds__(128) k_chol_step4(Batch B, int k) {
+// ONE = a single window: what the kernel would fetch from the window descriptor and the step table (descriptor -> step table ->
+// pair list -> tile rows: four dependent loads, ~600 cycles each, in front of the elimination) comes in the kernel arguments, and
+// the chain is pair list -> tile rows.
+struct StepOne { int algo, nS, nb, vec0, pair_off, npair; long long S0; };
+template <bool ONE>
+__global__ void __launch_bounds__(128) k_chol_step4(Batch B, int k, StepOne so) {
     __shared__ double XI[32 * 34];   // rows of L_Ik            (A operand: -L_Ik)
     __shared__ double XJ[32 * 34];   // rows of L_Jk            (B operand: L_Jk D_k, scaled when it is read)
     __shared__ double XD[32 * 34];   // where the diagonal lanes' Xrow stores go (never read)
     __shared__ double dg[32];
     const int w = blockIdx.y;
-    const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
-    if (!win_on(d, c)) return;
-    if (k >= d.nb) return;
-    const int* sb = B.tl_step_begin + d.tl_step0;
-    const int npair = sb[k + 1] - sb[k];
+    int n, npair, pair_off;
+    long long S0;
+    int vec0;
+    if constexpr (ONE) {
+        if (!(c.active && (so.algo == 0 || c.lm_need_trial))) return;   // win_on
+        if (k >= so.nb) return;
+        n = so.nS; npair = so.npair; pair_off = so.pair_off; S0 = so.S0; vec0 = so.vec0;
+    } else {
+        const WinDesc& d = B.desc[w];
+        if (!win_on(d, c)) return;
+        if (k >= d.nb) return;
+        const int* sb = B.tl_step_begin + d.tl_step0;
+        npair = sb[k + 1] - sb[k];
+        pair_off = d.tl_pair0 + sb[k];
+        n = d.nS; S0 = d.S0; vec0 = d.vec0;
+    }
     const int bx = blockIdx.x;
     if (bx >= (npair > 0 ? npair : 1)) return;
     const bool has_pair = bx < npair;
     int I = 0, J = 0;
     if (has_pair) {
-        const int v = B.tl_pairs[d.tl_pair0 + sb[k] + bx];
+        const int v = B.tl_pairs[pair_off + bx];
         I = v >> 16;
         J = v & 0xffff;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5;
-    const int n = d.nS;
-    double* S = B.S + d.S0;
-    double* Lf = B.Lf + d.S0;
-    double* vec = B.vec + d.vec0;
-    double* yv = B.yv + d.vec0;
+    double* S = B.S + S0;
+    double* Lf = B.Lf + S0;
+    double* vec = B.vec + vec0;
+    double* yv = B.yv + vec0;
     const size_t dk = (size_t)k * 32;
     const bool diagp = has_pair && (I == J);
 #ifdef VBA_STAMPS   // diagnostic build only (scripts/stamps.sh): shader-clock stamps of wave 0 of workgroup 1 of column 5 into B.dbg
@@ -1530,18 +1545,11 @@ __global__ void __launch_bounds__(128) k_chol_step4(Batch B, int k) {
 #else
 #define STAMP(i)
 #endif
-    // this wave's half of the trailing tile C_IJ (rows 16 wave .. 16 wave + 15), requested now: it arrives while the elimination runs
     const int l15 = lane & 15, l4 = lane >> 4;
-    d4_t cacc[2];
-#pragma unroll
-    for (int tj = 0; tj < 2; tj++) {
-        const double* C = S + ((size_t)I * 32 + 16 * wave) * n + (size_t)J * 32 + 16 * tj;
-#pragma unroll
-        for (int i = 0; i < 4; i++) cacc[tj][i] = has_pair ? C[(size_t)(l4 + 4 * i) * n + l15] : 0.0;
-    }
-    if (wave == 0 || (has_pair && !diagp)) {
-        const int T = wave ? J : I;                  // this wave's panel tile
-        double t[32];
+    const bool elim = wave == 0 || (has_pair && !diagp);
+    const int T = wave ? J : I;                      // this wave's panel tile
+    double t[32], rr = 0.0;
+    if (elim) {
         {   // whole rows, 32-byte pieces (rows start on 256-byte boundaries: nS is a multiple of 32)
             const double4* row = reinterpret_cast<const double4*>(S + (hi ? (size_t)T * 32 + r : dk + r) * n + dk);
             if (!hi || has_pair) {
@@ -1556,7 +1564,18 @@ __global__ void __launch_bounds__(128) k_chol_step4(Batch B, int k) {
             }
         }
         // right-hand side: one more column.  The rhs rows of a panel tile are updated by ONE workgroup, the one of its diagonal pair
-        double rr = hi ? ((diagp && wave == 0) ? vec[(size_t)I * 32 + r] : 0.0) : vec[dk + r];
+        rr = hi ? ((diagp && wave == 0) ? vec[(size_t)I * 32 + r] : 0.0) : vec[dk + r];
+    }
+    // this wave's half of the trailing tile C_IJ (rows 16 wave .. 16 wave + 15), requested behind the rows the elimination waits
+    // for: it arrives while the elimination runs
+    d4_t cacc[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+        const double* C = S + ((size_t)I * 32 + 16 * wave) * n + (size_t)J * 32 + 16 * tj;
+#pragma unroll
+        for (int i = 0; i < 4; i++) cacc[tj][i] = has_pair ? C[(size_t)(l4 + 4 * i) * n + l15] : 0.0;
+    }
+    if (elim) {
         double dout = 1.0, zout = 0.0;               // lane r < 32 ends up with d_r and z_r
 #ifdef VBA_STAMPS
         { double sink = t[0] + t[31] + rr; asm volatile("" :: "v"(sink)); }   // the loads have landed
@@ -2003,111 +2022,176 @@ __global__ void __launch_bounds__(256) k_trsv(Batch B) {
     for (int q = t; q < n; q += 256) vec[q] = xs[q];
 }
 
-// The same back-substitution for the row-major factor of the few-window kernels, where its latency counts (one window: 8-10
-// calls per solve, 23 block columns each, every column a chain  tile indices -> tiles -> products -> barrier -> 32-step triangular
-// solve -> barrier).  In-kernel stamps of k_trsv at C3 size: 6.0 k of the 9.4 k cycles of a long column go into the gather, most of
-// it ISSUING it -- sixteen 8-byte loads per tile and lane, each with its own 64-bit address arithmetic (~55 cycles apiece) behind a
-// dependent fetch of the tile index.  Here
-//   * the tile lists of the window are copied into LDS once (no index -> tile dependency through memory per column),
-//   * a lane takes two neighbouring columns of eight rows of a tile: eight 16-byte loads whose addresses are one uniform tile base +
-//     a 32-bit lane offset + a multiple of the row pitch,
-//   * the tiles and the diagonal tile of column k-1 -- which depend on the tile lists only, not on x -- are requested BEFORE the
-//     barriers and the triangular solve of column k (barriers that do not drain the vector-memory queue: lds_barrier).  Six tiles
-//     per wave cover the 22 tiles of the longest column of a 50-keyframe window; longer columns fetch the rest on the fly.
-// Fixed summation order (16 partial rows in order).  Measured at C3 size: 60 us per call against 66 (a dedicated solving wave
-// that fetches its own column of the diagonal tile: no better; the 32-step triangular solve and the two barriers per column remain).
-#define TRSV_W_PF 6
-__global__ void __launch_bounds__(256) k_trsv_w(Batch B) {
-    extern __shared__ double xs[];  // nS doubles + 16*32 partials + 32*33 diagonal tile + (tile lists) ints
+// The back-substitution for the row-major factor of the few-window kernels, where its latency counts (one window: 8-10 calls per
+// solve, 23 block columns each), as a two-stage pipeline (8 waves).  In k_trsv a block column is a chain  products of ALL its tiles
+// with x -> barrier -> 32-step triangular solve -> barrier  (2.3 us per column at C3 size even with the tile lists in LDS and the
+// tiles prefetched: round 3's k_trsv_w, 52 us per call), although only ONE of those tiles, (k+1, k), needs the x_{k+1} that the
+// previous column has just produced.  Here
+//   * wave 0 only solves: column K in 32 steps of  x_j = readlane(acc, j); acc -= reg[j] * x_j.  Lanes 0..31 hold column c of the
+//     (strictly lower) diagonal tile in reg[] and the running right-hand side in acc; lanes 32..63 hold column c of tile (K, K-1)
+//     and accumulate -sum_j L[32K + j][32(K-1) + c] x_j with the SAME instruction: the one product that needs x_K is finished when x_K
+//     is, and seeds column K - 1;
+//   * waves 1..7 work one column ahead: the products of column K - 1 with the tiles I >= K + 1 (x_I is final), summed to one partial
+//     row per wave; they also bring the diagonal tile and tile (K-1, K-2) of the next solve into LDS (zeros above the diagonal, so the
+//     solve needs no mask) and divide z by d (the solve starts from D^-1 z); their tiles are requested one phase earlier still
+//     (registers: eight 16-byte loads per tile from one wave-uniform base + 32-bit lane offsets), so no load waits inside a phase.
+// One LDS-only barrier per column; the chain per column is wave 0's ~10 LDS reads + 32 x 3 instructions.  Fixed summation order.
+// Measured at C3 size: 37 -> 30 us per call (k_trsv_w: 52).
+#define TRSV_P_PF 4
+#define TRSV_P_DW 7
+__global__ void __launch_bounds__(512) k_trsv_p(Batch B) {
+    extern __shared__ double xs[];  // nS doubles | 2 x 7 x 32 partial rows | 2 x 32 x 65 solve blocks | 32 seeds | tile lists (ints)
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
     if (!win_on(d, B.ctrl[w])) return;
-    const int n = d.nS, t = threadIdx.x;
+    const int n = d.nS, nb = d.nb, t = threadIdx.x;
     double* part = xs + n;
-    double* Lt = part + 512;
-    int* lpb = reinterpret_cast<int*>(Lt + 32 * 33);   // [nb + 1] column starts, then the tile rows
-    int* lpan = lpb + d.nb + 1;
+    double* R = part + 2 * TRSV_P_DW * 32;
+    double* seed = R + 2 * 32 * 65;
+    int* lpb = reinterpret_cast<int*>(seed + 32);   // [nb + 1] column starts, then the tile rows
+    int* lpan = lpb + nb + 1;
     const double* S = B.Lf + d.S0;
     double* vec = B.vec + d.vec0;
     const double* yv = B.yv + d.vec0;
     {
         const int* pb = B.tl_pan_begin + d.tl_step0;
         const int* pan = B.tl_pan + d.tl_pan0;
-        const int np = pb[d.nb];
-        for (int q = t; q <= d.nb; q += 256) lpb[q] = pb[q];
-        for (int q = t; q < np; q += 256) lpan[q] = pan[q];
+        const int np = pb[nb];
+        for (int q = t; q <= nb; q += 512) lpb[q] = pb[q];
+        for (int q = t; q < np; q += 512) lpan[q] = pan[q];
     }
-    for (int q = t; q < n; q += 256) xs[q] = yv[q];
+    for (int q = t; q < n; q += 512) xs[q] = yv[q];
+    for (int q = t; q < 2 * TRSV_P_DW * 32 + 2 * 32 * 65 + 32; q += 512) part[q] = 0.0;
     __syncthreads();
-    const int wave = t >> 6, lane = t & 63, cp = lane & 15, rg = lane >> 4;   // column pair, group of eight rows
-    const unsigned rowb = (unsigned)n * 8u;                                  // row pitch in bytes
-    const unsigned lane_off = (unsigned)(rg * 8) * rowb + (unsigned)cp * 16u;
-    double2 nlv[TRSV_W_PF][8];
-    double ndg[4];
-    int nI[TRSV_W_PF];
-    auto tile_load = [&](int I, size_t dk, double2 (&lv)[8]) {
-        const char* tb = reinterpret_cast<const char*>(S + (size_t)I * 32 * n + dk);   // wave-uniform
+    const int wave = t >> 6, lane = t & 63;
+    if (wave == 0) {
+        // ---------------- the solving wave ----------------
+        const int c = lane & 31, hiL = lane >> 5;
+        lds_barrier();                               // (the loaders' prologue)
+        for (int K = nb - 1; K >= 0; K--) {
+            const double* Rk = R + (K & 1) * (32 * 65);
+            const double* pk = part + (K & 1) * (TRSV_P_DW * 32);
+            double reg[32];
 #pragma unroll
-        for (int rr = 0; rr < 8; rr++) lv[rr] = *reinterpret_cast<const double2*>(tb + (lane_off + (unsigned)rr * rowb));
-    };
-    auto tile_dot = [&](int I, const double2 (&lv)[8], double& s0, double& s1) {
-        const double* x = xs + I * 32 + rg * 8;
+            for (int j = 0; j < 32; j++) reg[j] = Rk[j * 65 + lane];
+            double acc = 0.0;
+            if (!hiL) {
+                acc = xs[K * 32 + c] + seed[c];      // D^-1 z (divided by the loaders) - the product with tile (K+1, K)
 #pragma unroll
-        for (int rr = 0; rr < 8; rr++) { s0 += lv[rr].x * x[rr]; s1 += lv[rr].y * x[rr]; }
-    };
-    auto prefetch = [&](int k) {
-        const size_t dk = (size_t)k * 32;
-        const int i0 = lpb[k], m = lpb[k + 1] - i0;
-#pragma unroll
-        for (int s = 0; s < TRSV_W_PF; s++) {
-            const int i = wave + 4 * s;
-            nI[s] = (i < m) ? lpan[i0 + i] : -1;      // (wave-uniform)
-            if (nI[s] >= 0) tile_load(nI[s], dk, nlv[s]);
-        }
-        const char* db = reinterpret_cast<const char*>(S + dk * n + dk);
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const unsigned q = t + 256 * u; ndg[u] = *reinterpret_cast<const double*>(db + ((q >> 5) * rowb + (q & 31) * 8u)); }
-    };
-    prefetch(d.nb - 1);
-    for (int k = d.nb - 1; k >= 0; k--) {
-        const size_t dk = (size_t)k * 32;
-        const int i0 = lpb[k], m = lpb[k + 1] - i0;
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int q = 0; q < TRSV_W_PF; q++)          // tile i of the column goes to wave i % 4
-            if (nI[q] >= 0) tile_dot(nI[q], nlv[q], s0, s1);
-        for (int i = wave + 4 * TRSV_W_PF; i < m; i += 4) {
-            const int I = lpan[i0 + i];
-            double2 lv[8];
-            tile_load(I, dk, lv);
-            tile_dot(I, lv, s0, s1);
-        }
-        *reinterpret_cast<double2*>(part + (wave * 4 + rg) * 32 + 2 * cp) = make_double2(s0, s1);
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int q = t + 256 * u; Lt[(q >> 5) * 33 + (q & 31)] = ndg[u]; }
-        if (k > 0) prefetch(k - 1);                  // in flight during the barriers and the triangular solve below
-        lds_barrier();
-        if (t < 64) {
-            const int c = t & 31;
-            double col[32];
-#pragma unroll
-            for (int j = 0; j < 32; j++) col[j] = Lt[j * 33 + c];  // column c of L_kk (rows j >= c are the factor)
-            double dgc = 1.0;
-#pragma unroll
-            for (int j = 0; j < 32; j++) dgc = (j == c) ? col[j] : dgc;  // d_c sits on the diagonal of the tile
-            double v = xs[dk + c] / dgc;                                  // D^-1 z
-#pragma unroll
-            for (int q = 0; q < 16; q++) v -= part[q * 32 + c];
-#pragma unroll
-            for (int j = 31; j >= 0; j--) {                               // unit-diagonal L_kk^T x_k = v
-                const double xj = rl64(v, j);
-                v = (c < j) ? v - col[j] * xj : v;
+                for (int q = 0; q < TRSV_P_DW; q++) acc -= pk[q * 32 + c];
             }
-            if (t < 32) xs[dk + c] = v;
+#pragma unroll
+            for (int j = 31; j >= 0; j--) {          // unit-diagonal L_KK^T x_K = acc (reg is zero on and above the diagonal)
+                const double xj = rl64(acc, j);
+                acc = __builtin_fma(-reg[j], xj, acc);
+            }
+            if (hiL) seed[c] = acc; else xs[K * 32 + c] = acc;
+            lds_barrier();
         }
+    } else {
+        // ---------------- the seven waves that work ahead ----------------
+        const int dw = wave - 1, t2 = t - 64;        // 0..447
+        const int cp = lane & 15, rg = lane >> 4;   // column pair, group of eight rows of a tile
+        const unsigned rowb = (unsigned)n * 8u;      // row pitch in bytes
+        const unsigned lane_off = (unsigned)(rg * 8) * rowb + (unsigned)cp * 16u;
+        double2 nlv[TRSV_P_PF][8];
+        int nI[TRSV_P_PF];
+        double rst[5];
+        auto tile_load = [&](int I, size_t dk, double2 (&lv)[8]) {
+            const char* tb = reinterpret_cast<const char*>(S + (size_t)I * 32 * n + dk);   // wave-uniform
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) lv[rr] = *reinterpret_cast<const double2*>(tb + (lane_off + (unsigned)rr * rowb));
+        };
+        auto tile_dot = [&](int I, const double2 (&lv)[8], double& s0, double& s1) {
+            const double* x = xs + I * 32 + rg * 8;
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) { s0 += lv[rr].x * x[rr]; s1 += lv[rr].y * x[rr]; }
+        };
+        // the tiles (I, col) with I >= col + 2 (tile (col + 1, col), if the column has it, belongs to the solving wave)
+        auto dot_range = [&](int col, int& i0, int& m) {
+            i0 = lpb[col]; m = lpb[col + 1] - i0;
+            if (m > 0 && lpan[i0] == col + 1) { i0++; m--; }
+        };
+        auto prefetch_dots = [&](int col) {
+#pragma unroll
+            for (int s = 0; s < TRSV_P_PF; s++) nI[s] = -1;
+            if (col < 0) return;
+            int i0, m;
+            dot_range(col, i0, m);
+#pragma unroll
+            for (int s = 0; s < TRSV_P_PF; s++) {
+                const int i = dw + TRSV_P_DW * s;
+                nI[s] = (i < m) ? lpan[i0 + i] : -1;      // (wave-uniform)
+                if (nI[s] >= 0) tile_load(nI[s], (size_t)col * 32, nlv[s]);
+            }
+        };
+        // solve block of column K: element e = 1024 tile + 32 j + c; tile 0 = (K, K), tile 1 = (K, K - 1) (zeros if it is not in the
+        // factor).  What a lane fetches and where it goes do not depend on K: byte offsets from a wave-uniform base, computed once.
+        unsigned roff[5];
+        int ridx[5];
+        bool rkeep[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int e = t2 + 448 * u;
+            const int tile = (e >> 10) & 1, j = (e >> 5) & 31, cc = e & 31;
+            roff[u] = (unsigned)j * rowb + (unsigned)(cc + 32 - 32 * tile) * 8u;   // from 32 columns left of the diagonal tile
+            ridx[u] = (e < 2048) ? j * 65 + 32 * tile + cc : -1;
+            rkeep[u] = tile == 1 || cc < j;
+        }
+        const unsigned doff = (unsigned)(lane & 31) * (rowb + 8u) + 256u;           // the diagonal (wave 7 divides z by it)
+        double rdg = 1.0;
+        auto prefetch_R = [&](int K) {
+            if (K < 0) return;
+            const bool has_nxt = K >= 1 && lpb[K] > lpb[K - 1] && lpan[lpb[K - 1]] == K;
+            const char* base = reinterpret_cast<const char*>(S + (size_t)K * 32 * n + (size_t)K * 32) - 256;   // wave-uniform
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+                const bool want = ridx[u] >= 0 && (has_nxt || ridx[u] % 65 < 32);   // (ridx % 65 = 32 tile + c)
+                rst[u] = want ? *reinterpret_cast<const double*>(base + roff[u]) : 0.0;
+            }
+            if (dw == TRSV_P_DW - 1) rdg = *reinterpret_cast<const double*>(base + doff);
+        };
+        auto stage_R = [&](int K) {
+            if (K < 0) return;
+            double* Rk = R + (K & 1) * (32 * 65);
+#pragma unroll
+            for (int u = 0; u < 5; u++)
+                if (ridx[u] >= 0) Rk[ridx[u]] = rkeep[u] ? rst[u] : 0.0;
+            if (dw == TRSV_P_DW - 1 && lane < 32) xs[K * 32 + lane] = xs[K * 32 + lane] / rdg;   // D^-1 z
+        };
+        // prologue: the block of the last column; nothing to multiply yet
+        prefetch_R(nb - 1);
+        stage_R(nb - 1);
+        prefetch_dots(nb - 2);
+        prefetch_R(nb - 2);
         lds_barrier();
+        for (int K = nb - 1; K >= 0; K--) {
+            const int col = K - 1;                   // the column whose products are formed in this phase
+            if (col >= 0) {
+                int i0, m;
+                dot_range(col, i0, m);
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < TRSV_P_PF; q++)  // tile i of the column goes to wave 1 + i % 7
+                    if (nI[q] >= 0) tile_dot(nI[q], nlv[q], s0, s1);
+                for (int i = dw + TRSV_P_DW * TRSV_P_PF; i < m; i += TRSV_P_DW) {
+                    const int I = lpan[i0 + i];
+                    double2 lv[8];
+                    tile_load(I, (size_t)col * 32, lv);
+                    tile_dot(I, lv, s0, s1);
+                }
+                s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
+                s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+                if (rg == 0) *reinterpret_cast<double2*>(part + (col & 1) * (TRSV_P_DW * 32) + dw * 32 + 2 * cp) = make_double2(s0, s1);
+                stage_R(col);
+                prefetch_dots(col - 1);
+                prefetch_R(col - 1);
+            }
+            lds_barrier();
+        }
     }
-    for (int q = t; q < n; q += 256) vec[q] = xs[q];
+    __syncthreads();
+    for (int q = t; q < n; q += 512) vec[q] = xs[q];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -185,7 +185,9 @@ struct Handle {
     bool is_lane = false;
     Batch B;
     std::vector<WinDesc> desc;
-    std::vector<WinCtrl> hctrl;
+    PinVec<WinCtrl> hctrl;    // the control blocks after a run (pinned: the copy rides on the run's stream)
+    std::vector<int> one_sb;      // n_win == 1: the window's step table (first pair of every factorisation step), for StepOne
+    bool dl_prefetched = false;   // few windows: the run left the result arrays in the download staging already
     int n_win = 0;
     bool any_lin_fallback = false;  // an XYZ window of the batch has a landmark with > 256 observations: k_lin_xyz also runs
     int cur_group = 0; // window group being enqueued (its pinned words)
@@ -573,6 +575,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
             }
             h->tile_updates += (double)st.tpairs.size();
             h->win_tiles[w] = (int)st.tpairs.size();
+            if (n == 1) h->one_sb = st.step_begin;
             h->win_prod_order[2 * (size_t)w] = st.prod_order[0]; h->win_prod_order[2 * (size_t)w + 1] = st.prod_order[1];
             if ((int)st.pair_a.size() != d.n_pairs || (int)st.off_pair.size() != d.n_pairs || (int)st.pair_mask.size() != d.n_pairs ||
                 (int)st.pimu_begin.size() != d.n_pairs + 1 || st.lmask.size() != (size_t)d.n_pt * st.mwords)
@@ -667,6 +670,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         return fail(h, "internal: the upload staging moved under an incremental copy");
     h->algo = probs[0]->algo;
     h->variant = probs[0]->variant;
+    if (!pcg) {   // the back-substitution keeps x, its solve blocks and the window's tile lists in LDS (160 KiB per workgroup)
+        const size_t shm = ((size_t)h->max_nS + 2 * TRSV_P_DW * 32 + 2 * 32 * 65 + 32) * sizeof(double) + ((size_t)h->max_pan + h->max_nb + 2) * sizeof(int);
+        if (shm > 160 * 1024) return fail(h, "window too large for the direct solver (back-substitution workspace > 160 KiB of LDS): use VBA_SOLVER_PCG");
+    }
     const double t_pack = now_ms();
     // pads of S: identity on the padded diagonal, written once (the solve never touches them)
     if (h2d_vec(h, BUF_DESC, h->desc, G.s_desc)) return -1;
@@ -807,6 +814,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
                         now_ms() - t_begin, t_struct, t_pack - t_begin - t_struct, t_enq - t_pack, now_ms() - t_enq);
     h->uploaded = true;
     h->ran = false;
+    h->dl_prefetched = false;
     return 0;
 }
 
@@ -898,7 +906,13 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
             const int step_form = h->opt_chol_step > 0 ? h->opt_chol_step : (env_form > 0 ? env_form : 4);
             for (int k = 0; k < h->max_nb; k++) {
                 if (step_form == 1) hipLaunchKernelGGL(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
-                else hipLaunchKernelGGL(k_chol_step4, dim3(h->step_grid[k], n), dim3(128), 0, h->stream, B, k);
+                else if (h->n_win == 1 && n == 1 && (int)h->one_sb.size() > k + 1) {   // one window: descriptor and step table ride in the kernel arguments
+                    const WinDesc& d0 = h->desc[0];
+                    StepOne so;
+                    so.algo = d0.algo; so.nS = d0.nS; so.nb = d0.nb; so.vec0 = d0.vec0; so.S0 = d0.S0;
+                    so.pair_off = d0.tl_pair0 + h->one_sb[k]; so.npair = h->one_sb[k + 1] - h->one_sb[k];
+                    hipLaunchKernelGGL(k_chol_step4<true>, dim3(h->step_grid[k], 1), dim3(128), 0, h->stream, B, k, so);
+                } else hipLaunchKernelGGL(k_chol_step4<false>, dim3(h->step_grid[k], n), dim3(128), 0, h->stream, B, k, StepOne());
             }
         }
     }
@@ -908,9 +922,9 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
         if (h->ll_mode || trsv_old) {
             const size_t shm = ((size_t)h->max_nS + 256 + 32 * 33) * sizeof(double);
             hipLaunchKernelGGL(k_trsv, dim3(n), dim3(256), shm, h->stream, B);
-        } else {   // row-major factor: the next column's tiles prefetched, tile lists in LDS
-            const size_t shm = ((size_t)h->max_nS + 512 + 32 * 33) * sizeof(double) + ((size_t)h->max_pan + h->max_nb + 2) * sizeof(int);
-            hipLaunchKernelGGL(k_trsv_w, dim3(n), dim3(256), shm, h->stream, B);
+        } else {   // row-major factor: a solving wave + seven waves that work one column ahead
+            const size_t shm = ((size_t)h->max_nS + 2 * TRSV_P_DW * 32 + 2 * 32 * 65 + 32) * sizeof(double) + ((size_t)h->max_pan + h->max_nb + 2) * sizeof(int);
+            hipLaunchKernelGGL(k_trsv_p, dim3(n), dim3(512), shm, h->stream, B);
         }
     }
     }
@@ -1227,18 +1241,43 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     if (rc) return fail(h, h->err.empty() ? "enqueue failed" : h->err);
     if (h->profile) (void)hipEventRecord(ev_end, h->stream);
     HIPCHK(h, hipGetLastError());
-    // wait, forwarding the caller's stop flag (g2o forceStopFlag) into the device-visible word
-    for (int g = 0; g < ngroups; g++) {
-        if (stop_flag) {
-            while (hipEventQuery(done[g]) == hipErrorNotReady) {
-                if (*stop_flag) *h->stop_host = 1;
-                std::this_thread::yield();
-            }
-        }
-        HIPCHK(h, hipEventSynchronize(done[g]));
-    }
+    // behind the last kernel, on the main stream: the control blocks and -- for a few windows, where every synchronous copy of the
+    // download is a 20-us round trip on a 3-ms solve -- the result arrays, into pinned staging (do_download only scatters them)
+    for (int g = 1; g < ngroups; g++) HIPCHK(h, hipStreamWaitEvent(h->stream, done[g], 0));
     h->hctrl.resize(n);
-    HIPCHK(h, hipMemcpy(h->hctrl.data(), B.ctrl, sizeof(WinCtrl) * n, hipMemcpyDeviceToHost));
+    if (!h->hctrl.ok) return fail(h, "out of pinned host memory (control blocks)");
+    HIPCHK(h, hipMemcpyAsync(h->hctrl.data(), B.ctrl, sizeof(WinCtrl) * n, hipMemcpyDeviceToHost, h->stream));
+    h->dl_prefetched = false;
+    if (n < 4) {
+        const WinDesc& dl = h->desc[n - 1];
+        const size_t nkf = (size_t)dl.kf0 + dl.n_kf, npt = (size_t)dl.pt0 + dl.n_pt, nobs = (size_t)dl.obs0 + dl.n_obs;
+        const bool vi = h->variant != VBA_VARIANT_SE3_XYZ;
+        Staging& G = h->stg;
+        G.dl_pose.resize(7 * nkf); G.dl_pt.resize(3 * npt); G.dl_outl.resize(nobs); G.dl_chi2.resize(nobs);
+        if (vi) { G.dl_vel.resize(3 * nkf); G.dl_bias.resize(12 * nkf); }
+        if (!G.ok()) return fail(h, "out of pinned host memory (download staging)");
+        HIPCHK(h, hipMemcpyAsync(G.dl_pose.data(), B.pose, 56 * nkf, hipMemcpyDeviceToHost, h->stream));
+        if (npt) HIPCHK(h, hipMemcpyAsync(G.dl_pt.data(), B.pt, 24 * npt, hipMemcpyDeviceToHost, h->stream));
+        if (vi) {
+            HIPCHK(h, hipMemcpyAsync(G.dl_vel.data(), B.vel, 24 * nkf, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(G.dl_bias.data(), B.bias, 96 * nkf, hipMemcpyDeviceToHost, h->stream));
+        }
+        if (nobs) {
+            HIPCHK(h, hipMemcpyAsync(G.dl_outl.data(), B.out_outlier, nobs, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(G.dl_chi2.data(), B.out_chi2, 8 * nobs, hipMemcpyDeviceToHost, h->stream));
+        }
+        h->dl_prefetched = true;
+    }
+    hipEvent_t ev_all = get_evt(h);
+    HIPCHK(h, hipEventRecord(ev_all, h->stream));
+    // wait, forwarding the caller's stop flag (g2o forceStopFlag) into the device-visible word
+    if (stop_flag) {
+        while (hipEventQuery(ev_all) == hipErrorNotReady) {
+            if (*stop_flag) *h->stop_host = 1;
+            std::this_thread::yield();
+        }
+    }
+    HIPCHK(h, hipEventSynchronize(ev_all));
     if (h->profile) {
         vba_profile& pf = h->prof;
         memset(&pf, 0, sizeof pf);
@@ -1282,9 +1321,9 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
     HIPCHK(h, hipSetDevice(h->device));
     const Batch& B = h->B;
     // Many windows: every result array crosses PCIe ONCE into host staging and host threads scatter it to the callers'
-    // arrays (per-window copies cost ~12 synchronous hipMemcpy calls per window, 0.25 ms).  Few windows: direct copies.
-    const bool staged = n >= 4;
-    if (staged) {
+    // arrays (per-window copies cost ~12 synchronous hipMemcpy calls per window, 0.25 ms).  Few windows: the run has left them in the staging already (do_run).
+    const bool staged = n >= 4 || h->dl_prefetched;
+    if (staged && !h->dl_prefetched) {
         bool want_state = false, want_outl = false, want_chi2 = false;
         for (int w = 0; w < n; w++) {
             if (inout && inout[w] && h->hctrl[w].status != VBA_ABORTED_BEFORE) want_state = true;
@@ -1409,7 +1448,7 @@ static int make_handle(int device, Handle* parent, Handle** out) {
                               (int)LIN2_LDS);
     // the back-substitution keeps x (nS doubles) in LDS: maps of more than ~5 600 pose dofs need more than the default 64 KiB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_w), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_p), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     memset(&h->prof, 0, sizeof h->prof);
     *out = h;
     return 0;
@@ -1434,6 +1473,7 @@ int vba_destroy(void* handle) {
     (void)hipStreamSynchronize(h->up_stream);
     (void)hipStreamSynchronize(h->dl_stream);
     h->stg.release();
+    h->hctrl.release();
     h->up_arena.release();
     h->up_arena_host.release();
     for (auto& b : h->buf) b.release();
