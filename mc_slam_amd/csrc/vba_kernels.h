@@ -792,12 +792,18 @@ DEVI double window_chi2(const Batch& B, const WinDesc& d, double* sm) {
     return block_sum<64>(s, sm);
 }
 
-__global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval) {
+// host_slot >= 0 (a single window, no profile): the launch reports through the pinned word alive_cnt[host_slot] itself -- 1: done, the
+// window has stopped; 2: done, it goes on -- and the host reads that word instead of waiting for an event behind this kernel (an
+// event record between two kernels of a stream costs the next one ~4 us).
+__global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval, int host_slot) {
     __shared__ double sm[64];
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
-    if (!c.active) return;
+    if (!c.active) {
+        if (host_slot >= 0 && threadIdx.x == 0) __hip_atomic_store(B.alive_cnt + host_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     const double cur = window_chi2(B, d, sm);
     if (threadIdx.x != 0) return;
     const int st = c.stage, it = c.it;
@@ -822,6 +828,10 @@ __global__ void __launch_bounds__(64) k_ctrl_gn(Batch B, int final_eval) {
     c.active = active;
     c.chol_fail = 0;
     c.it = it + 1;
+    if (host_slot >= 0) {
+        __hip_atomic_store(B.alive_cnt + host_slot, active ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (active && B.alive_cnt && it < 32 && atomicExch(B.alive_dev + st * 32 + it, 1) == 0)  // lets the host skip dead iterations
         __hip_atomic_store(B.alive_cnt + st * 32 + it, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // a posted store, not a PCIe atomic
 }

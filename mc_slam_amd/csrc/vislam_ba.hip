@@ -187,6 +187,8 @@ struct Handle {
     std::vector<WinDesc> desc;
     PinVec<WinCtrl> hctrl;    // the control blocks after a run (pinned: the copy rides on the run's stream)
     std::vector<int> one_sb;      // n_win == 1: the window's step table (first pair of every factorisation step), for StepOne
+    hipEvent_t up_done = nullptr; // recorded behind an upload that was not waited for on the host (vba_solve)
+    bool up_pending = false;
     bool dl_prefetched = false;   // few windows: the run left the result arrays in the download staging already
     int n_win = 0;
     bool any_lin_fallback = false;  // an XYZ window of the batch has a landmark with > 256 observations: k_lin_xyz also runs
@@ -372,7 +374,7 @@ bool use_left_looking(const Handle* h, int n) {
     return left_looking && n >= (h->opt_ll_min > 0 ? h->opt_ll_min : ll_min);
 }
 
-int do_upload(Handle* h, int n, vba_problem* const* probs) {
+int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = false) {
     static const bool timing = getenv("VBA_TIMING") != nullptr;
     const double t_begin = now_ms();
     double t_struct = 0;
@@ -809,7 +811,14 @@ int do_upload(Handle* h, int n, vba_problem* const* probs) {
         HIPCHK(h, hipGetLastError());
     }
     const double t_enq = now_ms();
-    HIPCHK(h, hipStreamSynchronize(h->up_stream));
+    // vba_solve (one call: upload, run, download) does not come back to the host here: the run stream waits for the upload stream
+    // on the device (an event), and the run's kernels queue up behind the structure build instead of behind a host round trip
+    h->up_pending = false;
+    if (defer_sync && h->up_done) {
+        HIPCHK(h, hipEventRecord(h->up_done, h->up_stream));
+        h->up_pending = true;
+    } else
+        HIPCHK(h, hipStreamSynchronize(h->up_stream));
     if (timing) fprintf(stderr, "[vba] %p t=%.1f upload %d windows: total %.3f ms (structure %.3f, pack %.3f, alloc+H2D enqueue %.3f, sync %.3f)\n", (void*)h, now_ms(), n,
                         now_ms() - t_begin, t_struct, t_pack - t_begin - t_struct, t_enq - t_pack, now_ms() - t_enq);
     h->uploaded = true;
@@ -1111,6 +1120,7 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
             // never starves: one full iteration is always queued behind the one being waited for.
             const int nit = h->max_its[stage];
             std::vector<std::vector<hipEvent_t>> ev(groups.size(), std::vector<hipEvent_t>(nit, nullptr));
+            const bool word_report = h->n_win == 1 && groups.size() == 1 && !h->profile && nit <= 32;   // see k_ctrl_gn
             const bool pace = nit <= 32;  // also when profiling: the launch counts (and hence the per-launch averages) then equal those of a normal run
             // how far ahead: two iterations for batches (the device must never wait for the host); ONE for a handful of windows,
             // where an iteration is a chain of ~30 short launches that the host enqueues three times faster than the device runs
@@ -1124,8 +1134,19 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
                     Group& g = groups[gi];
                     if (g.dead) continue;
                     if (pace && it >= depth) {
-                        (void)wait_event_forwarding(h, ev[gi][it - depth], stop_flag);
-                        if (g.alive[stage * 32 + it - depth] == 0) { g.dead = true; continue; }
+                        const int slot = stage * 32 + it - depth;
+                        if (word_report) {   // the control kernel writes 1 (stopped) / 2 (goes on) into the pinned word when it is done
+                            long spins = 0;
+                            while (g.alive[slot] == 0) {
+                                forward_stop(h, stop_flag);
+                                if ((++spins & 1023) == 0 && hipStreamQuery(g.stream) != hipErrorNotReady) break;   // drained or failed: nothing will write it
+                                std::this_thread::yield();
+                            }
+                            if (g.alive[slot] != 2) { g.dead = true; continue; }
+                        } else {
+                            (void)wait_event_forwarding(h, ev[gi][it - depth], stop_flag);
+                            if (g.alive[slot] == 0) { g.dead = true; continue; }
+                        }
                     }
                     any = true;
                     use(g);
@@ -1134,9 +1155,9 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
                     {
                         ProfScope ps(h, VBA_PROF_CONTROL);
                         if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
-                        hipLaunchKernelGGL(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 0);
+                        hipLaunchKernelGGL(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 0, word_report ? stage * 32 + it : -1);
                     }
-                    if (pace) {
+                    if (pace && !word_report) {
                         ev[gi][it] = get_evt(h);
                         (void)hipEventRecord(ev[gi][it], g.stream);
                     }
@@ -1148,7 +1169,7 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
                 use(g);
                 enqueue_lin(h, LIN_ERR);
                 ProfScope ps(h, VBA_PROF_CONTROL);
-                hipLaunchKernelGGL(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 1);
+                hipLaunchKernelGGL(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 1, -1);
             }
         }
         if (h->variant != VBA_VARIANT_PRV_IDP)
@@ -1225,6 +1246,10 @@ int do_run(Handle* h, const volatile int* stop_flag) {
         groups[g].stream = (g == 0) ? h->stream : h->xstreams[g - 1];
         groups[g].alive = h->stop_host + 64 + 64 * g;
         groups[g].dead = false;
+    }
+    if (h->up_pending) {   // (vba_solve: the upload was not waited for on the host)
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->up_done, 0));
+        h->up_pending = false;
     }
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_ALIVE].p, 0, 14 * 1024 * sizeof(int), h->stream));   // the mirror words of this run
     // the other streams start after everything already queued on the main stream (upload, previous run)
@@ -1449,6 +1474,7 @@ static int make_handle(int device, Handle* parent, Handle** out) {
     // the back-substitution keeps x (nS doubles) in LDS: maps of more than ~5 600 pose dofs need more than the default 64 KiB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_p), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipEventCreateWithFlags(&h->up_done, hipEventDisableTiming);
     memset(&h->prof, 0, sizeof h->prof);
     *out = h;
     return 0;
@@ -1482,6 +1508,7 @@ int vba_destroy(void* handle) {
     h->pose_host_in.release();
     h->pose_host_out.release();
     for (auto e : h->evt_pool) (void)hipEventDestroy(e);
+    if (h->up_done) (void)hipEventDestroy(h->up_done);
     if (h->owns_streams)
         for (auto st : h->xstreams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (h->stop_host) (void)hipHostFree((void*)h->stop_host);
@@ -1523,7 +1550,7 @@ int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile 
     }
     vba_problem* ps[1] = {inout};
     vba_result* rs[1] = {out};
-    if (do_upload(h, 1, ps)) return -1;
+    if (do_upload(h, 1, ps, true)) return -1;
     if (do_run(h, stop_flag)) return -1;
     return do_download(h, 1, ps, rs);
 }
