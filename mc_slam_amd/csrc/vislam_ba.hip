@@ -152,7 +152,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_SLOTO, BUF_SLOTREF, BUF_SLOTQ, BUF_RECQ, BUF_TSQ, BUF_RECCNT, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_SLOTO, BUF_SLOTREF, BUF_SLOTQ, BUF_RECQ, BUF_TSQ, BUF_RECCNT, BUF_RESULTS, BUF_N
 };
 
 struct ProfEvt {
@@ -187,6 +187,8 @@ struct Handle {
     std::vector<WinDesc> desc;
     PinVec<WinCtrl> hctrl;    // the control blocks after a run (pinned: the copy rides on the run's stream)
     std::vector<int> one_sb;      // n_win == 1: the window's step table (first pair of every factorisation step), for StepOne
+    PinnedBuf res_host;           // few windows: control blocks + every result array in ONE block (device: BUF_RESULTS), one D2H copy
+    size_t res_bytes = 0, res_off[7] = {0, 0, 0, 0, 0, 0, 0};   // ctrl, pose, vel, bias, pt, outlier flags, chi2
     hipEvent_t up_done = nullptr; // recorded behind an upload that was not waited for on the host (vba_solve)
     bool up_pending = false;
     bool dl_prefetched = false;   // few windows: the run left the result arrays in the download staging already
@@ -725,6 +727,20 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d_vec(h, BUF_LINBLK, linblk, G.s_int[6])) return -1;
     if (h2d(h, BUF_OFFPAIR, offpair) || h2d(h, BUF_PAIRMASK, pairmask)) return -1;
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
+    h->res_bytes = 0;
+    if (n < 4) {   // few windows: everything the download reads lives in ONE block -- one D2H copy behind the run (do_run)
+        const size_t sz[7] = {sizeof(WinCtrl) * (size_t)n, pose.size() * 8, vel.size() * 8, bias.size() * 8, pt.size() * 8, (size_t)obs0, (size_t)obs0 * 8};
+        const int ids[7] = {BUF_CTRL, BUF_POSE, BUF_VEL, BUF_BIAS, BUF_PT, BUF_OUTL, BUF_OUTCHI};
+        size_t off = 0;
+        for (int i = 0; i < 7; i++) { h->res_off[i] = off; off += (std::max<size_t>(sz[i], 16) + 255) / 256 * 256; }
+        if (dalloc(h, BUF_RESULTS, off)) return -1;
+        HIPCHK(h, h->res_host.ensure(off));
+        for (int i = 0; i < 7; i++) {
+            h->buf[ids[i]].view = reinterpret_cast<char*>(h->buf[BUF_RESULTS].p) + h->res_off[i];
+            h->buf[ids[i]].view_bytes = std::max<size_t>(sz[i], 16);
+        }
+        h->res_bytes = off;
+    }
     // S: zero everything once, identity on the pads
     // (PCG reads whole keyframe-pair blocks, also the sub-blocks no factor tile covers and no Schur kernel writes: zero them once)
     if (use_left_looking(h, n) || pcg) HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->up_stream));
@@ -1271,28 +1287,12 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     for (int g = 1; g < ngroups; g++) HIPCHK(h, hipStreamWaitEvent(h->stream, done[g], 0));
     h->hctrl.resize(n);
     if (!h->hctrl.ok) return fail(h, "out of pinned host memory (control blocks)");
-    HIPCHK(h, hipMemcpyAsync(h->hctrl.data(), B.ctrl, sizeof(WinCtrl) * n, hipMemcpyDeviceToHost, h->stream));
     h->dl_prefetched = false;
-    if (n < 4) {
-        const WinDesc& dl = h->desc[n - 1];
-        const size_t nkf = (size_t)dl.kf0 + dl.n_kf, npt = (size_t)dl.pt0 + dl.n_pt, nobs = (size_t)dl.obs0 + dl.n_obs;
-        const bool vi = h->variant != VBA_VARIANT_SE3_XYZ;
-        Staging& G = h->stg;
-        G.dl_pose.resize(7 * nkf); G.dl_pt.resize(3 * npt); G.dl_outl.resize(nobs); G.dl_chi2.resize(nobs);
-        if (vi) { G.dl_vel.resize(3 * nkf); G.dl_bias.resize(12 * nkf); }
-        if (!G.ok()) return fail(h, "out of pinned host memory (download staging)");
-        HIPCHK(h, hipMemcpyAsync(G.dl_pose.data(), B.pose, 56 * nkf, hipMemcpyDeviceToHost, h->stream));
-        if (npt) HIPCHK(h, hipMemcpyAsync(G.dl_pt.data(), B.pt, 24 * npt, hipMemcpyDeviceToHost, h->stream));
-        if (vi) {
-            HIPCHK(h, hipMemcpyAsync(G.dl_vel.data(), B.vel, 24 * nkf, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(G.dl_bias.data(), B.bias, 96 * nkf, hipMemcpyDeviceToHost, h->stream));
-        }
-        if (nobs) {
-            HIPCHK(h, hipMemcpyAsync(G.dl_outl.data(), B.out_outlier, nobs, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(G.dl_chi2.data(), B.out_chi2, 8 * nobs, hipMemcpyDeviceToHost, h->stream));
-        }
+    if (h->res_bytes) {   // few windows: ONE copy brings the control blocks and every result array (do_upload laid them out in one block)
+        HIPCHK(h, hipMemcpyAsync(h->res_host.p, h->buf[BUF_RESULTS].p, h->res_bytes, hipMemcpyDeviceToHost, h->stream));
         h->dl_prefetched = true;
-    }
+    } else
+        HIPCHK(h, hipMemcpyAsync(h->hctrl.data(), B.ctrl, sizeof(WinCtrl) * n, hipMemcpyDeviceToHost, h->stream));
     hipEvent_t ev_all = get_evt(h);
     HIPCHK(h, hipEventRecord(ev_all, h->stream));
     // wait, forwarding the caller's stop flag (g2o forceStopFlag) into the device-visible word
@@ -1303,6 +1303,7 @@ int do_run(Handle* h, const volatile int* stop_flag) {
         }
     }
     HIPCHK(h, hipEventSynchronize(ev_all));
+    if (h->dl_prefetched) memcpy(h->hctrl.data(), h->res_host.p, sizeof(WinCtrl) * n);
     if (h->profile) {
         vba_profile& pf = h->prof;
         memset(&pf, 0, sizeof pf);
@@ -1376,6 +1377,15 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
         if (want_chi2) HIPCHK(h, hipMemcpyAsync(G.dl_chi2.data(), B.out_chi2, 8 * nobs, hipMemcpyDeviceToHost, h->dl_stream));
         HIPCHK(h, hipStreamSynchronize(h->dl_stream));
     }
+    // where the staged arrays are: the per-array staging of a big batch, or the one block a small one came back in
+    const char* rb = reinterpret_cast<const char*>(h->res_host.p);
+    const bool one = h->dl_prefetched;
+    const double* s_pose = one ? reinterpret_cast<const double*>(rb + h->res_off[1]) : h->stg.dl_pose.data();
+    const double* s_vel = one ? reinterpret_cast<const double*>(rb + h->res_off[2]) : h->stg.dl_vel.data();
+    const double* s_bias = one ? reinterpret_cast<const double*>(rb + h->res_off[3]) : h->stg.dl_bias.data();
+    const double* s_pt = one ? reinterpret_cast<const double*>(rb + h->res_off[4]) : h->stg.dl_pt.data();
+    const unsigned char* s_outl = one ? reinterpret_cast<const unsigned char*>(rb + h->res_off[5]) : h->stg.dl_outl.data();
+    const double* s_chi2 = one ? reinterpret_cast<const double*>(rb + h->res_off[6]) : h->stg.dl_chi2.data();
     std::atomic<int> next(0), bad(0);
     auto work = [&]() {
         for (int w = next.fetch_add(1); w < n; w = next.fetch_add(1)) {
@@ -1389,12 +1399,12 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
                 else if (hipMemcpy(dst, dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) bad.store(1);
             };
             if (P && c.status != VBA_ABORTED_BEFORE) {
-                get(P->kf_pose, B.pose + 7 * (size_t)d.kf0, h->stg.dl_pose.data() + 7 * (size_t)d.kf0, 56 * (size_t)d.n_free);
+                get(P->kf_pose, B.pose + 7 * (size_t)d.kf0, s_pose + 7 * (size_t)d.kf0, 56 * (size_t)d.n_free);
                 if (d.pdim == 15) {
-                    if (P->kf_vel) get(P->kf_vel, B.vel + 3 * (size_t)d.kf0, h->stg.dl_vel.data() + 3 * (size_t)d.kf0, 24 * (size_t)d.n_free);
-                    if (P->kf_bias) get(P->kf_bias, B.bias + 12 * (size_t)d.kf0, h->stg.dl_bias.data() + 12 * (size_t)d.kf0, 96 * (size_t)d.n_free);
+                    if (P->kf_vel) get(P->kf_vel, B.vel + 3 * (size_t)d.kf0, s_vel + 3 * (size_t)d.kf0, 24 * (size_t)d.n_free);
+                    if (P->kf_bias) get(P->kf_bias, B.bias + 12 * (size_t)d.kf0, s_bias + 12 * (size_t)d.kf0, 96 * (size_t)d.n_free);
                 }
-                get(P->pt, B.pt + 3 * (size_t)d.pt0, h->stg.dl_pt.data() + 3 * (size_t)d.pt0, 24 * (size_t)d.n_pt);
+                get(P->pt, B.pt + 3 * (size_t)d.pt0, s_pt + 3 * (size_t)d.pt0, 24 * (size_t)d.n_pt);
             }
             if (R) {
                 R->chi2_vis = c.chi2_vis; R->chi2_prv = c.chi2_prv; R->chi2_bias = c.chi2_bias;
@@ -1405,8 +1415,8 @@ int do_download(Handle* h, int n, vba_problem* const* inout, vba_result* const* 
                 R->lambda_final = c.lambda;
                 R->lin_iterations = c.lin_its;
                 if (c.status != VBA_ABORTED_BEFORE && d.n_obs) {
-                    if (R->obs_outlier) get(R->obs_outlier, B.out_outlier + d.obs0, h->stg.dl_outl.data() + d.obs0, (size_t)d.n_obs);
-                    if (R->obs_chi2) get(R->obs_chi2, B.out_chi2 + d.obs0, h->stg.dl_chi2.data() + d.obs0, 8 * (size_t)d.n_obs);
+                    if (R->obs_outlier) get(R->obs_outlier, B.out_outlier + d.obs0, s_outl + d.obs0, (size_t)d.n_obs);
+                    if (R->obs_chi2) get(R->obs_chi2, B.out_chi2 + d.obs0, s_chi2 + d.obs0, 8 * (size_t)d.n_obs);
                 }
             }
         }
@@ -1500,6 +1510,7 @@ int vba_destroy(void* handle) {
     (void)hipStreamSynchronize(h->dl_stream);
     h->stg.release();
     h->hctrl.release();
+    h->res_host.release();
     h->up_arena.release();
     h->up_arena_host.release();
     for (auto& b : h->buf) b.release();
@@ -1761,7 +1772,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE", "SLOTO", "SLOTREF", "SLOTQ", "RECQ", "TSQ", "RECCNT"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE", "SLOTO", "SLOTREF", "SLOTQ", "RECQ", "TSQ", "RECCNT", "RESULTS"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
