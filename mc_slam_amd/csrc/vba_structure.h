@@ -228,10 +228,15 @@ __global__ void __launch_bounds__(256) k_st_rec_scan(Batch B, StBuild T, int max
     int* cnt = T.rec_cnt + 2 * (size_t)d.kf0 * max_chunks;
     for (int k2 = threadIdx.x; k2 < 2 * nk; k2 += 256) {   // (keyframe, obs / ref) columns: exclusive prefix over the chunks
         int run = 0;
-        for (int c = 0; c < nch; c++) {
-            const int v = cnt[(size_t)c * 2 * nk + k2];
-            cnt[(size_t)c * 2 * nk + k2] = run;
-            run += v;
+        // eight chunks per trip, their counts requested together: the column is one dependent chain of ~80 loads otherwise (the
+        // stores in between keep the compiler from hoisting them; 19 us per launch for a single C3 window)
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+            int v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (c0 + i < nch) ? cnt[(size_t)(c0 + i) * 2 * nk + k2] : 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c0 + i < nch) { cnt[(size_t)(c0 + i) * 2 * nk + k2] = run; run += v[i]; }
         }
     }
 }
@@ -385,13 +390,98 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
         }
     }
 }
+// The same walk for windows of at most 64 keyframes (one mask word): the running counts of the pairs (a, b) live in LANE b of two
+// registers instead of LDS -- the count of the partner in hand is a v_readlane, its update a conditional add in lane b -- so the
+// inner loop has no barrier and no LDS round trip (a single C3 window: k_st_count 35 -> ?, k_st_fill 75 -> ? us).
+// Same ballots, same ranks: the item lists are identical to those of st_row_body.
+template <bool FILL>
+DEVI void st_row_body1(const Batch& B, const StBuild& T) {
+    const int w = blockIdx.y, a = blockIdx.x;
+    const WinDesc& d = B.desc[w];
+    const int nf = d.n_free;
+    if (a >= nf) return;
+    const int lane = threadIdx.x;
+    const bool idp = d.variant == 2;
+    const int rowbase = a * nf - a * (a - 1) / 2 - a;   // pair index of (a, b) = rowbase + b
+    int* ib = T.item_begin + d.pair0 + d.win;
+    int* im = T.item_mid + d.pair0 + d.win;
+    const bool mine = lane > a && lane < nf;             // lane b keeps the counts of pair (a, b)
+    int r0 = (FILL && mine) ? ib[rowbase + lane] : 0;
+    int r1 = (FILL && mine) ? im[rowbase + lane] : 0;
+    const int* kseg = T.kf_seg + d.kf0 + d.win;
+    const int* rseg = T.ref_seg + d.kf0 + d.win;
+    const int* ob = B.pt_obs_begin + d.pt0 + d.win;
+    const u64_t* LM = B.lmask + d.mask0;
+    const u64_t lt = lanes_below();
+    int2* items = reinterpret_cast<int2*>(T.items) + d.item0;
+    u64_t rg = ~0ull;                                    // bits that name a keyframe b with a < b < nf
+    rg &= (a + 1 >= 64) ? 0ull : (~0ull << (a + 1));
+    if (nf < 64) rg &= ~0ull >> (64 - nf);
+    // 1. observation records of a
+    for (int c = kseg[a]; c < kseg[a + 1]; c += 64) {
+        const int slot = c + lane;
+        const bool valid = slot < kseg[a + 1];
+        const int p = (FILL && valid) ? T.slot_obs[d.obs0 + slot] : 0;
+        const int r = (valid && idp) ? T.slot_ref[d.obs0 + slot] : -1;
+        int4 sr_lo = make_int4(0, 0, 0, 0), sr_hi = make_int4(0, 0, 0, 0);
+        if (FILL) slot_row_load(T, d, valid ? T.slot_q[d.obs0 + slot] : 0, valid, sr_lo, sr_hi);
+        const u64_t lmw0 = valid ? T.slot_mask[(size_t)(d.obs0 + slot) * T.smw] : 0ull;
+        const u64_t Mr = lmw0 & rg;
+        const u64_t rb = (r > a && r < nf) ? (1ull << r) : 0ull;
+        u64_t U = wave_or64(Mr | rb);
+        U = ((u64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(U >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)U);   // (uniform: scalar loop)
+        while (U) {
+            const int b = __builtin_ctzll(U);
+            U &= U - 1;
+            const bool h0 = (Mr >> b) & 1ull, h1 = (rb >> b) & 1ull;
+            const u64_t m0 = __ballot(h0), m1 = __ballot(h1);
+            if (FILL) {
+                const int base0 = __builtin_amdgcn_readlane(r0, b), base1 = __builtin_amdgcn_readlane(r1, b);
+                if (h0) items[base0 + __popcll(m0 & lt)] = make_int2(slot, slot_row_at(sr_lo, sr_hi, T, d, LM, ob, p, b, lmw0));
+                if (h1) items[base1 + __popcll(m1 & lt)] = make_int2(slot, d.n_obs + T.pt_perm[d.pt0 + p]);
+            }
+            if (lane == b) { r0 += __popcll(m0); r1 += __popcll(m1); }
+        }
+    }
+    // 2. landmark records a is the reference keyframe of: reference items only
+    if (idp)
+        for (int c = rseg[a]; c < rseg[a + 1]; c += 64) {
+            const int rec = c + lane;
+            const bool valid = rec < rseg[a + 1];
+            const int p = (FILL && valid) ? T.pt_inv[d.pt0 + rec] : 0;
+            const int q = valid ? T.rec_q[d.pt0 + rec] : 0;
+            int4 sr_lo = make_int4(0, 0, 0, 0), sr_hi = make_int4(0, 0, 0, 0);
+            if (FILL) slot_row_load(T, d, q, valid, sr_lo, sr_hi);
+            const u64_t lmw0 = valid ? T.mask_q[d.mask0 + (size_t)q] : 0ull;   // the landmark's mask, stored in lm_order (one word)
+            const u64_t Mr = lmw0 & rg;
+            u64_t U = wave_or64(Mr);
+            U = ((u64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(U >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)U);
+            while (U) {
+                const int b = __builtin_ctzll(U);
+                U &= U - 1;
+                const bool h1 = (Mr >> b) & 1ull;
+                const u64_t m1 = __ballot(h1);
+                if (FILL) {
+                    const int base1 = __builtin_amdgcn_readlane(r1, b);
+                    if (h1) items[base1 + __popcll(m1 & lt)] = make_int2(d.n_obs + rec, slot_row_at(sr_lo, sr_hi, T, d, LM, ob, p, b, lmw0));
+                }
+                if (lane == b) r1 += __popcll(m1);
+            }
+        }
+    if (!FILL) {
+        if (mine) { ib[rowbase + lane] = r0 + r1; im[rowbase + lane] = r0; }
+        else if (lane == a) { ib[rowbase + lane] = 0; im[rowbase + lane] = 0; }   // the diagonal pair has no list
+    }
+}
 __global__ void __launch_bounds__(64) k_st_count(Batch B, StBuild T, int max_free) {
     extern __shared__ int shc[];
-    st_row_body<false>(B, T, shc, shc + max_free);
+    if (B.desc[blockIdx.y].mwords == 1) st_row_body1<false>(B, T);
+    else st_row_body<false>(B, T, shc, shc + max_free);
 }
 __global__ void __launch_bounds__(64) k_st_fill(Batch B, StBuild T, int max_free) {
     extern __shared__ int shc[];
-    st_row_body<true>(B, T, shc, shc + max_free);
+    if (B.desc[blockIdx.y].mwords == 1) st_row_body1<true>(B, T);
+    else st_row_body<true>(B, T, shc, shc + max_free);
 }
 
 // per-pair counts -> offsets (exclusive scan over the pairs of a window); item_mid = first reference item of the pair
