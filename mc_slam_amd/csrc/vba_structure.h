@@ -101,7 +101,14 @@ __global__ void __launch_bounds__(1024) k_st_hist(Batch B, StBuild T) {
         for (int o = ob[p]; o < ob[p + 1]; o++) T.obs_pt[d.obs0 + o] = p;
         if (!idp) T.pt_perm[d.pt0 + p] = p;   // XYZ landmarks have no reference keyframe: point records stay in landmark order
     }
-    for (int o = t; o < d.n_obs; o += nt) atomicAdd(&ho[B.obs_kf[d.obs0 + o] + 1], 1);
+    for (int o0 = t; o0 < d.n_obs; o0 += 8 * nt) {   // eight loads in flight per thread (a loop of load -> LDS atomic runs one at a time)
+        int kf[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) kf[i] = (o0 + i * nt < d.n_obs) ? B.obs_kf[d.obs0 + o0 + i * nt] : -1;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (kf[i] >= 0) atomicAdd(&ho[kf[i] + 1], 1);
+    }
     __syncthreads();
     if (t < 3) {
         int* h = sh + t * (nk + 1);
@@ -392,7 +399,7 @@ DEVI void st_row_body(const Batch& B, const StBuild& T, int* c0, int* c1) {
 }
 // The same walk for windows of at most 64 keyframes (one mask word): the running counts of the pairs (a, b) live in LANE b of two
 // registers instead of LDS -- the count of the partner in hand is a v_readlane, its update a conditional add in lane b -- so the
-// inner loop has no barrier and no LDS round trip (a single C3 window: k_st_count 35 -> ?, k_st_fill 75 -> ? us).
+// inner loop has no barrier and no LDS round trip (a single C3 window: k_st_count 35 -> 24 us, k_st_fill 75 -> 58 us).
 // Same ballots, same ranks: the item lists are identical to those of st_row_body.
 template <bool FILL>
 DEVI void st_row_body1(const Batch& B, const StBuild& T) {
