@@ -31,6 +31,7 @@ struct StBuild {   // what the build writes (the solve reads the same arrays thr
                                                   // and per RANK the first eight slots of the landmark's row (neighbouring records of a
                                                   // keyframe are neighbouring ranks: their rows share cache lines)
     int smw;                                      // words per slot_mask entry (the largest mwords of the batch)
+    int row_lds;                                  // test hook (VBA_ST_ROW_LDS): the pair-row walks keep their counts in LDS also for windows of <= 64 keyframes
 };
 
 DEVI u64_t wave_or64(u64_t v) {
@@ -482,12 +483,12 @@ DEVI void st_row_body1(const Batch& B, const StBuild& T) {
 }
 __global__ void __launch_bounds__(64) k_st_count(Batch B, StBuild T, int max_free) {
     extern __shared__ int shc[];
-    if (B.desc[blockIdx.y].mwords == 1) st_row_body1<false>(B, T);
+    if (B.desc[blockIdx.y].mwords == 1 && !T.row_lds) st_row_body1<false>(B, T);
     else st_row_body<false>(B, T, shc, shc + max_free);
 }
 __global__ void __launch_bounds__(64) k_st_fill(Batch B, StBuild T, int max_free) {
     extern __shared__ int shc[];
-    if (B.desc[blockIdx.y].mwords == 1) st_row_body1<true>(B, T);
+    if (B.desc[blockIdx.y].mwords == 1 && !T.row_lds) st_row_body1<true>(B, T);
     else st_row_body<true>(B, T, shc, shc + max_free);
 }
 

@@ -807,6 +807,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
         T.key_seg = dp<int>(h, BUF_KEYSEG); T.tslot = dp<int>(h, BUF_TSLOT);
         T.mask_q = dp<unsigned long long>(h, BUF_MASKQ); T.slot_mask = dp<unsigned long long>(h, BUF_SLOTMASK); T.ref_q = dp<int>(h, BUF_REFQ);
         T.smw = (int)slotmask_words;
+        T.row_lds = getenv("VBA_ST_ROW_LDS") ? 1 : 0;   // (read per upload: the test flips it inside one process)
         T.slot_o = dp<int>(h, BUF_SLOTO);
         T.slot_ref = dp<int>(h, BUF_SLOTREF); T.slot_q = dp<int>(h, BUF_SLOTQ); T.rec_q = dp<int>(h, BUF_RECQ); T.tsq = dp<int>(h, BUF_TSQ);
         hipLaunchKernelGGL(k_st_hist, dim3(n), dim3(n <= 64 ? 1024 : 256), sh_order, h->up_stream, B, T);

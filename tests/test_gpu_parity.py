@@ -2,6 +2,7 @@
 seeded windows.  Bars (BASELINE.json north_star): final chi2 <= 1e-4 relative, keyframe translations
 <= 1e-6 m; on top: same iteration counts and the same outlier bitmap."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -546,3 +547,25 @@ def test_left_looking_kernels_at_full_window_size(ba, oracle):
         np.testing.assert_allclose(r.chi2_trace, r1.chi2_trace, rtol=1e-8)
         if i < 3:
             assert (qs[i].kf_pose == q.kf_pose).all() and rs[i].chi2_vis == r.chi2_vis   # batch == single solve, bit for bit
+
+
+def test_structure_row_walk_in_lanes_equals_the_lds_walk(ba):
+    """Windows of at most 64 keyframes build their per-pair item lists with the counts of a keyframe row held in lanes
+    (st_row_body1); VBA_ST_ROW_LDS keeps them in LDS as windows of more keyframes do (st_row_body).  Same ballots, same ranks: the
+    lists -- and with them every summation order of the solve -- must be identical, so the results are equal bit for bit."""
+    ps = [synth.config_c3_ragged(300 + s) for s in range(3)] + [synth.config_c3s(5),
+          synth.make_window(abi.VARIANT_SE3_XYZ, algo=abi.ALGO_LM, n_kf=14, n_fixed=2, n_pt=700, n_obs=4200, seed=77)]
+    fast = [ba.solve(p) for p in ps[:3]] + [ba.solve(p) for p in ps[3:]]
+    ba.upload(ps[:3]); ba.run(); qb, rb = ba.download()
+    qb = [q.copy() for q in qb]
+    os.environ["VBA_ST_ROW_LDS"] = "1"
+    try:
+        slow = [ba.solve(p) for p in ps]
+        ba.upload(ps[:3]); ba.run(); qc, rc = ba.download()
+    finally:
+        del os.environ["VBA_ST_ROW_LDS"]
+    for (q, r), (q1, r1) in zip(fast, slow):
+        assert r.its_done == r1.its_done and r.chi2_vis == r1.chi2_vis and r.n_outliers == r1.n_outliers
+        assert np.array_equal(q.kf_pose, q1.kf_pose) and np.array_equal(q.pt, q1.pt)
+    for q, q1, r, r1 in zip(qb, qc, rb, rc):
+        assert r.chi2_vis == r1.chi2_vis and np.array_equal(q.kf_pose, q1.kf_pose)
