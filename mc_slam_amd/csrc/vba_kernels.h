@@ -503,6 +503,46 @@ __global__ void __launch_bounds__(64) k_lin_imu_hess(Batch B) {
     lin_imu_hess(B, d, k, sm);
 }
 
+// The geometry of one inverse-depth edge (g2otypes.cpp:25-60), shared by the linearisation and by the two passes that classify
+// edges (k_classify, k_final_edges): those evaluate chi2 and depth again at the estimates instead of reading a per-edge copy the
+// linearisation used to leave behind on EVERY pass (16 of its 218 bytes per edge; the estimates do not move between a window's last
+// linearisation and its classification, and the expressions are these same ones, so the values are the same).
+DEVI void idp_point_world(const WinDesc& d, const double* C0, double rho, double xb, double yb, double& dd, double (&c0)[3], double (&b0)[3],
+                          double (&Xw)[3]) {   // C0: R|t of the reference keyframe
+    if (rho < 1e-6) rho = 1e-6;  // g2otypes.cpp:42-47
+    dd = 1.0 / rho;
+    const double P0[3] = {xb * dd, yb * dd, dd};
+    double tb[3];
+    mtv3(d.Rcb, P0, c0);
+    mtv3(d.Rcb, d.tcb, tb);
+    b0[0] = c0[0] - tb[0]; b0[1] = c0[1] - tb[1]; b0[2] = c0[2] - tb[2];
+    mv3(C0, b0, Xw);
+    Xw[0] += C0[9]; Xw[1] += C0[10]; Xw[2] += C0[11];
+}
+DEVI void idp_edge_pc(const WinDesc& d, const double* Xw, const double* Ri, const double* ti, double (&ta)[3], double (&Pc)[3]) {
+    const double v[3] = {Xw[0] - ti[0], Xw[1] - ti[1], Xw[2] - ti[2]};
+    mtv3(Ri, v, ta);
+    mv3(d.Rcb, ta, Pc);
+    Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
+}
+DEVI double idp_edge_chi2(const WinDesc& d, const double (&Pc)[3], double u, double v, double wgt, double& iz, double& ex, double& ey) {
+    iz = 1.0 / Pc[2];
+    ex = u - (Pc[0] * iz * d.K[0] + d.K[2]);
+    ey = v - (Pc[1] * iz * d.K[1] + d.K[3]);
+    return ex * (wgt * ex) + ey * (wgt * ey);
+}
+// chi2 and depth of edge go at the current estimates (the classification passes)
+DEVI void idp_edge_eval(const Batch& B, const WinDesc& d, size_t go, double& s, double& depth) {
+    const size_t gp = d.pt0 + B.obs_pt[go];
+    const double* C0 = B.kfR + 12 * (size_t)(d.kf0 + B.pt_ref[gp]);
+    const double* Ci = B.kfR + 12 * (size_t)(d.kf0 + B.obs_kf[go]);
+    double dd, c0[3], b0[3], Xw[3], ta[3], Pc[3], iz, ex, ey;
+    idp_point_world(d, C0, B.pt[3 * gp], B.pt[3 * gp + 1], B.pt[3 * gp + 2], dd, c0, b0, Xw);
+    idp_edge_pc(d, Xw, Ci, Ci + 9, ta, Pc);
+    depth = Pc[2];
+    s = idp_edge_chi2(d, Pc, B.obs_uv[2 * go], B.obs_uv[2 * go + 1], B.obs_w[go], iz, ex, ey);
+}
+
 DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
     double* ER = lsm;                       // 256 x LIN2_ES
     double* PT = lsm + 256 * LIN2_ES;       // 64 x LIN2_PS
@@ -548,21 +588,12 @@ DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
     // A. one lane per landmark: quantities shared by all its edges
     if (t < npb) {
         const size_t gp = d.pt0 + p0 + t;
-        double rho = B.pt[3 * gp];
-        const double xb = B.pt[3 * gp + 1], yb = B.pt[3 * gp + 2];
-        if (rho < 1e-6) rho = 1e-6;  // g2otypes.cpp:42-47
-        const double dd = 1.0 / rho;
-        const double P0[3] = {xb * dd, yb * dd, dd};
         const int rf = B.pt_ref[gp];
         const double* C0 = B.kfR + 12 * (size_t)(d.kf0 + rf);
-        double R0[9], c0[3], b0[3], y[3], Xw[3], tb[3], Hb[9], N0[9];
+        double R0[9], c0[3], b0[3], y[3], Xw[3], Hb[9], N0[9], dd;
 #pragma unroll
         for (int i = 0; i < 9; i++) R0[i] = C0[i];
-        mtv3(d.Rcb, P0, c0);
-        mtv3(d.Rcb, d.tcb, tb);
-        b0[0] = c0[0] - tb[0]; b0[1] = c0[1] - tb[1]; b0[2] = c0[2] - tb[2];
-        mv3(R0, b0, Xw);
-        Xw[0] += C0[9]; Xw[1] += C0[10]; Xw[2] += C0[11];
+        idp_point_world(d, C0, B.pt[3 * gp], B.pt[3 * gp + 1], B.pt[3 * gp + 2], dd, c0, b0, Xw);
         mv3(R0, c0, y);
         hat3(b0, Hb);
         mm3(R0, Hb, N0);
@@ -585,21 +616,14 @@ DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
         const size_t go = d.obs0 + e0 + t;
         const double* q = PT + pl * LIN2_PS;
         const int kf = e_kf;
-        const double v[3] = {q[4] - e_t[0], q[5] - e_t[1], q[6] - e_t[2]};
         double ta[3], Pc[3];
-        mtv3(Ri, v, ta);
-        mv3(d.Rcb, ta, Pc);
-        Pc[0] += d.tcb[0]; Pc[1] += d.tcb[1]; Pc[2] += d.tcb[2];
-        B.depth_e[go] = Pc[2];
+        idp_edge_pc(d, q + 4, Ri, e_t, ta, Pc);
         rpc[0] = Pc[0]; rpc[1] = Pc[1]; rpc[2] = Pc[2];
         double A[6] = {0, 0, 0, 0, 0, 0};
         if (!e_out) {
-            const double iz = 1.0 / Pc[2];
-            const double ex = e_u - (Pc[0] * iz * fx + cx);
-            const double ey = e_v - (Pc[1] * iz * fy + cy);
+            double iz, ex, ey;
             const double wgt = e_w;
-            const double s = ex * (wgt * ex) + ey * (wgt * ey);
-            B.chi2_e[go] = s;
+            const double s = idp_edge_chi2(d, Pc, e_u, e_v, wgt, iz, ex, ey);
             double rw = 1.0;
             if (c.robust_vis) chi = huber(s, d.hub_vis, &rw);
             else chi = s;
@@ -2299,7 +2323,12 @@ __global__ void __launch_bounds__(64) k_classify(Batch B) {
     const int o = blockIdx.x * 64 + threadIdx.x;
     if (o >= d.n_obs) return;
     const size_t go = d.obs0 + o;
-    bool bad = (B.chi2_e[go] > d.chi2_th) || !(B.depth_e[go] > d.depth_min);
+    double s, depth;
+    if (d.variant == 2) {   // inverse depth: evaluated here (idp_edge_eval); the value is kept for the edges this pass takes out --
+        idp_edge_eval(B, d, go, s, depth);   // e->chi2() of a level-1 edge stays what it was when the edge left the optimisation
+        B.chi2_e[go] = s;
+    } else { s = B.chi2_e[go]; depth = B.depth_e[go]; }
+    bool bad = (s > d.chi2_th) || !(depth > d.depth_min);
     if (d.variant == 2 && B.pt[3 * (size_t)(d.pt0 + B.obs_pt[go])] < d.rho_min) bad = true;
     if (bad) B.lvl[go] = 1;
 }
@@ -2318,9 +2347,15 @@ __global__ void __launch_bounds__(64) k_final_edges(Batch B) {
     double chi = 0.0, cnt = 0.0;
     if (o < d.n_obs) {
         const size_t go = d.obs0 + o;
-        const double stored = B.chi2_e[go];   // written by the last linearisation, i.e. at the final estimates
+        // e->chi2() at the final estimates (what the last linearisation computed); for an edge the outlier pass took out: its value
+        // at that pass (k_classify); the depth is evaluated at the final estimates for every edge (isDepthPositive())
+        double stored, depth;
+        if (d.variant == 2) {
+            idp_edge_eval(B, d, go, stored, depth);
+            if (B.lvl[go]) stored = B.chi2_e[go];
+        } else { stored = B.chi2_e[go]; depth = B.depth_e[go]; }
         const double s = never ? 0.0 : stored;
-        bool bad = (s > d.chi2_th) || !(B.depth_e[go] > d.depth_min);
+        bool bad = (s > d.chi2_th) || !(depth > d.depth_min);
         if (d.variant == 2 && (B.pt[3 * (size_t)(d.pt0 + B.obs_pt[go])] < d.rho_min || B.lvl[go])) bad = true;
         if (d.protocol == 1) bad = false;  // global BA classifies nothing
         B.out_outlier[go] = bad ? 1 : 0;
