@@ -720,9 +720,8 @@ DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
             sr[6] = beta;
             sr[7] = sD;
         } else if (sub == 3) {
-            double* nr = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + pp);
-#pragma unroll
-            for (int i = 0; i < 9; i++) nr[i] = N0[i];
+            // (N0 = R0 hat(b0) had a 128-byte record of its own here, 10 % of the bytes of a pass: its readers -- the reference items of
+            //  the off-diagonal Schur pairs -- rebuild it from the landmark and the reference keyframe's rotation, idp_point_world)
         } else {
             double Ms[9], MN[9], G0[21], g0[6];
             Ms[0] = M[0]; Ms[1] = M[1]; Ms[2] = M[2]; Ms[3] = M[1]; Ms[4] = M[3]; Ms[5] = M[4]; Ms[6] = M[2]; Ms[7] = M[4]; Ms[8] = M[5];
@@ -1037,29 +1036,48 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
         // the items [im, ie) involve the landmark's reference keyframe and also carry a direct H_pp term: the edge of the
         // other keyframe adds Br^T Bi (a = ref) or Bi^T Br (b = ref), with Br = [-A | A N0] rebuilt from the record's
         // A = Bi[:, 0:3].  Their own loop: the walk above stays free of this branch and of its loads.
+        // (indices one trip ahead, as above: item -> landmark of its reference record -> landmark is two dependent fetches otherwise)
+        int2 rnx = make_int2(0, 0);
+        int rnx_lm = 0;
+        if (im + l16 < ie) {
+            rnx = items[im + l16];
+            rnx_lm = B.rec_lm[d.pt0 + ((rnx.x >= d.n_obs) ? rnx.x : rnx.y) - d.n_obs];
+        }
         for (int it = im + l16; it < ie; it += LP) {
-            const int2 itm = items[it];
+            const int2 itm = rnx;
+            const size_t gp = d.pt0 + rnx_lm;   // the landmark of the reference record
+            if (it + LP < ie) {
+                rnx = items[it + LP];
+                rnx_lm = B.rec_lm[d.pt0 + ((rnx.x >= d.n_obs) ? rnx.x : rnx.y) - d.n_obs];
+            }
             const int sa = itm.x, sb = itm.y;
             const bool a_ref = sa >= d.n_obs;
             const double* re = B.erec + VBA_EREC1 * (size_t)(d.obs0 + (a_ref ? sb : sa));
-            const double* n0 = B.n0rec + VBA_N0REC * (size_t)(d.pt0 + (a_ref ? sa : sb) - d.n_obs);
+            const double rho = B.pt[3 * gp], xb = B.pt[3 * gp + 1], yb = B.pt[3 * gp + 2];
             const double* Ro = B.kfR + 12 * (size_t)(d.kf0 + (a_ref ? b : a));  // the observer's rotation
-            double N0[9], rec[6], bi0[6], bi1[6], rr0, rr1;
+            double rec[6], bi0[6], bi1[6], br0[6], br1[6], rr0, rr1;
 #pragma unroll
             for (int i = 0; i < 4; i++) rec[i] = re[i];
             rec[4] = rec[5] = 0.0;
             rebuild_edge(d, Ro, rec, bi0, bi1, rr0, rr1);   // (the rotation is read where it is used: nine registers fewer in flight)
+            {   // N0 = R0 hat(b0) of the landmark in its reference keyframe, as the linearisation forms it (lin2_body, phase A): the
+                // landmark has not moved since (the update comes after the solve).  Br = [-A | A N0], both rows, then N0 is dead.
+                const double* C0 = B.kfR + 12 * (size_t)(d.kf0 + (a_ref ? a : b));
+                double dd, c0[3], b0[3], Xw[3], Hb[9], N0[9];
+                idp_point_world(d, C0, rho, xb, yb, dd, c0, b0, Xw);
+                hat3(b0, Hb);
+                mm3(C0, Hb, N0);
 #pragma unroll
-            for (int i = 0; i < 9; i++) N0[i] = n0[i];
+                for (int k = 0; k < 3; k++) {
+                    br0[k] = -bi0[k]; br1[k] = -bi1[k];
+                    br0[3 + k] = bi0[0] * N0[k] + bi0[1] * N0[3 + k] + bi0[2] * N0[6 + k];
+                    br1[3 + k] = bi1[0] * N0[k] + bi1[1] * N0[3 + k] + bi1[2] * N0[6 + k];
+                }
+            }
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const double* bi = h ? bi1 : bi0;
-                double br[6];
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    br[k] = -bi[k];
-                    br[3 + k] = bi[0] * N0[k] + bi[1] * N0[3 + k] + bi[2] * N0[6 + k];
-                }
+                const double* br = h ? br1 : br0;
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     const double x = a_ref ? br[i] : bi[i];
@@ -1083,11 +1101,11 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
     __syncthreads();
     if (have) schur_write_block(B, d, c, w, pr, a, b, blk, l16, LP, 6);
 }
-__global__ void __launch_bounds__(64, 3) k_schur_off(Batch B, int max_quads) {
+__global__ void __launch_bounds__(64, 2) k_schur_off(Batch B, int max_quads) {   // (the split form, VBA_SCHUR_SPLIT: not the default path)
     __shared__ double blk4[4 * 36];
     schur_off_body<1, 16>(B, max_quads, blk4);
 }
-__global__ void __launch_bounds__(64, 3) k_schur_off_w(Batch B, int max_quads) {  // one pair per wave
+__global__ void __launch_bounds__(64) k_schur_off_w(Batch B, int max_quads) {  // one pair per wave
     __shared__ double blk4[4 * 36];
     schur_off_body<1, 64>(B, max_quads, blk4);
 }
@@ -1273,7 +1291,7 @@ __global__ void __launch_bounds__(64, 3) k_schur_all(Batch B, int max_free, int 
     else schur_off_body<1, 16>(B, max_quads, blk, w, idx - max_free);
 }
 // the same for fewer than 8 windows: one off-diagonal pair per wave (latency), still one launch
-__global__ void __launch_bounds__(64, 3) k_schur_all_w(Batch B, int max_free, int max_offp) {
+__global__ void __launch_bounds__(64) k_schur_all_w(Batch B, int max_free, int max_offp) {
     __shared__ double blk[15 * 15 + 16];
     __shared__ double sh_r[6], sh_b[6], sh_h[6];
     int w, idx;
