@@ -31,6 +31,10 @@ struct Structure {
     std::vector<unsigned long long> lmask;  // [n_pt][mwords] observing keyframes of every landmark
     std::vector<int> adj_begin, adj;        // PCG: per free keyframe the other free keyframes its block row of S is non-zero for
     std::vector<int> linblk;                // k_lin2 work split (inverse-depth windows): (p0, p1, e0, e1) per workgroup
+    // inverse-depth windows: a workgroup of k_lin2 sums the reference-keyframe terms (G0, g0) of its landmarks over RUNS of
+    // consecutive landmarks that share the reference keyframe and writes one record per run instead of one per landmark
+    std::vector<int> prun0;                 // per workgroup: id of its first run record (the window has prun0.back() of them)
+    std::vector<int> pref_begin, pref_list; // per keyframe the run records it is the reference of (ids ascending)
     int mwords = 1;
     long long item_cap = 0;            // upper bound of the off-diagonal items (exact when every keyframe is free)
     int order = 0;                     // elimination order of the reduced system (see below)
@@ -131,6 +135,26 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
             st.linblk.push_back(p_first); st.linblk.push_back(p);
             st.linblk.push_back(P->pt_obs_begin[p_first]); st.linblk.push_back(P->pt_obs_begin[p]);
         }
+    }
+    st.prun0.clear(); st.pref_begin.clear(); st.pref_list.clear();
+    if (idp) {
+        const int nblk = (int)(st.linblk.size() / 4);
+        std::vector<int> run_ref;
+        st.prun0.reserve(nblk + 1);
+        for (int lb = 0; lb < nblk; lb++) {
+            st.prun0.push_back((int)run_ref.size());
+            for (int p = st.linblk[4 * lb]; p < st.linblk[4 * lb + 1]; p++) {
+                const int rf = P->pt_ref_kf ? P->pt_ref_kf[p] : 0;
+                if (p == st.linblk[4 * lb] || rf != (P->pt_ref_kf ? P->pt_ref_kf[p - 1] : 0)) run_ref.push_back(rf);
+            }
+        }
+        st.prun0.push_back((int)run_ref.size());
+        st.pref_begin.assign(nkf + 1, 0);
+        for (int rf : run_ref) st.pref_begin[rf + 1]++;
+        for (int k = 0; k < nkf; k++) st.pref_begin[k + 1] += st.pref_begin[k];
+        st.pref_list.resize(run_ref.size());
+        std::vector<int> fill(st.pref_begin.begin(), st.pref_begin.end() - 1);
+        for (int id = 0; id < (int)run_ref.size(); id++) st.pref_list[fill[run_ref[id]]++] = id;
     }
     const double t_b1 = timing ? now_ms() : 0.0;
     // IMU edges per block pair: (edge, role) with role bit0: a is keyframe j of the edge, bit1: b is keyframe j

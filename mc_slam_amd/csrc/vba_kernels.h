@@ -52,6 +52,10 @@ struct Batch {
                                         // keyframe, landmark records by reference keyframe (the items of the diagonal pair (a,a))
     const int *off_pair, *pair_mask;  // off-diagonal pair indices; per pair: which sub-blocks of S are ever read
     const int* lin_blk;  // k_lin2: per workgroup its run of landmarks and edges (p0, p1, e0, e1), n_part_lin records per window
+    // inverse depth: the reference-keyframe terms (G0, g0) leave k_lin2 summed over runs of consecutive landmarks with one reference
+    // keyframe -- prun0[workgroup]: id of its first run record; per keyframe (rows at kf0 + win) the run records it is the
+    // reference of: pref_list[pt0 + pref_begin[k] .. pref_begin[k + 1])
+    const int *prun0, *pref_begin, *pref_list;
     // tile structure of the factor (symbolic factorisation on 32x32 tiles, built at upload)
     const int *tl_step_begin, *tl_pairs, *tl_pan_begin, *tl_pan;
     const int *tl_kl_begin, *tl_kl;  // left-looking factorisation: per column entry (J,J),(I,J).. the steps k < J that update it
@@ -586,6 +590,8 @@ DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
         c_pp = B.pt_perm[d.pt0 + p];
     }
     // A. one lane per landmark: quantities shared by all its edges
+    int a_run = 0, a_nruns = 0;   // (landmark lanes, all in wave 0: run of consecutive landmarks with one reference keyframe; runs of the workgroup)
+    bool a_first = false;
     if (t < npb) {
         const size_t gp = d.pt0 + p0 + t;
         const int rf = B.pt_ref[gp];
@@ -604,6 +610,13 @@ DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
 #pragma unroll
         for (int i = 0; i < 9; i++) q[7 + i] = N0[i];
         q[16] = (kf_free(B, d, rf) & 1) ? 1.0 : 0.0;
+        if (mode == LIN_FULL) {
+            const int rf_prev = __shfl_up(rf, 1, 64);
+            a_first = (t == 0) || (rf != rf_prev);
+            const unsigned long long fm = __ballot(a_first);
+            a_run = __popcll(fm & ((2ull << t) - 1ull)) - 1;
+            a_nruns = __popcll(fm);
+        }
     }
     __syncthreads();
     // B. one lane per edge.  With A = sqrt(rho' w) J_pi R_cb R_i^T (2x3) the two pose Jacobians of the edge are
@@ -672,11 +685,16 @@ DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
     __syncthreads();
     // C. FOUR lanes per landmark: each sums every fourth edge (fixed order), the quad adds up (fixed order again), then
     //    all four hold D, b_l and, for the reference keyframe, sum Br^T Br = Q^T (sum A^T A) Q, sum Br^T a = Q^T sum A^T a,
-    //    sum Br^T r = Q^T sum A^T r with Q = [-I | N0]; the three records of the landmark leave from different lanes
+    //    sum Br^T r = Q^T sum A^T r with Q = [-I | N0].  The landmark's reference slot record leaves from lane 0 of the quad; the
+    //    reference keyframe's direct terms (G0: 21, g0: 6) go to LDS -- over the edge rows, which nobody reads any more after the
+    //    barrier -- and leave summed over RUNS of consecutive landmarks with one reference keyframe (phase E): one 256-byte record
+    //    per run instead of one per landmark (a quarter of the bytes of a pass when the caller's landmarks come track by track).
+    double* GS = ER;                                            // 64 x 28
+    int* RS = reinterpret_cast<int*>(ER + 64 * 28);             // run starts [nruns + 1], then the number of runs
+    double gv[7];
+    const int c_jl = t >> 2, c_sub = t & 3;
     if (t < 4 * npb) {
-        const int jl = t >> 2, sub = t & 3;
-        const int p = p0 + jl;
-        const size_t gp = d.pt0 + p;
+        const int jl = c_jl, sub = c_sub;
         double D = 0, bl = 0, M[6] = {0, 0, 0, 0, 0, 0}, wa[3] = {0, 0, 0}, wr[3] = {0, 0, 0};
         for (int o = c_ob + sub; o < c_oe; o += 4) {
             const double* er = ER + o * LIN2_ES;
@@ -719,18 +737,13 @@ DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
             }
             sr[6] = beta;
             sr[7] = sD;
-        } else if (sub == 3) {
-            // (N0 = R0 hat(b0) had a 128-byte record of its own here, 10 % of the bytes of a pass: its readers -- the reference items of
-            //  the off-diagonal Schur pairs -- rebuild it from the landmark and the reference keyframe's rotation, idp_point_world)
-        } else {
-            double Ms[9], MN[9], G0[21], g0[6];
+        }
+        // (N0 = R0 hat(b0) had a 128-byte record of its own, 10 % of the bytes of a pass: its readers -- the reference items of the
+        //  off-diagonal Schur pairs -- rebuild it from the landmark and the reference keyframe's rotation)
+        {   // G0 (21) and g0 (6): every lane of the quad forms them, lane `sub` keeps values 7 sub .. 7 sub + 6 across the barrier
+            double Ms[9], MN[9], G[28];
             Ms[0] = M[0]; Ms[1] = M[1]; Ms[2] = M[2]; Ms[3] = M[1]; Ms[4] = M[3]; Ms[5] = M[4]; Ms[6] = M[2]; Ms[7] = M[4]; Ms[8] = M[5];
             mm3(Ms, N0, MN);
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                g0[k] = wr[k] * rfm;
-                g0[3 + k] = -(N0[k] * wr[0] + N0[3 + k] * wr[1] + N0[6 + k] * wr[2]) * rfm;
-            }
             int gi = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++)
@@ -740,20 +753,27 @@ DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
                     if (i < 3 && j < 3) v = Ms[3 * i + j];
                     else if (i < 3) v = -MN[3 * i + (j - 3)];
                     else v = N0[i - 3] * MN[j - 3] + N0[3 + i - 3] * MN[3 + j - 3] + N0[6 + i - 3] * MN[6 + j - 3];
-                    G0[gi++] = v * rfm;
+                    G[gi++] = v * rfm;
                 }
-            double* pr = B.prec + VBA_PREC * (size_t)(d.pt0 + pp);
-            if (sub == 1) {
 #pragma unroll
-                for (int i = 0; i < 14; i++) pr[i] = G0[i];
-            } else {
-#pragma unroll
-                for (int i = 14; i < 21; i++) pr[i] = G0[i];
-#pragma unroll
-                for (int i = 0; i < 6; i++) pr[21 + i] = g0[i];
-                pr[27] = D;
+            for (int k = 0; k < 3; k++) {
+                G[21 + k] = wr[k] * rfm;
+                G[24 + k] = -(N0[k] * wr[0] + N0[3 + k] * wr[1] + N0[6 + k] * wr[2]) * rfm;
             }
+            G[27] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 7; i++) gv[i] = (sub == 0) ? G[i] : (sub == 1) ? G[7 + i] : (sub == 2) ? G[14 + i] : G[21 + i];
         }
+    }
+    __syncthreads();   // every quad has read its edge rows: they become GS / RS
+    if (t < 4 * npb) {
+        double* g = GS + c_jl * 28 + 7 * c_sub;   // [0..20] G0, [21..26] g0
+#pragma unroll
+        for (int i = 0; i < 7; i++) g[i] = gv[i];
+    }
+    if (t < npb) {
+        if (a_first) RS[a_run] = t;
+        if (t == 0) { RS[a_nruns] = npb; RS[65] = a_nruns; }
     }
     __syncthreads();
     // D. one lane per edge: its slot record U = Bi^T a / sqrt(D) and its 64-B edge record (P_c, scale, weighted residual),
@@ -770,6 +790,17 @@ DEVI void lin2_body(const Batch& B, int nblk_lin, int mode, double* lsm) {
         dst[0] = make_double2(rpc[0], rpc[1]);
         dst[1] = make_double2(rpc[2], rsc);
         dst[2] = make_double2(r2[0], r2[1]);
+    }
+    // E. the reference-keyframe terms, one record per run: value v of run r is the sum over the run's landmarks, in order
+    {
+        const int nruns = RS[65];
+        double* pr0 = B.prec + VBA_PREC * (size_t)(d.pt0 + B.prun0[d.lb0 + lb]);
+        for (int idx = t; idx < nruns * 27; idx += 256) {
+            const int r = idx / 27, v = idx - 27 * r;
+            double sum = 0.0;
+            for (int jl = RS[r]; jl < RS[r + 1]; jl++) sum += GS[jl * 28 + v];
+            pr0[VBA_PREC * r + v] = sum;
+        }
     }
     const double tot = block_sum256(chi, red);
     if (t == 0) B.part[d.part0 + lb] = tot;
@@ -1150,7 +1181,30 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
 #pragma unroll
         for (int i = 0; i < 9; i++) Ra[i] = Ca[i];
     }
-    for (int it = t; it < n_o + n_r; it += 64) {
+    // inverse depth: a third range of items -- the run records of this keyframe's reference terms (G0: 21, g0: 6 summed over runs of
+    // landmarks by k_lin2, phase E).  A lane's first run item has its index fetched now: inside the walk only the record itself is a
+    // dependent fetch, like a slot record.
+    int n_run = 0, run_first = -1;
+    const int* run_list = nullptr;
+    if (LD == 1) {
+        const int* pfb = B.pref_begin + d.kf0 + d.win;
+        const int m0 = pfb[a];
+        n_run = pfb[a + 1] - m0;
+        run_list = B.pref_list + d.pt0 + m0;
+        const int j0 = (t - (n_o + n_r)) & 63;   // the first run item this lane meets in the walk
+        if (j0 < n_run) run_first = run_list[j0];
+    }
+    for (int it = t; it < n_o + n_r + n_run; it += 64) {
+        if (LD == 1 && it >= n_o + n_r) {   // a run record: direct terms only
+            const int j = it - (n_o + n_r);
+            const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + ((j < 64) ? run_first : run_list[j]));
+#pragma unroll
+            for (int g = 0; g < 21; g++) acc[g] += pr_[g];
+            // (no H_pp diagonal here: it feeds Levenberg-Marquardt's lambda init, and inverse-depth windows run Gauss-Newton)
+#pragma unroll
+            for (int i = 0; i < 6; i++) bp[i] += pr_[21 + i];
+            continue;
+        }
         const int sa = (it < n_o) ? s0 + it : d.n_obs + r0s + (it - n_o);
         // XYZ landmarks (Levenberg-Marquardt): the direct terms sum Bi^T Bi and b_p do not depend on the damping, so the pass
         // that opens an outer iteration (hd_pass) takes them from the edge records ONCE and parks them per keyframe (kf_dir);
@@ -1182,12 +1236,7 @@ DEVI void schur_diag_body(const Batch& B, int max_free, int hd_pass, double* blk
         }
         if (!want_dir) {
         } else if (LD == 1 && sa >= d.n_obs) {
-            const double* pr_ = B.prec + VBA_PREC * (size_t)(d.pt0 + sa - d.n_obs);
-#pragma unroll
-            for (int g = 0; g < 21; g++) acc[g] += pr_[g];
-            // (no H_pp diagonal here: it feeds Levenberg-Marquardt's lambda init, and inverse-depth windows run Gauss-Newton)
-#pragma unroll
-            for (int i = 0; i < 6; i++) bp[i] += pr_[21 + i];
+            // (a landmark record of this keyframe: its direct terms come summed over runs of landmarks, below)
         } else {
             const double* ra = B.erec + ((LD == 1) ? VBA_EREC1 : VBA_EREC) * (size_t)(d.obs0 + sa);
             double r0 = 0.0, r1 = 0.0;

@@ -131,7 +131,7 @@ struct Staging {
     PinVec<int> ptref, ptobs, obskf, imui, imuj, pair_a, pair_b, pimu_begin, pimu;
     PinVec<int> offpair, pairmask;
     PinVec<unsigned long long> lmask;
-    PinVec<int> s_int[9];        // pinned copies of the small host-built lists (tile lists, k_lin2 runs)
+    PinVec<int> s_int[12];       // pinned copies of the small host-built lists (tile lists, k_lin2 runs, reference-run lists)
     PinVec<WinDesc> s_desc;
     PinVec<double> dl_pose, dl_vel, dl_bias, dl_pt, dl_chi2;
     PinVec<unsigned char> dl_outl;
@@ -152,7 +152,7 @@ enum {
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
     BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_SLOTO, BUF_SLOTREF, BUF_SLOTQ, BUF_RECQ, BUF_TSQ, BUF_RECCNT, BUF_RESULTS, BUF_N
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_SLOTO, BUF_SLOTREF, BUF_SLOTQ, BUF_RECQ, BUF_TSQ, BUF_RECCNT, BUF_RESULTS, BUF_PRUN0, BUF_PREFBEG, BUF_PREFLIST, BUF_N
 };
 
 struct ProfEvt {
@@ -401,7 +401,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     auto &offpair = G.offpair, &pairmask = G.pairmask;
     auto& lmask = G.lmask;
     G.each([](auto& v) { v.clear(); });
-    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, tlkb, tlk, adjbeg, adj;
+    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, tlkb, tlk, adjbeg, adj, prun0, prefbeg, preflist;
     const bool pcg = probs[0] && probs[0]->solver == VBA_SOLVER_PCG;
     h->step_grid.clear();
     h->pan_grid.clear();
@@ -551,6 +551,14 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
                 linblk.insert(linblk.end(), st.linblk.begin(), st.linblk.end());
                 d.n_part_lin = (int)(st.linblk.size() / 4);
                 d.lin_runs = 1;
+                if (!st.prun0.empty()) {   // inverse depth: the run records of the reference-keyframe terms (ids window-local)
+                    prun0.resize((size_t)d.lb0, 0);
+                    prun0.insert(prun0.end(), st.prun0.begin(), st.prun0.end() - 1);
+                    prefbeg.resize((size_t)kf0 + w, 0);   // rows start at kf0 + win, like the keyframe segments
+                    prefbeg.insert(prefbeg.end(), st.pref_begin.begin(), st.pref_begin.end());
+                    preflist.resize((size_t)pt0, 0);      // a window has at most n_pt run records: its list starts at pt0
+                    preflist.insert(preflist.end(), st.pref_list.begin(), st.pref_list.end());
+                }
             } else
                 h->any_lin_fallback = true;
             d.S0 = (long long)S_tot;
@@ -725,6 +733,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
         if (dalloc(h, BUF_PCGV, (size_t)vec0 * 5 * 8) || dalloc(h, BUF_PCGM, (size_t)kf0 * 225 * 8) || dalloc(h, BUF_PCGS, (size_t)n * 8 * 8)) return -1;
     }
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d_vec(h, BUF_LINBLK, linblk, G.s_int[6])) return -1;
+    prun0.resize(linblk.size() / 4 + 1, 0); prefbeg.resize((size_t)kf0 + n + 1, 0); preflist.resize((size_t)pt0 + 1, 0);
+    if (h2d_vec(h, BUF_PRUN0, prun0, G.s_int[9]) || h2d_vec(h, BUF_PREFBEG, prefbeg, G.s_int[10]) || h2d_vec(h, BUF_PREFLIST, preflist, G.s_int[11])) return -1;
     if (h2d(h, BUF_OFFPAIR, offpair) || h2d(h, BUF_PAIRMASK, pairmask)) return -1;
     if (dalloc(h, BUF_PART, (size_t)part0 * 8) || dalloc(h, BUF_OUTL, (size_t)obs0) || dalloc(h, BUF_OUTCHI, (size_t)obs0 * 8)) return -1;
     h->res_bytes = 0;
@@ -784,6 +794,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     B.lmask = dp<unsigned long long>(h, BUF_LMASK); B.kf_seg = dp<int>(h, BUF_KFSEG); B.ref_seg = dp<int>(h, BUF_REFSEG);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
     B.lin_blk = dp<int>(h, BUF_LINBLK);
+    B.prun0 = dp<int>(h, BUF_PRUN0); B.pref_begin = dp<int>(h, BUF_PREFBEG); B.pref_list = dp<int>(h, BUF_PREFLIST);
     B.off_pair = dp<int>(h, BUF_OFFPAIR); B.pair_mask = dp<int>(h, BUF_PAIRMASK);
     B.part = dp<double>(h, BUF_PART);
     B.stop_host_word = h->stop_dev;
@@ -1773,7 +1784,7 @@ int vba_debug_buf_id(const char* name) {
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
         "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE", "SLOTO", "SLOTREF", "SLOTQ", "RECQ", "TSQ", "RECCNT", "RESULTS"};
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE", "SLOTO", "SLOTREF", "SLOTQ", "RECQ", "TSQ", "RECCNT", "RESULTS", "PRUN0", "PREFBEG", "PREFLIST"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;

@@ -35,6 +35,25 @@ int main(int argc, char** argv) {
                 p = st.linblk[i + 1];
             }
             ok = ok && p == P->n_pt;
+            // the run records of the reference-keyframe terms: per workgroup the maximal runs of consecutive landmarks with one reference
+            // keyframe, ids in workgroup order; per keyframe the ids of its runs, ascending, every run listed exactly once
+            const int nblk = (int)(st.linblk.size() / 4);
+            ok = ok && (int)st.prun0.size() == nblk + 1 && (int)st.pref_begin.size() == P->n_kf + 1;
+            int id = 0;
+            std::vector<int> ref_of;
+            for (int lb = 0; lb < nblk && ok; lb++) {
+                ok = ok && st.prun0[lb] == id;
+                for (int q = st.linblk[4 * lb]; q < st.linblk[4 * lb + 1]; q++)
+                    if (q == st.linblk[4 * lb] || P->pt_ref_kf[q] != P->pt_ref_kf[q - 1]) { ref_of.push_back(P->pt_ref_kf[q]); id++; }
+            }
+            ok = ok && st.prun0.back() == id && (int)st.pref_list.size() == id && id <= P->n_pt && st.pref_begin.back() == id;
+            std::vector<int> seen(id, 0);
+            for (int k = 0; k < P->n_kf && ok; k++)
+                for (int m = st.pref_begin[k]; m < st.pref_begin[k + 1]; m++) {
+                    const int r = st.pref_list[m];
+                    ok = ok && r >= 0 && r < id && ref_of[r] == k && !seen[r] && (m == st.pref_begin[k] || st.pref_list[m - 1] < r);
+                    if (ok) seen[r] = 1;
+                }
         }
         printf("%s order %d mwords %d item_cap %lld mask_bits %lld tiles %zu klist %zu pimu %zu pan %zu h_tiles %llx h_mask %llx\n", ok ? "ok" : "error inconsistent",
                st.order, st.mwords, st.item_cap, mask_bits, st.tpairs.size(), st.klist.size(), st.pimu.size() / 2, st.pan.size(),
