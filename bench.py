@@ -44,12 +44,14 @@ def csrc_sha():
 
 
 def _gen_window(spec):
-    """(workload, seed, uniform) -> Problem; runs in forked worker processes (numpy only, no GPU, no torch)"""
+    """(workload, seed, uniform, landmark order) -> Problem; runs in forked worker processes (numpy only, no GPU, no torch)"""
     from mc_slam_amd import synth
-    wl, seed, uniform = spec
+    wl, seed, uniform, order = spec
     if wl == "c3":
-        return synth.config_c3(seed=seed) if uniform else synth.config_c3_ragged(seed=seed)
-    return {"c2": synth.config_c2, "c4": synth.config_c4, "gba": synth.config_gba, "c3s": synth.config_c3s, "c2s": synth.config_c2s}[wl](seed=seed)
+        return synth.config_c3(seed=seed, landmark_order=order) if uniform else synth.config_c3_ragged(seed=seed, landmark_order=order)
+    if wl in ("c4", "c3s"):   # inverse-depth windows: the order the caller hands landmarks over in matters to the record layout
+        return {"c4": synth.config_c4, "c3s": synth.config_c3s}[wl](seed=seed, landmark_order=order)
+    return {"c2": synth.config_c2, "gba": synth.config_gba, "c2s": synth.config_c2s}[wl](seed=seed)
 
 
 def make_windows(specs, n_proc):
@@ -129,6 +131,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default: 4096 for c3, 2048 for c2, 16 for c4, 4 for gba, 4096 frames for pose)")
     ap.add_argument("--distinct", type=int, default=None, help="distinct seeded windows generated per rank and replicated to fill the batch (default: 256 for c3, 16 for c2, 2 for c4 / gba)")
+    ap.add_argument("--landmark-order", default="caller", choices=["caller", "random"],
+                    help="inverse-depth workloads (c3, c3s, c4): 'caller' = landmarks in the order the reference's caller builds lLocalMapPoints in -- keyframe by "
+                         "keyframe over lLocalKeyFrames, every keyframe appending the map points no earlier one has listed (src/Optimizer.cpp:59-78), i.e. grouped by "
+                         "the first local keyframe that observes them; 'random' = the generator's order (uncorrelated with the keyframes; the workload of rounds 1-3a)")
     ap.add_argument("--uniform", action="store_true", help="c3: every window exactly 50 KF / 5 000 landmarks / 30 000 edges instead of sizes drawn around it")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose", "c3s", "c2s"],
                     help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, pose = IMU-aided per-frame pose "
@@ -164,7 +170,7 @@ def main():
     specs = []
     if args.workload != "pose":
         n_distinct = max(1, min(args.distinct, args.batch))
-        specs = [(args.workload, shard.window_seed(g), args.uniform) for g in shard.window_ids(n_distinct * world, rank, world)]
+        specs = [(args.workload, shard.window_seed(g), args.uniform, args.landmark_order) for g in shard.window_ids(n_distinct * world, rank, world)]
     # under rocprofv3 the profiler's preloaded library has initialised the GPU runtime before main(): forking such a process is
     # what this pool forbids (children inherit the runtime's locks; an intermittent hang of a PMC pass was traced to it) -> serial
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -290,7 +296,7 @@ def main():
         if args.single_reps > 0 and args.workload in ("c2", "c3", "c3s", "c2s"):
             import ctypes as C
             from mc_slam_amd import abi, synth
-            w1 = synth.config_c3(seed=3) if args.workload == "c3" else wins[0]
+            w1 = synth.config_c3(seed=3, landmark_order=args.landmark_order) if args.workload == "c3" else wins[0]
             ba1 = backend.LocalBA(local_rank)
             ts = []
             for k in range(args.single_reps + 3):
@@ -483,6 +489,8 @@ def main():
                                           "chain, GN 5+10",
                                     "gba": "GlobalBundleAdjustmentNavStatePRV, 300 KF / 30000 XYZ landmarks / 180000 EdgeNavStatePRPointXYZ "
                                            "+ IMU chain, LM optimize(10)"}[args.workload],
+                       "landmark_order": (args.landmark_order + (" (grouped by first local keyframe, as src/Optimizer.cpp:59-78 builds lLocalMapPoints)" if args.landmark_order == "caller" else
+                                                                 " (uncorrelated with the keyframes)")) if args.workload in ("c3", "c3s", "c4") else None,
                        "windows_per_gpu_per_step": args.batch, "distinct_windows": len(wins),
                        "n_kf_range": rng(lambda w: w.n_kf), "n_pt_range": rng(lambda w: w.n_pt), "n_obs_range": rng(lambda w: w.n_obs),
                        "mean_n_kf": float(np.mean([w.n_kf for w in batch])), "mean_n_obs": float(np.mean([w.n_obs for w in batch])),

@@ -155,7 +155,7 @@ def prv_information(cov_pvphi):
 # ---------------------------------------------------------------- the generator
 def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_obs=30000, seed=3,
                 kf_dt=0.25, imu_dt=0.005, outlier_frac=0.05, algo=None, noise=True, init_scale=1.0, pix_noise=1.0,
-                tracks="nearest"):
+                tracks="nearest", landmark_order="random"):
     """Build one synthetic local-BA window.
 
     n_kf keyframes in time order t0..; the FIRST n_fixed in time are fixed (the window's predecessor and,
@@ -271,6 +271,18 @@ def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_ob
     pidx = np.zeros(n_kf, dtype=np.int64)
     pidx[tidx] = np.arange(n_kf)
 
+    if landmark_order == "caller":
+        # the order the reference's caller hands landmarks over in: lLocalMapPoints is filled keyframe by keyframe over
+        # lLocalKeyFrames (oldest first, the current keyframe last), every keyframe appending the map points no earlier one has
+        # listed (src/Optimizer.cpp:59-78) -- landmarks come grouped by the FIRST local keyframe that observes them; inside a
+        # group the order is the keyframe's feature order (arbitrary: the generation order here)
+        key = np.array([min(int(pidx[k]) for k in l if pidx[k] < n_free) for l in obs_lists])
+        perm = np.argsort(key, kind="stable")
+        pts_w = pts_w[perm]
+        obs_lists = [obs_lists[i] for i in perm]
+    elif landmark_order != "random":
+        raise ValueError("landmark_order: 'random' or 'caller'")
+
     # observations (vectorised): edge list in point order, ascending keyframe time inside a point
     first = 1 if variant == abi.VARIANT_PRV_IDP else 0
     e_pt = np.concatenate([np.full(len(l) - first, p) for p, l in enumerate(obs_lists)])
@@ -375,12 +387,12 @@ def config_c2(seed=2):
     return make_window(abi.VARIANT_SE3_XYZ, n_kf=20, n_fixed=2, n_pt=2000, n_obs=12000, seed=seed)
 
 
-def config_c3(seed=3, n_kf=50, n_pt=5000, n_obs=30000):
+def config_c3(seed=3, n_kf=50, n_pt=5000, n_obs=30000, landmark_order="random"):
     """LocalBAPRVIDP: 50 KF (49 free + fixed predecessor) / 5k pts / 30k EdgePRIDP + 49 PRV + 49 bias, GN."""
-    return make_window(abi.VARIANT_PRV_IDP, n_kf=n_kf, n_fixed=1, n_pt=n_pt, n_obs=n_obs, seed=seed)
+    return make_window(abi.VARIANT_PRV_IDP, n_kf=n_kf, n_fixed=1, n_pt=n_pt, n_obs=n_obs, seed=seed, landmark_order=landmark_order)
 
 
-def config_c3_ragged(seed=3):
+def config_c3_ragged(seed=3, landmark_order="random"):
     """A LocalBAPRVIDP window whose size is drawn around BASELINE configs[2]: 40..60 keyframes (mean 50), 100 landmarks per
     keyframe, 6 edges per landmark (mean 5 000 / 30 000) -- so that the windows of a batch differ in size, co-visibility and
     ITERATION COUNTS the way the windows of a real session do (everything depends on the seed only).  Three kinds of window:
@@ -398,15 +410,15 @@ def config_c3_ragged(seed=3):
     elif kind >= 0.6:
         outlier_frac, pix = 0.0, 0.3
     return make_window(abi.VARIANT_PRV_IDP, n_kf=n_kf, n_fixed=1, n_pt=100 * n_kf, n_obs=600 * n_kf, seed=seed,
-                       outlier_frac=outlier_frac, pix_noise=pix)
+                       outlier_frac=outlier_frac, pix_noise=pix, landmark_order=landmark_order)
 
 
-def config_c3s(seed=3):
+def config_c3s(seed=3, landmark_order="random"):
     """The LocalBAPRVIDP window of configs[2] with SCATTERED co-visibility: 50 free keyframes + 8 fixed older
     co-observers (src/Optimizer.cpp:199-232: every keyframe outside the window that sees a window landmark is added as a fixed
     vertex), 5 000 landmarks / 30 000 edges whose tracks are random subsets of the keyframes that see them (gaps instead of runs of
     consecutive keyframes), 10-20 % of the landmarks anchored in a fixed reference keyframe."""
-    return make_window(abi.VARIANT_PRV_IDP, n_kf=58, n_fixed=8, n_pt=5000, n_obs=30000, seed=seed, tracks="random")
+    return make_window(abi.VARIANT_PRV_IDP, n_kf=58, n_fixed=8, n_pt=5000, n_obs=30000, seed=seed, tracks="random", landmark_order=landmark_order)
 
 
 def config_c2s(seed=2):
@@ -415,9 +427,9 @@ def config_c2s(seed=2):
     return make_window(abi.VARIANT_SE3_XYZ, n_kf=20, n_fixed=2, n_pt=2000, n_obs=12000, seed=seed, tracks="random")
 
 
-def config_c4(seed=4):
+def config_c4(seed=4, landmark_order="random"):
     """Synthetic VI graph: 200 KF / 50k pts / 500k obs + IMU chain."""
-    return make_window(abi.VARIANT_PRV_IDP, n_kf=200, n_fixed=1, n_pt=50000, n_obs=500000, seed=seed)
+    return make_window(abi.VARIANT_PRV_IDP, n_kf=200, n_fixed=1, n_pt=50000, n_obs=500000, seed=seed, landmark_order=landmark_order)
 
 
 def config_gba(seed=6, n_kf=300, n_pt=30000, n_obs=180000, its=10, robust=1):

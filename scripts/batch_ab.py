@@ -7,7 +7,8 @@ from mc_slam_amd import synth, backend
 import oracle_lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-wins = [synth.config_c3_ragged(100 + i) for i in range(nd)]
+order = os.environ.get("AB_LM_ORDER", "random")   # "caller": landmarks grouped by first local keyframe (src/Optimizer.cpp:59-78)
+wins = [synth.config_c3_ragged(100 + i, landmark_order=order) for i in range(nd)]
 ba = backend.LocalBA(0)
 ba.upload([wins[i % nd] for i in range(n)])
 ba.run(); ba.run()

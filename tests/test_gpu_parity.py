@@ -569,3 +569,27 @@ def test_structure_row_walk_in_lanes_equals_the_lds_walk(ba):
         assert np.array_equal(q.kf_pose, q1.kf_pose) and np.array_equal(q.pt, q1.pt)
     for q, q1, r, r1 in zip(qb, qc, rb, rc):
         assert r.chi2_vis == r1.chi2_vis and np.array_equal(q.kf_pose, q1.kf_pose)
+
+
+@pytest.mark.parametrize("make", [
+    lambda: synth.config_c3_ragged(411, landmark_order="caller"),
+    lambda: synth.config_c3s(412, landmark_order="caller"),                       # fixed reference keyframes inside the runs
+    lambda: synth.make_window(abi.VARIANT_PRV_IDP, n_kf=9, n_fixed=2, n_pt=300, n_obs=1500, seed=413, landmark_order="caller"),
+    lambda: synth.make_window(abi.VARIANT_PRV_IDP, n_kf=70, n_fixed=1, n_pt=900, n_obs=5400, seed=414, landmark_order="caller"),   # two mask words
+], ids=["c3_ragged", "c3s", "small", "70kf"])
+def test_landmarks_in_the_callers_order_match_oracle(ba, oracle, make):
+    """The reference's caller hands landmarks over grouped by the first local keyframe that observes them (lLocalMapPoints is filled
+    keyframe by keyframe, src/Optimizer.cpp:59-78).  k_lin2 then sums the reference-keyframe terms of a workgroup over RUNS of
+    landmarks with one reference keyframe (one record per run; the other windows of this suite come in random order: runs of one):
+    alone and inside a batch, against the oracle (which does not care about the order)."""
+    p = make()
+    runs = 1 + int((np.diff(p.pt_ref_kf) != 0).sum())
+    assert runs < 0.8 * p.n_pt                  # runs of several landmarks (long ones in the sliding windows, short ones with scattered tracks)
+    q, r = ba.solve(p)
+    qo, ro = oracle.solve(p)
+    _check(p, q, r, qo, ro)
+    if p.n_pt <= 1000:
+        ps = [p, synth.make_window(abi.VARIANT_PRV_IDP, n_kf=9, n_fixed=2, n_pt=300, n_obs=1500, seed=415)] * 5   # mixed with random-order windows
+        ba.upload(ps); ba.run(); qs, rs = ba.download()
+        for qq, rr in zip(qs[0::2], rs[0::2]):
+            assert rr.its_done == r.its_done and np.abs(qq.kf_pose - q.kf_pose).max() < 1e-9
