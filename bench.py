@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcg", action="store_true", help="c4 / gba: skip the second run of the batch with the PCG solver")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--e2e-chi2", action="store_true", help="end to end: also bring the per-edge chi2 back (an optional output of the C-ABI, 8 B per edge; the reference's "
+                    "caller reads the erase list only)")
     ap.add_argument("--e2e-steps", type=int, default=4, help="timed vba_batch_solve calls over fresh copies of the batch (0: skip)")
     ap.add_argument("--gen-procs", type=int, default=None, help="worker processes that generate the synthetic windows (default: up to 16; 1 under a profiler)")
     ap.add_argument("--single-reps", type=int, default=21, help="vba_solve repetitions behind single_window_ms (0: skip)")
@@ -267,7 +269,7 @@ def main():
     # ---- (2) end to end: fresh host arrays in, solved host arrays out ----
     e2e = None
     if args.e2e_steps > 0:
-        packed = ba.pack(batch)
+        packed = ba.pack(batch, want_chi2=args.e2e_chi2)
         ba.solve_packed(packed)                      # warm-up: lanes, pinned staging and device buffers get allocated
         tot_e, dt_e = 0, 0.0
         for _ in range(args.e2e_steps):
@@ -285,7 +287,8 @@ def main():
                 raise SystemExit("bench: vba_batch_solve and upload+run+download disagree on window %d" % i)
         e2e = {"value": tot_e / dt_e, "unit": "windows/s", "steps": args.e2e_steps, "ms_per_step": dt_e / args.e2e_steps * 1e3,
                "frac_of_resident": (tot_e / dt_e) / value,
-               "what": "vba_batch_solve on fresh copies of the batch: host packing + H2D + structure build + solve + D2H + scatter, chunks in flight concurrently"}
+               "what": "vba_batch_solve on fresh copies of the batch: host packing + H2D + structure build + solve + D2H + scatter, chunks in flight concurrently; "
+                       "back come states, landmarks and the erase list" + (" and the per-edge chi2" if args.e2e_chi2 else " (the optional per-edge chi2 is not requested: --e2e-chi2)")}
         del packed, sol_e, res_e
 
     out = None

@@ -193,18 +193,22 @@ class Result:
 class ResultBuf:
     """Caller-allocated result storage for one window."""
 
-    def __init__(self, n_obs: int):
+    def __init__(self, n_obs: int, want_chi2: bool = True):
+        """want_chi2 = False: vba_result.obs_chi2 stays NULL -- the per-edge chi2 is an optional output (the reference's caller reads
+        the erase list only: the classification of src/Optimizer.cpp:496-517 happens inside the call)"""
         self.outlier = np.zeros(max(n_obs, 1), dtype=np.uint8)
-        self.chi2 = np.zeros(max(n_obs, 1), dtype=np.float64)
+        self.chi2 = np.zeros(max(n_obs, 1) if want_chi2 else 1, dtype=np.float64)
         self.n_obs = n_obs
+        self.want_chi2 = want_chi2
         self.s = vba_result()
         self.s.obs_outlier = self.outlier.ctypes.data_as(_pu8)
-        self.s.obs_chi2 = self.chi2.ctypes.data_as(_pd)
+        if want_chi2:
+            self.s.obs_chi2 = self.chi2.ctypes.data_as(_pd)
 
     def get(self) -> Result:
         s = self.s
         return Result(s.chi2_vis, s.chi2_prv, s.chi2_bias, (s.its_done[0], s.its_done[1]), s.n_outliers, s.status,
-                      self.outlier[:self.n_obs].copy(), self.chi2[:self.n_obs].copy(),
+                      self.outlier[:self.n_obs].copy(), self.chi2[:self.n_obs].copy() if self.want_chi2 else None,
                       np.array(s.chi2_trace[:s.n_trace]), s.lambda_final, s.lin_iterations)
 
 

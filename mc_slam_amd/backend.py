@@ -111,12 +111,12 @@ class LocalBA:
         return self._probs, [r.get() for r in rbs]
 
     # ---- fresh windows in, solved windows out (vba_batch_solve: chunks of the batch in flight concurrently) ----
-    def pack(self, probs):
+    def pack(self, probs, want_chi2=True):
         """private copies of the windows + the ctypes views vba_batch_solve needs (kept alive by the returned dict)"""
         n = len(probs)
         own = [p.copy() for p in probs]
         structs = [p.as_struct() for p in own]
-        rbs = [abi.ResultBuf(p.n_obs) for p in own]
+        rbs = [abi.ResultBuf(p.n_obs, want_chi2) for p in own]
         return dict(n=n, src=list(probs), own=own, structs=structs, rbs=rbs,
                     parr=(C.POINTER(abi.vba_problem) * n)(*[C.pointer(s) for s in structs]),
                     rarr=(C.POINTER(abi.vba_result) * n)(*[C.pointer(r.s) for r in rbs]))
