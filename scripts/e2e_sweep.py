@@ -6,7 +6,7 @@ import bench
 from mc_slam_amd import backend
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-wins = bench.make_windows([("c3", 100 + i, False) for i in range(nd)], 16)
+wins = bench.make_windows([("c3", 100 + i, False, "caller") for i in range(nd)], 16)
 batch = [wins[i % nd] for i in range(n)]
 ba = backend.LocalBA(0)
 ba.upload(batch); ba.run()

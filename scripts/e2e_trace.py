@@ -36,7 +36,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
 import bench
 from mc_slam_amd import backend
 n, nd = 4096, 64
-wins = bench.make_windows([("c3", 100 + i, False) for i in range(nd)], 1)
+wins = bench.make_windows([("c3", 100 + i, False, "caller") for i in range(nd)], 1)
 batch = [wins[i % nd] for i in range(n)]
 ba = backend.LocalBA(0)
 ba.upload(batch); ba.run(); ba.run()

@@ -12,6 +12,9 @@ for n, v in seq.items():
     # one factorisation = a run of launches until the grid size pattern repeats; print the second factorisation seen (warm)
     grids = [g for _, g in v]
     per = next((p for p in range(1, len(grids)) if grids[p:2 * p] == grids[:p]), len(grids))
+    if n.startswith("k_chol_diag") and "k_chol_panel_ll" in seq:   # the diagonal kernel has one grid for every column: one more launch per factorisation than the panel kernel
+        gp = [g for _, g in seq["k_chol_panel_ll"]]
+        per = next((p for p in range(1, len(gp)) if gp[p:2 * p] == gp[:p]), len(gp)) + 1
     print(n, "launches per factorisation:", per)
     nf = len(v) // per
     for j in range(per):
