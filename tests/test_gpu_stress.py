@@ -30,7 +30,8 @@ def _random_window(i):
     n_pt = int(rng.integers(40, 700))
     n_obs = n_pt * per + int(rng.integers(0, n_pt))
     p = synth.make_window(variant, algo=algo, n_kf=n_kf, n_fixed=n_fixed, n_pt=n_pt, n_obs=n_obs, seed=1000 + i,
-                          outlier_frac=float(rng.choice([0.0, 0.05, 0.15])))
+                          outlier_frac=float(rng.choice([0.0, 0.05, 0.15])),
+                          landmark_order="caller" if (i // 4) % 2 else "random")   # half of the windows in the reference caller's landmark order
     if i % 3 == 0:
         p = _shuffled(p, i, drop_middle=(i % 2 == 0))
     return p
