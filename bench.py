@@ -49,9 +49,9 @@ def _gen_window(spec):
     wl, seed, uniform, order = spec
     if wl == "c3":
         return synth.config_c3(seed=seed, landmark_order=order) if uniform else synth.config_c3_ragged(seed=seed, landmark_order=order)
-    if wl in ("c4", "c3s"):   # inverse-depth windows: the order the caller hands landmarks over in matters to the record layout
-        return {"c4": synth.config_c4, "c3s": synth.config_c3s}[wl](seed=seed, landmark_order=order)
-    return {"c2": synth.config_c2, "gba": synth.config_gba, "c2s": synth.config_c2s}[wl](seed=seed)
+    if wl in ("c4", "c3s", "c2", "c2s"):   # local windows: the order the caller hands landmarks over in matters to the record layout
+        return {"c4": synth.config_c4, "c3s": synth.config_c3s, "c2": synth.config_c2, "c2s": synth.config_c2s}[wl](seed=seed, landmark_order=order)
+    return synth.config_gba(seed=seed)   # (the global BA walks pMap->GetAllMapPoints(): no keyframe grouping)
 
 
 def make_windows(specs, n_proc):
@@ -132,8 +132,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default: 4096 for c3, 2048 for c2, 16 for c4, 4 for gba, 4096 frames for pose)")
     ap.add_argument("--distinct", type=int, default=None, help="distinct seeded windows generated per rank and replicated to fill the batch (default: 256 for c3, 16 for c2, 2 for c4 / gba)")
     ap.add_argument("--landmark-order", default="caller", choices=["caller", "random"],
-                    help="inverse-depth workloads (c3, c3s, c4): 'caller' = landmarks in the order the reference's caller builds lLocalMapPoints in -- keyframe by "
-                         "keyframe over lLocalKeyFrames, every keyframe appending the map points no earlier one has listed (src/Optimizer.cpp:59-78), i.e. grouped by "
+                    help="local-window workloads (c3, c3s, c4, c2, c2s): 'caller' = landmarks in the order the reference's caller builds lLocalMapPoints in -- keyframe by "
+                         "keyframe over lLocalKeyFrames, every keyframe appending the map points no earlier one has listed (src/Optimizer.cpp:59-78, 3877-3894), i.e. grouped by "
                          "the first local keyframe that observes them; 'random' = the generator's order (uncorrelated with the keyframes; the workload of rounds 1-3a)")
     ap.add_argument("--uniform", action="store_true", help="c3: every window exactly 50 KF / 5 000 landmarks / 30 000 edges instead of sizes drawn around it")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose", "c3s", "c2s"],
@@ -493,7 +493,7 @@ def main():
                                     "gba": "GlobalBundleAdjustmentNavStatePRV, 300 KF / 30000 XYZ landmarks / 180000 EdgeNavStatePRPointXYZ "
                                            "+ IMU chain, LM optimize(10)"}[args.workload],
                        "landmark_order": (args.landmark_order + (" (grouped by first local keyframe, as src/Optimizer.cpp:59-78 builds lLocalMapPoints)" if args.landmark_order == "caller" else
-                                                                 " (uncorrelated with the keyframes)")) if args.workload in ("c3", "c3s", "c4") else None,
+                                                                 " (uncorrelated with the keyframes)")) if args.workload in ("c3", "c3s", "c4", "c2", "c2s") else None,
                        "windows_per_gpu_per_step": args.batch, "distinct_windows": len(wins),
                        "n_kf_range": rng(lambda w: w.n_kf), "n_pt_range": rng(lambda w: w.n_pt), "n_obs_range": rng(lambda w: w.n_obs),
                        "mean_n_kf": float(np.mean([w.n_kf for w in batch])), "mean_n_obs": float(np.mean([w.n_obs for w in batch])),

@@ -382,9 +382,9 @@ def make_window(variant=abi.VARIANT_PRV_IDP, n_kf=50, n_fixed=1, n_pt=5000, n_ob
 
 
 # the BASELINE.json configurations
-def config_c2(seed=2):
+def config_c2(seed=2, landmark_order="random"):
     """Vision-only LocalBundleAdjustment: 20 KF / 2k MapPoints / ~12k EdgeSE3ProjectXYZ, LM."""
-    return make_window(abi.VARIANT_SE3_XYZ, n_kf=20, n_fixed=2, n_pt=2000, n_obs=12000, seed=seed)
+    return make_window(abi.VARIANT_SE3_XYZ, n_kf=20, n_fixed=2, n_pt=2000, n_obs=12000, seed=seed, landmark_order=landmark_order)
 
 
 def config_c3(seed=3, n_kf=50, n_pt=5000, n_obs=30000, landmark_order="random"):
@@ -421,10 +421,10 @@ def config_c3s(seed=3, landmark_order="random"):
     return make_window(abi.VARIANT_PRV_IDP, n_kf=58, n_fixed=8, n_pt=5000, n_obs=30000, seed=seed, tracks="random", landmark_order=landmark_order)
 
 
-def config_c2s(seed=2):
+def config_c2s(seed=2, landmark_order="random"):
     """configs[1] with scattered co-visibility: the vision-only LocalBundleAdjustment(KeyFrame*, bool*, Map*, LocalMapping*) takes the
     co-visibility set of the current keyframe as its window (src/Optimizer.cpp:3861-3875), not a run of consecutive keyframes"""
-    return make_window(abi.VARIANT_SE3_XYZ, n_kf=20, n_fixed=2, n_pt=2000, n_obs=12000, seed=seed, tracks="random")
+    return make_window(abi.VARIANT_SE3_XYZ, n_kf=20, n_fixed=2, n_pt=2000, n_obs=12000, seed=seed, tracks="random", landmark_order=landmark_order)
 
 
 def config_c4(seed=4, landmark_order="random"):
