@@ -358,7 +358,10 @@ def main():
         # guide, + WRITE_SIZE), per class launch -- only when that profile was taken from THESE kernel sources and batch size
         try:
             import glob
-            tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")), key=os.path.getmtime)[-1]
+            # the profile taken from THESE kernel sources (a fresh checkout gives every file the same mtime: match by content, newest name last)
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_traffic.json")))
+            match = [f for f in cands if json.load(open(f)).get("csrc_sha") == csrc_sha() and json.load(open(f)).get("batch") == args.batch]
+            tj = (match or cands)[-1]
             tr = json.load(open(tj))
             if tr.get("batch") == args.batch and tr.get("csrc_sha") == csrc_sha() and tr.get("workload", "c3") == args.workload:
                 kmap = {"schur": ["k_schur_all", "k_schur_all_w", "k_schur_diag", "k_schur_off", "k_schur_ref"], "linearize": ["k_lin2", "k_lin2_imu", "k_lin_imu"],
