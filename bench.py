@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default: 4096 for c3, 2048 for c2, 16 for c4, 4 for gba, 4096 frames for pose)")
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU per step (default: 4096 for c3, 2048 for c2, 256 for c4, 4 for gba, 4096 frames for pose)")
     ap.add_argument("--distinct", type=int, default=None, help="distinct seeded windows generated per rank and replicated to fill the batch (default: 256 for c3, 16 for c2, 2 for c4 / gba)")
     ap.add_argument("--landmark-order", default="caller", choices=["caller", "random"],
                     help="local-window workloads (c3, c3s, c4, c2, c2s): 'caller' = landmarks in the order the reference's caller builds lLocalMapPoints in -- keyframe by "
@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--single-reps", type=int, default=21, help="vba_solve repetitions behind single_window_ms (0: skip)")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = {"c2": 2048, "c3": 4096, "c4": 16, "gba": 4, "pose": 4096, "c3s": 4096, "c2s": 2048}[args.workload]
+        args.batch = {"c2": 2048, "c3": 4096, "c4": 256, "gba": 4, "pose": 4096, "c3s": 4096, "c2s": 2048}[args.workload]
     if args.distinct is None:
         args.distinct = {"c2": 64, "c3": 256, "c4": 2, "gba": 2, "pose": 16, "c3s": 64, "c2s": 64}[args.workload]
 
@@ -439,7 +439,8 @@ def main():
             for w_ in wins:
                 q_ = w_.copy(); q_.solver = abi.SOLVER_PCG; pw.append(q_)
             bp = backend.LocalBA(local_rank)
-            bp.upload([pw[i % len(pw)] for i in range(args.batch)])
+            n_pcg = min(args.batch, 16)              # (CG runs ~1 400 iterations per solve: a smaller batch keeps the leg at a few seconds)
+            bp.upload([pw[i % len(pw)] for i in range(n_pcg)])
             bp.run()
             torch.cuda.synchronize(); t1 = time.perf_counter()
             for _ in range(2):
@@ -451,7 +452,7 @@ def main():
                         or np.abs(solp[i].kf_pose[:, :3] - sol[i].kf_pose[:, :3]).max() > 1e-6:
                     raise SystemExit("bench: the PCG path does not land where the LDL^T path lands (window %d)" % i)
             n_p = (6 if batch[0].variant == 0 else 15) * batch[0].n_kf_free
-            pcg = {"value": args.batch / tp, "unit": "windows/s", "ms_per_step": tp * 1e3, "vs_ldlt": (args.batch / tp) / value,
+            pcg = {"value": n_pcg / tp, "unit": "windows/s", "ms_per_step": tp * 1e3, "windows": n_pcg, "vs_ldlt": (n_pcg / tp) / value,
                    "cg_iterations_per_solve": float(np.mean([r.lin_iterations / max(1, sum(r.its_done)) for r in resp])), "n_p": n_p,
                    "what": "same batch, vba_problem.solver = VBA_SOLVER_PCG (block-Jacobi PCG on the reduced system, tolerance 1e-10); "
                            "iteration counts, chi2 (1e-4) and translations (1e-6 m) equal to the LDL^T run"}
