@@ -997,6 +997,9 @@ DEVI void rebuild_edge(const WinDesc& d, const double* Ra, const double* rec, do
     }
 }
 
+#ifndef VBA_SCHUR_UNR
+#define VBA_SCHUR_UNR 1
+#endif
 template <int LD, int LP>
 DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in = -1, int quad_in = 0) {
     constexpr int SS = (LD == 1) ? VBA_SLOT : VBA_SLOT3;
@@ -1025,6 +1028,39 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
     for (int i = 0; i < 36; i++) acc[i] = 0;
     const double* slots = B.slot + SS * (size_t)(d.obs0 + d.pt0);
     const int2* items = reinterpret_cast<const int2*>(B.items) + d.item0;
+#if VBA_SCHUR_UNR
+    if constexpr (LD == 1) {
+        // two items per lane and trip, their four records requested together: the gather is bound by the latency of its dependent
+        // fetches (occupancy experiment: 3 / 2 / 1 waves per SIMD = 107 / 128 / 179 ms), so a wave keeps twice as many in flight.
+        // Every lane still takes its items in the same order: the same sums.
+        int2 n0 = make_int2(0, 0), n1 = make_int2(0, 0);
+        if (ib + l16 < ie) n0 = items[ib + l16];
+        if (ib + l16 + LP < ie) n1 = items[ib + l16 + LP];
+        for (int it = ib + l16; it < ie; it += 2 * LP) {
+            const int2 i0 = n0;
+            const bool two = it + LP < ie;
+            const int2 i1 = two ? n1 : n0;
+            if (it + 2 * LP < ie) n0 = items[it + 2 * LP];
+            if (it + 3 * LP < ie) n1 = items[it + 3 * LP];
+            const double *qa0 = slots + SS * (size_t)i0.x, *qb0 = slots + SS * (size_t)i0.y;
+            const double *qa1 = slots + SS * (size_t)i1.x, *qb1 = slots + SS * (size_t)i1.y;
+            double UA0[6], UB0[6], UA1[6], UB1[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { UA0[i] = qa0[i]; UB0[i] = qb0[i]; UA1[i] = qa1[i]; UB1[i] = qb1[i]; }
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA0[i] * UB0[j];
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) acc[6 * i + j] -= UA1[i] * UB1[j];
+            }
+        }
+    } else
+#endif
+    {
     int2 nxt = make_int2(0, 0);
     int nxt_lm = 0;
     if (ib + l16 < ie) {
@@ -1062,6 +1098,7 @@ DEVI void schur_off_body(const Batch& B, int max_quads, double* blk4, int w_in =
             for (int j = 0; j < 6; j++)
 #pragma unroll
                 for (int l = 0; l < LD; l++) acc[6 * i + j] -= UA[LD * i + l] * UB[LD * j + l];
+    }
     }
     if (LD == 1) {
         // the items [im, ie) involve the landmark's reference keyframe and also carry a direct H_pp term: the edge of the
