@@ -83,3 +83,21 @@ def test_reader_rejects_damaged_files(tmp_path):
         open(f, "wb").write(data)
         assert l.vba_problem_load(f.encode(), C.byref(q)) != 0 and not q
     assert l.vba_problem_load(str(tmp_path / "missing").encode(), C.byref(q)) != 0
+
+
+def test_landmarks_in_the_callers_order_are_grouped_by_first_local_keyframe():
+    """synth.make_window(landmark_order="caller") hands landmarks over the way the reference's caller does (lLocalMapPoints is filled
+    keyframe by keyframe over lLocalKeyFrames, src/Optimizer.cpp:59-78): the first FREE keyframe (problem index) that observes a
+    landmark -- its own reference observation included -- never decreases along the list; same landmarks, same sizes as the random order"""
+    for variant, kw in ((abi.VARIANT_PRV_IDP, dict(n_kf=12, n_fixed=2, n_pt=300, n_obs=1500)), (abi.VARIANT_SE3_XYZ, dict(algo=abi.ALGO_LM, n_kf=10, n_fixed=2, n_pt=200, n_obs=1000))):
+        p = synth.make_window(variant, seed=77, landmark_order="caller", **kw)
+        q = synth.make_window(variant, seed=77, **kw)
+        assert (p.n_pt, p.n_obs, p.n_kf, p.n_kf_free) == (q.n_pt, q.n_obs, q.n_kf, q.n_kf_free)
+        first = []
+        for i in range(p.n_pt):
+            ks = list(p.obs_kf[p.pt_obs_begin[i]:p.pt_obs_begin[i + 1]])
+            if variant == abi.VARIANT_PRV_IDP:
+                ks.append(int(p.pt_ref_kf[i]))
+            first.append(min(k for k in ks if k < p.n_kf_free))
+        assert all(a <= b for a, b in zip(first, first[1:]))
+        assert sorted(np.diff(p.pt_obs_begin)) == sorted(np.diff(q.pt_obs_begin))     # the same tracks, another order
