@@ -315,6 +315,35 @@ def main():
             single = {"ms": ts[len(ts) // 2] * 1e3, "min_ms": ts[0] * 1e3, "reps": len(ts),
                       "what": "median wall time of vba_solve (H2D + structure + two-stage solve + D2H) on one fresh window, BASELINE configs[%d] seed %s" % (
                           2 if args.workload in ("c3", "c3s") else 1, "3" if args.workload == "c3" else str(specs[0][1]))}
+            single["kernel_launches"] = ba1.get_profile()["kernel_launches"]   # launches one vba_solve enqueued (vba_profile)
+            if args.workload == "c3":
+                # The reference's actual call: LocalMapping::Run -> Optimizer::LocalBAPRVIDP(pKF, lLocalKeyFrames, &mbAbortBA, ...) once per
+                # keyframe (src/LocalMapping.cpp:1035).  The C++ facade with that signature on a mock KeyFrame / MapPoint map holding this
+                # window: graph extraction (src/Optimizer.cpp:49-451), vba_solve_b behind it, erase + write-back under the map lock
+                # (:496-623) -- a fresh map per repetition (the call changes the map).
+                try:
+                    import facade_lib
+                    facade_lib.lib().fc_set_device(local_rank)
+                    fts = []
+                    for k in range(max(3, min(args.single_reps, 7)) + 2):
+                        fm = facade_lib.FacadeMap(w1)
+                        flag = C.c_bool(False)
+                        fm.local_ba_prvidp_flag(flag)
+                        fts.append(fm.last_timing())
+                        r_f = facade_lib.lib().fc_last_result().contents
+                        if r_f.status != 0:
+                            raise SystemExit("bench: the facade call did not finish (status %d)" % r_f.status)
+                        fm.close()
+                    fts = fts[2:]
+                    med = lambda key: float(sorted(t[key] for t in fts)[len(fts) // 2])
+                    single["facade"] = {"total_ms": med("total_ms"), "extract_ms": med("extract_ms"), "solve_ms": med("solve_ms"),
+                                        "writeback_ms": med("writeback_ms"), "overhead_us": (med("total_ms") - med("solve_ms")) * 1e3,
+                                        "reps": len(fts),
+                                        "what": "median wall time of Optimizer::LocalBAPRVIDP (mc_slam_amd/host) on a mock map holding the same window: "
+                                                "extraction + vba_solve_b + erase / write-back; the map's float32 storage makes its window "
+                                                "differ from `ms`'s in rounding only"}
+                except OSError as ex:
+                    single["facade"] = {"error": "libvba_facade.so not built: %s" % ex}
             if not args.no_cpu_baseline:
                 import oracle_lib
                 # ONE baseline for the whole line: both elimination orders of the oracle are timed on this window (best of 3
@@ -340,7 +369,7 @@ def main():
         ba.run()
         pf = ba.get_profile()
         ba.set_profile(False)
-        classes = {k: v for k, v in pf.items() if k != "total_ms"}
+        classes = {k: v for k, v in pf.items() if isinstance(v, dict)}
         dom = max(classes, key=lambda k: classes[k]["ms"])
         its = [sum(r.its_done) for r in res]
         alg_bytes = classes[dom]["bytes"]   # algorithmic bytes of the class over the whole run (vba_profile)
@@ -461,8 +490,11 @@ def main():
         if batch[0].variant != 0:   # visual-inertial windows: tile products of the symbolic factorisation under both elimination orders
             import ctypes as C
             tp = np.zeros((len(wins), 4), dtype=np.int64)
+            bh = backend.LocalBA(local_rank, hooks=True)   # (a diagnostic of the symbolic factorisation: the hooks flavour of the library)
+            bh.upload(wins)
             for i in range(len(wins)):
-                ba.lib.vba_debug_tile_products(ba.h, i, tp[i].ctypes.data_as(C.c_void_p))
+                bh.lib.vba_debug_tile_products(bh.h, i, tp[i].ctypes.data_as(C.c_void_p))
+            bh.close()
             if (tp[:, 0] >= 0).all():
                 tile_products = {"vbias_first_mean": float(tp[:, 0].mean()), "keyframe_order_mean": float(tp[:, 1].mean()),
                                  "windows_in_keyframe_order": int(tp[:, 2].sum()), "chosen_mean": float(tp[:, 3].mean())}
@@ -504,7 +536,7 @@ def main():
                        "its_done_histogram": its_hist, "tile_products_per_factorisation": tile_products,
                        "parallelism": "independent windows sharded %d per GPU, no data-path collective" % args.batch,
                        "value_is": "kernel-only (windows resident in HBM, no PCIe in the timed region); value_end_to_end includes H2D + D2H",
-                       "host_threads": int(ba.lib.vba_debug_host_threads()), "cpu_affinity": {"cores": len(my_cpus), "first": my_cpus[0], "last": my_cpus[-1]},
+                       "host_threads": int(ba.lib.vba_host_threads()), "cpu_affinity": {"cores": len(my_cpus), "first": my_cpus[0], "last": my_cpus[-1]},
                        "mean_outer_iterations": float(np.mean(its))},
             "end_to_end": e2e, "single_window": single, "pcg": pcg,
             "roofline": roofline, "cpu_baseline": cpu, "verified": verified,

@@ -123,6 +123,7 @@ typedef struct vba_profile {
     double total_ms;             /* first launch -> last launch of the run */
     double factor_flops;         /* FP64 flop the factorisation class executed on MFMA: 2*32^3 per tile product of the
                                     symbolic tile lists, per solve (structurally zero tiles are never touched) */
+    int64_t kernel_launches;     /* kernel launches the last vba_batch_run / vba_solve enqueued (filled with or without profiling) */
 } vba_profile;
 
 /* One handle per host thread / GPU; owns device buffers and a stream.  Errors: nonzero return, message
@@ -151,6 +152,15 @@ int vba_batch_download(void *handle, int32_t n_windows, vba_problem *const *inou
  * host packing, the PCIe transfers and the structure build of one chunk overlap the solve of another. */
 int vba_batch_solve(void *handle, int32_t n_windows, vba_problem *const *inout, vba_result *const *out,
                     const volatile int *stop_flag);
+
+/* The same three entry points for a caller whose flag is a C++ `bool` (one byte): the reference hands `bool* pbStopFlag` =
+ * &LocalMapping::mbAbortBA down to g2o (include/Optimizer.h:22-24; written by the Tracking thread, src/LocalMapping.cpp:1769-1772).
+ * The flag is read at its own width, so `Optimizer::LocalBAPRVIDP` passes its argument straight through -- no mirror word, no
+ * helper thread.  (sizeof(bool) == 1 on every ABI the library is built for; the facade static_asserts it.) */
+int vba_solve_b(void *handle, vba_problem *inout, vba_result *out, const volatile unsigned char *stop_flag);
+int vba_batch_run_b(void *handle, const volatile unsigned char *stop_flag);
+int vba_batch_solve_b(void *handle, int32_t n_windows, vba_problem *const *inout, vba_result *const *out,
+                      const volatile unsigned char *stop_flag);
 
 /* On-device IMU preintegration: IMUPreintegrator::update (src/IMU/IMUPreintegrator.cpp:63-112) applied
  * over the samples of n_edges keyframe intervals, the way KeyFrame::ComputePreInt feeds it (src/KeyFrame.cpp:195-252:
@@ -217,6 +227,10 @@ int vba_pose_optimize(void *handle, int32_t n_frames, vba_frame_problem *const *
 int vba_problem_save(const char *path, const vba_problem *p);
 int vba_problem_load(const char *path, vba_problem **out);
 void vba_problem_free(vba_problem *p);
+
+/* Host threads one handle of this process uses for packing, the host half of the structure build and the scatter of the results:
+ * this rank's share of the cores it may run on (VBA_UPLOAD_THREADS, else cores / LOCAL_WORLD_SIZE, at most 16). */
+int vba_host_threads(void);
 
 int vba_set_profile(void *handle, int32_t enable);
 int vba_get_profile(void *handle, vba_profile *out);

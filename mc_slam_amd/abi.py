@@ -66,6 +66,7 @@ class vba_profile(C.Structure):
     _fields_ = [
         ("ms", C.c_double * PROF_N), ("launches", C.c_int64 * PROF_N),
         ("bytes", C.c_double * PROF_N), ("total_ms", C.c_double), ("factor_flops", C.c_double),
+        ("kernel_launches", C.c_int64),
     ]
 
 

@@ -11,20 +11,25 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VBA_LIB", os.path.join(_HERE, "csrc", "libvislam_ba.so"))   # VBA_LIB: A/B builds in experiments
+# the same library built with -DVBA_TEST_HOOKS (vba_debug_*: test / diagnostic hooks that the shipped library does not export)
+HOOKS_LIB_PATH = os.environ.get("VBA_LIB", os.path.join(_HERE, "csrc", "libvislam_ba_hooks.so"))
 _lib = None
+_libs = {}
 
 EXPORTS = ["vba_create", "vba_destroy", "vba_last_error", "vba_solve", "vba_batch_upload", "vba_batch_run",
-           "vba_batch_download", "vba_batch_solve", "vba_preintegrate", "vba_pose_optimize", "vba_problem_save", "vba_problem_load", "vba_problem_free", "vba_set_profile", "vba_get_profile"]
+           "vba_batch_download", "vba_batch_solve", "vba_solve_b", "vba_batch_run_b", "vba_batch_solve_b", "vba_preintegrate", "vba_pose_optimize", "vba_problem_save", "vba_problem_load", "vba_problem_free", "vba_set_profile", "vba_get_profile", "vba_host_threads"]
 
 
-def load_library():
-    """dlopen the in-tree HIP library and declare every entry point of include/vislam_ba.h."""
+def load_library(hooks=False):
+    """dlopen the in-tree HIP library and declare every entry point of include/vislam_ba.h.  hooks=True: the flavour with the
+    test / diagnostic hooks (a second, independent instance of the library)."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("HIP backend not built: %s is missing (run __graft_entry__.build())" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    path = HOOKS_LIB_PATH if hooks else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError("HIP backend not built: %s is missing (run __graft_entry__.build())" % path)
+    lib = C.CDLL(path)
     PP = C.POINTER(C.POINTER(abi.vba_problem))
     PR = C.POINTER(C.POINTER(abi.vba_result))
     lib.vba_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -36,6 +41,9 @@ def load_library():
     lib.vba_batch_run.argtypes = [C.c_void_p, C.c_void_p]
     lib.vba_batch_download.argtypes = [C.c_void_p, C.c_int32, PP, PR]
     lib.vba_batch_solve.argtypes = [C.c_void_p, C.c_int32, PP, PR, C.c_void_p]
+    lib.vba_solve_b.argtypes = [C.c_void_p, C.POINTER(abi.vba_problem), C.POINTER(abi.vba_result), C.c_void_p]
+    lib.vba_batch_run_b.argtypes = [C.c_void_p, C.c_void_p]
+    lib.vba_batch_solve_b.argtypes = [C.c_void_p, C.c_int32, PP, PR, C.c_void_p]
     _pd, _pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     lib.vba_preintegrate.argtypes = [C.c_void_p, C.c_int32, _pi, _pd, _pd, _pd, C.c_double, C.c_double, _pd, _pd, _pd]
     lib.vba_pose_optimize.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(abi.vba_frame_problem)), C.POINTER(C.POINTER(abi.vba_frame_result))]
@@ -44,7 +52,9 @@ def load_library():
     for n in EXPORTS:
         if n != "vba_last_error":
             getattr(lib, n).restype = C.c_int
-    _lib = lib
+    _libs[path] = lib
+    if not hooks:
+        _lib = lib
     return lib
 
 
@@ -52,8 +62,8 @@ class LocalBA:
     """One backend handle = one GPU + one stream (vba_create).  Mirrors how the reference owns one
     function-local g2o::SparseOptimizer per call (src/Optimizer.cpp:130), but keeps device buffers alive."""
 
-    def __init__(self, device=0):
-        self.lib = load_library()
+    def __init__(self, device=0, hooks=False):
+        self.lib = load_library(hooks)
         self.h = C.c_void_p()
         rc = self.lib.vba_create(device, C.byref(self.h))
         if rc != 0:
@@ -196,4 +206,5 @@ class LocalBA:
         d = {abi.PROF_NAMES[i]: dict(ms=pf.ms[i], launches=pf.launches[i], bytes=pf.bytes[i]) for i in range(7)}
         d["factor"]["flops"] = pf.factor_flops
         d["total_ms"] = pf.total_ms
+        d["kernel_launches"] = int(pf.kernel_launches)
         return d

@@ -10,7 +10,6 @@
 #define VBA_EREC 18        // doubles per edge record, XYZ variants (144 B): Bi (2x6), g = -Bi^T r
 #define VBA_EREC1 8        // doubles per edge record, inverse-depth variant (64 B): P_c (3), sqrt(rho' w) (1), r (2); the
                            // readers rebuild Bi = [A | B_rot] from it and the observer's rotation (rebuild_edge)
-#define VBA_N0REC 16       // doubles per landmark: N0 = R0 hat(b0) (9), so that Br = [-A | A N0] is rebuilt by the reader
 #define VBA_PREC 32        // doubles per point record  (256 B)
 #define VBA_SLOT 8         // doubles per slot record   (64 B = one line), inverse-depth landmarks
 #define VBA_SLOT3 18       // doubles per slot record, XYZ landmarks (144 B): W = Bi^T A (6x3), independent of the damping
@@ -48,6 +47,9 @@ struct WinDesc {
     int tl_kb0;     // offset of this window's column-entry table of the left-looking factorisation (pan entries + nb + 1)
     int tl_k0;      // offset into its k lists
     int order;      // elimination order: 0 = V/Bias blocks first, 1 = keyframe by keyframe
+    int nc;         // chain columns: block columns [0, nc) are factored by k_chol_chain, the per-column kernels start at nc
+    int ct0;        // offset (records of four ints) of the window's chain-column table (Structure::chain_tab)
+    int cu0, n_cu;  // few-window regime: the window's tiles that collect updates from chain columns (k_chol_chain_upd)
     int vp_pr0, vp_prs, vp_vb0, vp_vbs;  // position of dof r of free keyframe a: r < 6 ? pr0 + prs a + r : vb0 + vbs a + r - 6
     long long S0;   // offset (doubles) into S
     long long mask0; // offset (64-bit words) of the window's landmark masks (n_pt x mwords)
@@ -284,6 +286,15 @@ DEVI double wave64_sum(double v) {  // every lane ends up with the wave's sum: r
 DEVI void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// The same for code that ONE wave runs on its own (LDS written by some lanes, read by others of the same wave): the wave's LDS
+// operations complete in order, so draining them is all it takes -- no s_barrier, hence usable where other waves of the workgroup
+// have already left.
+DEVI void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 

@@ -40,6 +40,14 @@ struct Structure {
     int order = 0;                     // elimination order of the reduced system (see below)
     long long prod_order[2] = {-1, -1}; // tile products of the symbolic factorisation under order 0 / order 1 (-1: not evaluated)
     std::vector<int> kl_begin, klist;  // left-looking factorisation: per column entry the steps k < J that update it
+    // Chain columns: the leading block columns J < nc whose row of L has no tile left of (J, J-1) -- the V/Bias blocks of the IMU chain
+    // under the V/Bias-first order.  One launch walks them per window (k_chol_chain) instead of one launch per column.  Few-window
+    // regime: `cu` lists the tiles (I,J), J >= nc, that collect updates from chain columns -- (I << 16 | J, first and end position of the chain columns in its k list, 0) per tile
+    // (k_chol_chain_upd brings them up to date in one launch before the per-column steps take over).
+    int nc = 0;
+    std::vector<int> cu;
+    std::vector<int> chain_tab;        // per chain column J: (mask lo, mask hi, rides, 0) -- bit q of the mask: tile (nc + q, J) is in the factor;
+                                       // rides: tile (J+1, J) is in the factor and J+1 is a chain column
 };
 
 inline int vpos_host(int order, int pdim, int nf, int a, int r) {
@@ -259,6 +267,47 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
         }
     }
     st.kl_begin.push_back((int)st.klist.size());
+    {   // chain columns (see Structure::nc): T holds L's pattern
+        static const int chain_min = getenv("VBA_CHAIN_MIN") ? atoi(getenv("VBA_CHAIN_MIN")) : 4;
+        int nc = 0;
+        for (int J = 0; J < nb; J++) {
+            bool ok = true;
+            for (int k = 0; k + 1 < J && ok; k++) ok = !T[(size_t)J * nb + k];
+            if (!ok) break;
+            nc = J + 1;
+        }
+        if (nc == nb && nc > 0) nc--;   // (the last column has nothing to its right: leave it to the per-column kernels)
+        st.nc = (chain_min > 0 && nc >= chain_min) ? nc : 0;
+        if (nb - nc > 64) st.nc = 0;      // (the row masks of chain_tab are 64 bits wide)
+        st.chain_tab.clear();
+        for (int J = 0; J < st.nc; J++) {
+            unsigned long long mask = 0;
+            int ride = 0;
+            for (int i = st.pan_begin[J]; i < st.pan_begin[J + 1]; i++) {
+                const int I = st.pan[i];
+                if (I == J + 1 && J + 1 < st.nc) ride = 1;
+                else if (I >= st.nc) mask |= 1ull << (I - st.nc);
+            }
+            st.chain_tab.push_back((int)(unsigned)(mask & 0xffffffffull));
+            st.chain_tab.push_back((int)(unsigned)(mask >> 32));
+            st.chain_tab.push_back(ride);
+            st.chain_tab.push_back(0);
+        }
+        st.cu.clear();
+        for (int J = st.nc; J < nb && st.nc > 0; J++)
+            for (int e = -1; e < st.pan_begin[J + 1] - st.pan_begin[J]; e++) {
+                const int I = (e < 0) ? J : st.pan[st.pan_begin[J] + e];
+                const int ent = st.pan_begin[J] + J + 1 + e;
+                if (st.kl_begin[ent + 1] > st.kl_begin[ent] && st.klist[st.kl_begin[ent]] < st.nc) {
+                    int ke = st.kl_begin[ent + 1];
+                    while (ke > st.kl_begin[ent] && st.klist[ke - 1] >= st.nc) ke--;   // (ascending list: the chain columns are its head)
+                    st.cu.push_back((I << 16) | J);
+                    st.cu.push_back(st.kl_begin[ent]);
+                    st.cu.push_back(ke);
+                    st.cu.push_back(0);
+                }
+            }
+    }
     // which sub-blocks of a keyframe pair's block can land in a tile the factorisation reads (T now holds L's pattern)
     st.pair_mask.assign(npairs, 0);
     for (int pi = 0; pi < npairs; pi++) {

@@ -24,7 +24,7 @@ struct Batch {
     const double *obs_uv, *obs_w;
     unsigned char* lvl;
     double *chi2_e, *depth_e, *chi2_f;  // chi2_f: chi2 recomputed at the final estimates (LM: chi2_e may be stale)
-    double *erec, *prec, *slot, *n0rec;
+    double *erec, *prec, *slot;
     const int* slot_perm;         // [n_obs] record position of every observation edge (keyframe-major for inverse-depth windows)
     const int* pt_perm;           // [n_pt] record position of every landmark (grouped by reference keyframe)
     const unsigned char* kf_fix;  // [n_kf] per-vertex setFixed() of listed-free keyframes: bit0 PR, bit1 V, bit2 Bias
@@ -59,7 +59,10 @@ struct Batch {
     // tile structure of the factor (symbolic factorisation on 32x32 tiles, built at upload)
     const int *tl_step_begin, *tl_pairs, *tl_pan_begin, *tl_pan;
     const int *tl_kl_begin, *tl_kl;  // left-looking factorisation: per column entry (J,J),(I,J).. the steps k < J that update it
+    const int* tl_ct;                // per chain column: row mask (two words), rides, 0 (Structure::chain_tab)
+    const int* tl_cu;                // few-window regime: tiles behind the chain columns that collect updates from them (I << 16 | J, first, end of the chain columns in its k list, 0)
     double *dvec, *winv;             // D of the factor (nS per window); L_JJ^-T D_J^-1 of the current step (32x32 per window)
+    int w_total, w_stride;           // behind those: W_J of every chain column, w_stride tiles per window (batch-wide window index d.win)
     double* part;
     const volatile int* stop_word;   // DEVICE copy of the caller's stop flag (word 1023 of the group's mirror words), refreshed by k_poll_stop
                                      // before every control launch: thousands of windows reading the pinned host word cost 0.5 ms per launch
@@ -376,7 +379,9 @@ DEVI void lin_imu_res(const Batch& B, const WinDesc& d, int k, int mode) {
     }
 }
 
-// H = J^T (Omega J) + the bias edge's -I / +I terms, rhs = -J^T Omega e, of one keyframe pair (one wave; sm: 672 doubles)
+// H = J^T (Omega J) + the bias edge's -I / +I terms, rhs = -J^T Omega e, of one keyframe pair.  ONE WAVE by contract (sm: 672 doubles):
+// the phases are ordered with wave_lds_sync(), not with a workgroup barrier -- k_lin2_imu calls it from wave 0 of a 256-thread
+// workgroup whose other waves have left (a barrier behind a divergent exit is undefined in the HIP model)
 DEVI void lin_imu_hess(const Batch& B, const WinDesc& d, int k, double* sm) {
     const size_t gk = d.imu0 + k;
     const int i = B.imu_i[gk], j = B.imu_j[gk];
@@ -396,7 +401,7 @@ DEVI void lin_imu_hess(const Batch& B, const WinDesc& d, int k, double* sm) {
     if (t < 54) T[t] = jr[t * js];
     if (t < 47) er[t] = jr[(54 + t) * js];
     for (int q = t; q < 81; q += 64) Om[q] = on ? rw * info[q] : 0.0;
-    __syncthreads();
+    wave_lds_sync();
     if (t < 9) {   // Jacobians (g2otypes.cpp:296-359); local columns: PR_i 0..5, V_i 6..8, B_i 9..14, PR_j 15..20, V_j 21..23
         const int a = t / 3, b = t % 3, q = t;
         const double dT = meas[0];
@@ -417,7 +422,7 @@ DEVI void lin_imu_hess(const Batch& B, const WinDesc& d, int k, double* sm) {
         J[(3 + a) * 30 + 18 + b] = JrI[q];            // d rphi / d phi_j
         J[(6 + a) * 30 + 21 + b] = RiT[q];            // d rV / d V_j
     }
-    __syncthreads();
+    wave_lds_sync();
     for (int q = t; q < 270; q += 64) {  // T = Om J
         const int a = q / 30, col = q % 30;
         double s = 0;
@@ -425,7 +430,7 @@ DEVI void lin_imu_hess(const Batch& B, const WinDesc& d, int k, double* sm) {
         for (int b = 0; b < 9; b++) s += Om[9 * a + b] * J[b * 30 + col];
         T[q] = s;
     }
-    __syncthreads();
+    wave_lds_sync();
     double* H = B.imuH + VBA_IMUH * gk;
     for (int q = t; q < 900; q += 64) {  // H = J^T T  (+ bias edge: -I/+I Jacobians on B_i (9..14), B_j (24..29))
         const int r = q / 30, col = q % 30;
@@ -825,8 +830,8 @@ __global__ void __launch_bounds__(256) k_lin2_imu(Batch B, int nblk_lin, int mod
     if (k >= d.n_imu) return;
     if (threadIdx.x == 0) lin_imu_res(B, d, k, (mode == LIN_FULL) ? LIN_FULL : LIN_ERR);
     if (mode != LIN_FULL) return;
-    __threadfence_block();
-    __syncthreads();
+    __threadfence_block();              // lane 0's record (global memory) before the other lanes of this wave read it
+    __builtin_amdgcn_wave_barrier();
     lin_imu_hess(B, d, k, lsm);
 }
 
@@ -1410,7 +1415,7 @@ __global__ void __launch_bounds__(64) k_chol_step(Batch B, int k) {
     const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
     if (!win_on(d, c)) return;
-    if (k >= d.nb) return;
+    if (k >= d.nb || k < d.nc) return;   // (columns [0, nc): k_chol_chain)
     const int* sb = B.tl_step_begin + d.tl_step0;
     const int npair = sb[k + 1] - sb[k];
     const int bx = blockIdx.x;
@@ -1599,7 +1604,10 @@ struct ElimUpd {   // columns C2..31 of pivot CC
 // uLow / uHigh are column CC replicated into every 16-lane row; those of the NEXT pivot are requested as soon as its column is
 // final (after the first FMAC) so that the crossbar round trip hides behind the remaining FMACs of this one.  (A fully hand-
 // scheduled variant -- the reciprocal, l, z and the captures of the next pivot slotted between the FMACs -- measured the same.)
-template <int CC, bool WRITE_X>
+// WRITE_X: 0 nothing; 1 Xrow[CC] = l; 2 (vba_chain.h) Xrow[pc] = l and Xrow[pc + ELIM_U_OFF] = u = l d with pc = (CC & 3) * 8 + (CC >> 2): the
+// eight k-steps a lane needs as an MFMA operand lie side by side, and the second operand (rows times D) needs no multiplication
+#define ELIM_U_OFF (32 * 34)
+template <int CC, int WRITE_X>
 struct ElimStep {
     static DEVI void run(double (&t)[32], double& rr, double& dout, double& zout, double uLow, double uHigh, int aLow, int aHigh, double* Xrow) {
         if constexpr (CC < 32) {
@@ -1613,7 +1621,8 @@ struct ElimStep {
             dout = wl64<CC>(dout, piv);
             zout = wl64<CC>(zout, zc);
             rr -= l * zc;
-            if constexpr (WRITE_X) Xrow[CC] = l;         // lanes 32..63: row r of L_Tk for the MFMA update (lanes 0..31: a scratch row)
+            if constexpr (WRITE_X == 1) Xrow[CC] = l;    // lanes 32..63: row r of L_Tk for the MFMA update (lanes 0..31: a scratch row)
+            if constexpr (WRITE_X == 2) { Xrow[(CC & 3) * 8 + (CC >> 2)] = l; Xrow[(CC & 3) * 8 + (CC >> 2) + ELIM_U_OFF] = u; }
             t[CC] = l;
             double nLow = 0.0, nHigh = 0.0;
             if constexpr (CC < 31) {
@@ -1627,7 +1636,7 @@ struct ElimStep {
         }
     }
 };
-template <bool WRITE_X>
+template <int WRITE_X>
 DEVI void elim_tile(double (&t)[32], double& rr, double& dout, double& zout, int aLow, int aHigh, double* Xrow) {
     ElimStep<0, WRITE_X>::run(t, rr, dout, zout, bperm64(t[0], aLow), bperm64(t[0], aHigh), aLow, aHigh, Xrow);
 }
@@ -1654,7 +1663,7 @@ __global__ void __launch_bounds__(128) k_chol_step4(Batch B, int k, StepOne so) 
     } else {
         const WinDesc& d = B.desc[w];
         if (!win_on(d, c)) return;
-        if (k >= d.nb) return;
+        if (k >= d.nb || k < d.nc) return;
         const int* sb = B.tl_step_begin + d.tl_step0;
         npair = sb[k + 1] - sb[k];
         pair_off = d.tl_pair0 + sb[k];
@@ -1719,7 +1728,7 @@ __global__ void __launch_bounds__(128) k_chol_step4(Batch B, int k, StepOne so) 
         { double sink = t[0] + t[31] + rr; asm volatile("" :: "v"(sink)); }   // the loads have landed
 #endif
         STAMP(1)
-        elim_tile<true>(t, rr, dout, zout, 4 * l15, 4 * (16 + l15), (hi ? (wave ? XJ : XI) : XD) + r * 34);
+        elim_tile<1>(t, rr, dout, zout, 4 * l15, 4 * (16 + l15), (hi ? (wave ? XJ : XI) : XD) + r * 34);
         STAMP(2)
         if (wave == 0) {
             if (bx == 0 && !hi) {                    // the factor's diagonal tile (unit L below the diagonal, D on it) and z_k = L_kk^-1 r_k
@@ -1727,10 +1736,11 @@ __global__ void __launch_bounds__(128) k_chol_step4(Batch B, int k, StepOne so) 
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     double4 v;
-                    v.x = (4 * q == r) ? dout : t[4 * q];
-                    v.y = (4 * q + 1 == r) ? dout : t[4 * q + 1];
-                    v.z = (4 * q + 2 == r) ? dout : t[4 * q + 2];
-                    v.w = (4 * q + 3 == r) ? dout : t[4 * q + 3];
+                    // (what the elimination leaves above the diagonal is arbitrary: zeros go into the factor)
+                    v.x = (4 * q == r) ? dout : ((4 * q < r) ? t[4 * q] : 0.0);
+                    v.y = (4 * q + 1 == r) ? dout : ((4 * q + 1 < r) ? t[4 * q + 1] : 0.0);
+                    v.z = (4 * q + 2 == r) ? dout : ((4 * q + 2 < r) ? t[4 * q + 2] : 0.0);
+                    v.w = (4 * q + 3 == r) ? dout : ((4 * q + 3 < r) ? t[4 * q + 3] : 0.0);
                     lrow[q] = v;
                 }
                 yv[dk + r] = zout;
@@ -1755,18 +1765,21 @@ __global__ void __launch_bounds__(128) k_chol_step4(Batch B, int k, StepOne so) 
     lds_barrier();
     const double* XJp = diagp ? XI : XJ;
 #pragma unroll
+    for (int ks = 0; ks < 8; ks++) {    // (the wave's two products side by side: independent accumulators)
+        const double av = -XI[(16 * wave + l15) * 34 + 4 * ks + l4];
+        const double dvk = dg[4 * ks + l4];
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) {
+            const double bv = XJp[(16 * tj + l15) * 34 + 4 * ks + l4] * dvk;
+            cacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, cacc[tj], 0, 0, 0);
+        }
+    }
+#pragma unroll
     for (int tj = 0; tj < 2; tj++) {
         if (diagp && tj > wave) continue;
         double* C = S + ((size_t)I * 32 + 16 * wave) * n + (size_t)J * 32 + 16 * tj;
-        d4_t acc = cacc[tj];
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            const double av = -XI[(16 * wave + l15) * 34 + 4 * ks + l4];
-            const double bv = XJp[(16 * tj + l15) * 34 + 4 * ks + l4] * dg[4 * ks + l4];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = acc[i];
+        for (int i = 0; i < 4; i++) C[(size_t)(l4 + 4 * i) * n + l15] = cacc[tj][i];
     }
 #ifdef VBA_STAMPS
     STAMP(4)
@@ -1834,18 +1847,19 @@ DEVI void ll_diag_accumulate(const Batch& B, const WinDesc& d, int J, int kb, in
             p0 += ((ks & 1) ? a0.y : a0.x) * yk[ks];
             p1 += ((ks & 1) ? a1.y : a1.x) * yk[ks];
         }
+        // (k-step outermost: four independent accumulators back to back -- a chain of dependent FP64 MFMAs issues at about two
+        // thirds of the rate; every accumulator still sums its k-steps in ascending order)
 #pragma unroll
-        for (int ti = 0; ti < 2; ti++)
+        for (int ks = 0; ks < 8; ks++)
 #pragma unroll
-            for (int tj = 0; tj < 2; tj++) {
+            for (int ti = 0; ti < 2; ti++)
 #pragma unroll
-                for (int ks = 0; ks < 8; ks++) {
+                for (int tj = 0; tj < 2; tj++) {
                     const double2 pi = x[ti * 4 + (ks >> 1)], pj = x[tj * 4 + (ks >> 1)];
                     const double av = -((ks & 1) ? pi.y : pi.x);
                     const double bv = ((ks & 1) ? pj.y : pj.x) * dv[ks];
                     acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[ti][tj], 0, 0, 0);
                 }
-            }
     }
     p0 += __shfl_xor(p0, 16, 64); p0 += __shfl_xor(p0, 32, 64);
     p1 += __shfl_xor(p1, 16, 64); p1 += __shfl_xor(p1, 32, 64);
@@ -1888,7 +1902,7 @@ DEVI void ll_diag2(const Batch& B, const WinDesc& d, WinCtrl& c, int w, int J, d
     const double rh = (B.vec + d.vec0)[dk + r] - __shfl(sdot, r, 64);   // b_J - sum_k L_Jk y_k
     double rr = hi ? 0.0 : rh, dout = 1.0, zout = 0.0;
     lds_barrier();                                    // every lane has its row: CT is free
-    elim_tile<false>(t, rr, dout, zout, 4 * l15, 4 * (16 + l15), nullptr);
+    elim_tile<0>(t, rr, dout, zout, 4 * l15, 4 * (16 + l15), nullptr);
     {
         const bool badl = !hi && (dout == 0.0 || !isfinite(dout));
         if (__ballot(badl) != 0ull && lane == 0) c.chol_fail = 1;
@@ -1924,7 +1938,7 @@ __global__ void __launch_bounds__(64) k_chol_diag_ll2(Batch B, int J) {
     const WinDesc& d = B.desc[w];
     WinCtrl& c = B.ctrl[w];
     if (!win_on(d, c)) return;
-    if (J >= d.nb) return;
+    if (J >= d.nb || J < d.nc) return;
     ll_diag2(B, d, c, w, J, CT, WT);
 }
 
@@ -1944,34 +1958,50 @@ DEVI void ll_panel_init(const double* S, int n, int I, int J, int l15, int l4, d
 }
 DEVI void ll_panel_mfma(const double (&av)[2][8], const double2 (&xi)[8], d4_t (&acc)[2][2]) {
 #pragma unroll
-    for (int tj = 0; tj < 2; tj++)
+    for (int ks = 0; ks < 8; ks++)      // (k-step outermost: the four accumulators are independent of one another)
 #pragma unroll
-        for (int ti = 0; ti < 2; ti++) {
+        for (int tj = 0; tj < 2; tj++)
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
+            for (int ti = 0; ti < 2; ti++) {
                 const double2 pi = xi[ti * 4 + (ks >> 1)];
                 const double bv = -((ks & 1) ? pi.y : pi.x);
                 acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tj][ks], bv, acc[tj][ti], 0, 0, 0);
             }
-        }
 }
 // L_IJ^T = W_J^T C_IJ^T: A operand = the packed W tile, B operand = the accumulators; the result registers are the packed tile
+DEVI void ll_panel_finish_keep(const double2 (&xw)[8], const d4_t (&acc)[2][2], double2* out, double2 (&xo)[8]);
 DEVI void ll_panel_finish(const double2 (&xw)[8], const d4_t (&acc)[2][2], double2* out) {
+    double2 xo[8];
+    ll_panel_finish_keep(xw, acc, out, xo);
+}
+
+// the same, also handing the tile back as the operand pieces of a later product (k_chol_chain_panel)
+DEVI void ll_panel_finish_keep(const double2 (&xw)[8], const d4_t (&acc)[2][2], double2* out, double2 (&xo)[8]) {
+    d4_t o[2][2];
+#pragma unroll
+    for (int tk = 0; tk < 2; tk++)
+#pragma unroll
+        for (int ti = 0; ti < 2; ti++) o[tk][ti] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++)      // (k-step outermost: four independent accumulators)
+#pragma unroll
+        for (int tk = 0; tk < 2; tk++)
+#pragma unroll
+            for (int ti = 0; ti < 2; ti++) {
+                const double2 pw = xw[tk * 4 + (ks >> 1)];
+                const double av = (ks & 1) ? pw.y : pw.x;
+                const double bv = acc[ks >> 2][ti][ks & 3];
+                o[tk][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, o[tk][ti], 0, 0, 0);
+            }
 #pragma unroll
     for (int tk = 0; tk < 2; tk++)
 #pragma unroll
         for (int ti = 0; ti < 2; ti++) {
-            d4_t o = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-                const double2 pw = xw[tk * 4 + (ks >> 1)];
-                const double av = (ks & 1) ? pw.y : pw.x;
-                const double bv = acc[ks >> 2][ti][ks & 3];
-                o = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, o, 0, 0, 0);
-            }
             // o[i] = L[16 ti + l15][16 tk + 4 i + l4]: k-steps 4 tk + i of row half ti
-            out[64 * (ti * 4 + 2 * tk)] = make_double2(o[0], o[1]);
-            out[64 * (ti * 4 + 2 * tk + 1)] = make_double2(o[2], o[3]);
+            xo[ti * 4 + 2 * tk] = make_double2(o[tk][ti][0], o[tk][ti][1]);
+            xo[ti * 4 + 2 * tk + 1] = make_double2(o[tk][ti][2], o[tk][ti][3]);
+            out[64 * (ti * 4 + 2 * tk)] = xo[ti * 4 + 2 * tk];
+            out[64 * (ti * 4 + 2 * tk + 1)] = xo[ti * 4 + 2 * tk + 1];
         }
 }
 
@@ -1984,7 +2014,7 @@ __global__ void __launch_bounds__(64) k_chol_panel_ll(Batch B, int J, int per_wi
     if (!schur_map(B, per_win, w, bx)) return;
     const WinDesc& d = B.desc[w];
     if (!win_on(d, B.ctrl[w])) return;
-    if (J >= d.nb) return;
+    if (J >= d.nb || J < d.nc) return;
     const int* pb = B.tl_pan_begin + d.tl_step0;
     const int* pan = B.tl_pan + d.tl_pan0;
     const int npan = pb[J + 1] - pb[J];

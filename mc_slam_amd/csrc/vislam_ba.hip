@@ -13,6 +13,7 @@
 #include "vba_pose.h"
 #include "vba_structure.h"
 #include "vba_pcg.h"
+#include "vba_chain.h"
 
 #include <sched.h>
 #include <algorithm>
@@ -131,7 +132,7 @@ struct Staging {
     PinVec<int> ptref, ptobs, obskf, imui, imuj, pair_a, pair_b, pimu_begin, pimu;
     PinVec<int> offpair, pairmask;
     PinVec<unsigned long long> lmask;
-    PinVec<int> s_int[12];       // pinned copies of the small host-built lists (tile lists, k_lin2 runs, reference-run lists)
+    PinVec<int> s_int[14];       // pinned copies of the small host-built lists (tile lists, k_lin2 runs, reference-run lists)
     PinVec<WinDesc> s_desc;
     PinVec<double> dl_pose, dl_vel, dl_bias, dl_pt, dl_chi2;
     PinVec<unsigned char> dl_outl;
@@ -151,9 +152,12 @@ enum {
     BUF_BIASBK, BUF_PT, BUF_PT0, BUF_PTBK, BUF_PTREF, BUF_PTOBS, BUF_OBSKF, BUF_OBSPT, BUF_OBSUV, BUF_OBSW, BUF_LVL,
     BUF_CHI2E, BUF_CHI2F, BUF_DEPTH, BUF_EREC, BUF_PREC, BUF_SLOT, BUF_IMUI, BUF_IMUJ, BUF_IMUMEAS, BUF_IMUINFO, BUF_IMUH, BUF_IMUCHI,
     BUF_S, BUF_LF, BUF_YV, BUF_TLSTEP, BUF_TLPAIR, BUF_TLPANB, BUF_TLPAN, BUF_VEC, BUF_BPOSE, BUF_VARACT, BUF_PAIRA, BUF_PAIRB, BUF_ITEMBEG, BUF_ITEMS, BUF_PIMUBEG, BUF_PIMU,
-    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_N0REC, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
-    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_SLOTO, BUF_SLOTREF, BUF_SLOTQ, BUF_RECQ, BUF_TSQ, BUF_RECCNT, BUF_RESULTS, BUF_PRUN0, BUF_PREFBEG, BUF_PREFLIST, BUF_N
+    BUF_PART, BUF_OUTL, BUF_OUTCHI, BUF_LINBLK, BUF_OFFPAIR, BUF_PAIRMASK, BUF_DBG, BUF_CU, BUF_KFFIX, BUF_TLKB, BUF_TLK, BUF_DVEC, BUF_WINV, BUF_SLOTPERM, BUF_PTPERM,
+    BUF_LMASK, BUF_KFSEG, BUF_REFSEG, BUF_ITEMMID, BUF_STKEY, BUF_LMORDER, BUF_SLOTOBS, BUF_PTINV, BUF_KEYSEG, BUF_TSLOT, BUF_ADJBEG, BUF_ADJ, BUF_PCGV, BUF_PCGM, BUF_KFDIR, BUF_MASKQ, BUF_SLOTMASK, BUF_REFQ, BUF_PCGS, BUF_IMUJREC, BUF_ALIVE, BUF_SLOTO, BUF_SLOTREF, BUF_SLOTQ, BUF_RECQ, BUF_TSQ, BUF_RECCNT, BUF_RESULTS, BUF_PRUN0, BUF_PREFBEG, BUF_PREFLIST, BUF_CHAINTAB, BUF_N
 };
+
+// every kernel launch of a handle is counted (vba_profile.kernel_launches: launches the last run enqueued)
+#define VBA_LAUNCH(...) do { h->n_launch++; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 struct ProfEvt {
     int cls;
@@ -200,6 +204,8 @@ struct Handle {
     // launch geometry (maxima over the batch)
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
     int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0, max_quads = 1, max_offp = 1, max_pan = 0;
+    size_t chain_lds = 0;   // dynamic LDS of k_chol_chain (its per-column tile tables)
+    int min_nc = 0, max_nc = 0, max_cu = 0, max_chain_rows = 0;   // chain columns of the batch's windows (k_chol_chain); tiles of its update launch
     std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
     std::vector<int> pan_grid;   // panel tiles per step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
@@ -214,6 +220,8 @@ struct Handle {
     int opt_chunk = 0, opt_lanes = 0;  // > 0: chunk size / lanes of vba_batch_solve (test hook; defaults from VBA_CHUNK, VBA_LANES)
     int opt_streams = 0;  // > 0: window groups / streams for GN batches (test hook; default from VBA_STREAMS, 1)
     int opt_chol_step = 0;    // test hook: 1 = the first form of the fused factorisation step (k_chol_step) instead of k_chol_step4
+    long long n_launch = 0;   // kernel launches enqueued through this handle so far
+    int opt_no_chain = 0;     // test hook: 1 = one launch per block column everywhere (vba_debug_set_chain)
     int opt_stop_after = -1;  // test hook: >= 0 -- every window reads the stop flag as 1 from that terminate() poll on (poll_stop)
     std::vector<ProfEvt> evts;
     std::vector<hipEvent_t> evt_pool;
@@ -358,11 +366,13 @@ int host_threads() {
         cpu_set_t set;
         CPU_ZERO(&set);
         if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) cores = CPU_COUNT(&set);
+        // ranks of THIS node that share the cores (torchrun exports LOCAL_WORLD_SIZE; WORLD_SIZE counts the ranks of other nodes too
+        // and is not used).  A rank counts as pinned to its share only when the launcher says so (mc_slam_amd/launch.py exports
+        // VBA_RANK_CPUS with the cores it bound the rank to): a cpuset-limited container also shows fewer cores than the machine
+        // has, and there the ranks still share what it shows.
         int local_world = 1;
         if (const char* e = getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, atoi(e));
-        else if (const char* e2 = getenv("WORLD_SIZE")) local_world = std::max(1, atoi(e2));
-        // a rank the launcher pinned already sees only its share
-        const bool pinned = cores < (int)std::thread::hardware_concurrency();
+        const bool pinned = getenv("VBA_RANK_CPUS") != nullptr;
         const int share = pinned ? cores : std::max(1, cores / local_world);
         return std::max(std::min(2, std::max(1, cores)), std::min(16, share));
     }();
@@ -401,7 +411,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     auto &offpair = G.offpair, &pairmask = G.pairmask;
     auto& lmask = G.lmask;
     G.each([](auto& v) { v.clear(); });
-    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, tlkb, tlk, adjbeg, adj, prun0, prefbeg, preflist;
+    std::vector<int> tlstep, tlpair, tlpanb, tlpan, linblk, tlkb, tlk, adjbeg, adj, prun0, prefbeg, preflist, culist, chaintab;
     const bool pcg = probs[0] && probs[0]->solver == VBA_SOLVER_PCG;
     h->step_grid.clear();
     h->pan_grid.clear();
@@ -418,6 +428,13 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
     h->max_its[0] = h->max_its[1] = 0;
     h->any_lin_fallback = false;
+    h->min_nc = 1 << 30; h->max_nc = 0; h->max_cu = 0; h->chain_lds = 0; h->max_chain_rows = 0;
+    // Chain columns in one launch (vba_chain.h): in the left-looking regime (two lean launches for all chain columns of all windows),
+    // and for a handful of windows (one workgroup per tile row walks the chain; measured on MI355X: one window 2.85 ms against 2.89,
+    // 64 windows 9.5 ms per run against 8.0 -- every row workgroup redoes the chain's diagonal work, which is only free while compute
+    // units idle).  In between: one launch per block column.  VBA_NO_CHAIN: A/B switch, one launch per block column everywhere.
+    static const int chain_rl_max = getenv("VBA_CHAIN_RL_MAX") ? atoi(getenv("VBA_CHAIN_RL_MAX")) : 7;
+    const bool chain_on = getenv("VBA_NO_CHAIN") == nullptr && !h->opt_no_chain && (use_left_looking(h, n) || n <= chain_rl_max);
     // Per chunk of windows: (1) the per-window structure (item lists, IMU lists, symbolic tile factorisation: 0.7 ms for a C3
     // window) on a pool of host threads, (2) descriptors and offsets in window order on this thread, (3) the concatenated
     // arrays grown once, (4) the pool again copies every window's arrays to its offsets (2.2 MB per C3 window).
@@ -580,6 +597,14 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
             d.tl_kb0 = (int)tlkb.size(); d.tl_k0 = (int)tlk.size();
             tlkb.insert(tlkb.end(), st.kl_begin.begin(), st.kl_begin.end());
             tlk.insert(tlk.end(), st.klist.begin(), st.klist.end());
+            d.nc = chain_on ? st.nc : 0;
+            d.cu0 = (int)(culist.size() / 4); d.n_cu = d.nc > 0 ? (int)(st.cu.size() / 4) : 0;
+            if (d.nc > 0) culist.insert(culist.end(), st.cu.begin(), st.cu.end());
+            d.ct0 = (int)(chaintab.size() / 4);
+            if (d.nc > 0) chaintab.insert(chaintab.end(), st.chain_tab.begin(), st.chain_tab.end());
+            h->min_nc = std::min(h->min_nc, d.nc); h->max_nc = std::max(h->max_nc, d.nc); h->max_cu = std::max(h->max_cu, d.n_cu);
+            h->max_chain_rows = std::max(h->max_chain_rows, d.nc > 0 ? d.nb - d.nc : 0);
+            h->chain_lds = std::max(h->chain_lds, ((size_t)d.nc * (d.nb - d.nc) + 2 * (size_t)d.nc + 8) * sizeof(short));   // chain_tab_bytes
             if ((int)h->step_grid.size() < d.nb) { h->step_grid.resize(d.nb, 1); h->pan_grid.resize(d.nb, 0); }
             for (int k = 0; k < d.nb; k++) {
                 h->step_grid[k] = std::max(h->step_grid[k], std::max(1, st.step_npairs[k]));
@@ -682,6 +707,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
         return fail(h, "internal: the upload staging moved under an incremental copy");
     h->algo = probs[0]->algo;
     h->variant = probs[0]->variant;
+    if (h->chain_lds > 40 * 1024 || h->max_nc > 256) {   // (256: CHAIN_MAX_NC)   // (a window whose tile tables do not fit beside the kernel's 53 KB of tiles: one launch per column)
+        for (auto& d : h->desc) { d.nc = 0; d.n_cu = 0; }
+        h->min_nc = h->max_nc = h->max_cu = 0;
+    }
     if (!pcg) {   // the back-substitution keeps x, its solve blocks and the window's tile lists in LDS (160 KiB per workgroup)
         const size_t shm = ((size_t)h->max_nS + 2 * TRSV_P_DW * 32 + 2 * 32 * 65 + 32) * sizeof(double) + ((size_t)h->max_pan + h->max_nb + 2) * sizeof(int);
         if (shm > 160 * 1024) return fail(h, "window too large for the direct solver (back-substitution workspace > 160 KiB of LDS): use VBA_SOLVER_PCG");
@@ -711,10 +740,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     if (dalloc(h, BUF_ITEMBEG, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMMID, ((size_t)pair0 + n) * 4) || dalloc(h, BUF_ITEMS, (size_t)item0 * 8)) return -1;
     if (dalloc(h, BUF_STKEY, (size_t)pt0 * 4) || dalloc(h, BUF_LMORDER, (size_t)pt0 * 4) || dalloc(h, BUF_SLOTOBS, (size_t)obs0 * 4) || dalloc(h, BUF_PTINV, (size_t)pt0 * 4)) return -1;
     if (!inc_on && (h2d(h, BUF_OBSUV, uv) || h2d(h, BUF_OBSW, ow))) return -1;
-    if (dalloc(h, BUF_LVL, (size_t)obs0) || dalloc(h, BUF_CHI2E, (size_t)obs0 * 8) || dalloc(h, BUF_DEPTH, (size_t)obs0 * 8)) return -1;
     const bool idp = probs[0]->variant == VBA_VARIANT_PRV_IDP;
+    // (inverse-depth windows evaluate the depth of an edge where they need it, idp_edge_eval: no per-edge copy)
+    if (dalloc(h, BUF_LVL, (size_t)obs0) || dalloc(h, BUF_CHI2E, (size_t)obs0 * 8) || dalloc(h, BUF_DEPTH, idp ? 16 : (size_t)obs0 * 8)) return -1;
     if (dalloc(h, BUF_EREC, (size_t)obs0 * (idp ? VBA_EREC1 : VBA_EREC) * 8) || dalloc(h, BUF_PREC, (size_t)pt0 * VBA_PREC * 8)) return -1;
-    if (dalloc(h, BUF_N0REC, idp ? (size_t)pt0 * VBA_N0REC * 8 : 256)) return -1;
     if (dalloc(h, BUF_SLOT, ((size_t)obs0 + pt0) * (probs[0]->variant == VBA_VARIANT_PRV_IDP ? VBA_SLOT : VBA_SLOT3) * 8)) return -1;
     if (dalloc(h, BUF_CHI2F, (size_t)obs0 * 8)) return -1;
     if (h2d(h, BUF_IMUI, imui) || h2d(h, BUF_IMUJ, imuj) || h2d(h, BUF_IMUMEAS, meas) || h2d(h, BUF_IMUINFO, info)) return -1;
@@ -722,8 +751,9 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     if (dalloc(h, BUF_S, S_tot * 8) || dalloc(h, BUF_VEC, (size_t)vec0 * 8) || dalloc(h, BUF_BPOSE, (size_t)vec0 * 2 * 8)) return -1;
     if (dalloc(h, BUF_LF, S_tot * 8) || dalloc(h, BUF_YV, (size_t)vec0 * 8)) return -1;
     if (h2d_vec(h, BUF_TLSTEP, tlstep, G.s_int[0]) || h2d_vec(h, BUF_TLPAIR, tlpair, G.s_int[1]) || h2d_vec(h, BUF_TLPANB, tlpanb, G.s_int[2]) ||
-        h2d_vec(h, BUF_TLPAN, tlpan, G.s_int[3]) || h2d_vec(h, BUF_TLKB, tlkb, G.s_int[4]) || h2d_vec(h, BUF_TLK, tlk, G.s_int[5])) return -1;
-    if (dalloc(h, BUF_DVEC, (size_t)vec0 * 8) || dalloc(h, BUF_WINV, (size_t)n * 1024 * 8)) return -1;
+        h2d_vec(h, BUF_TLPAN, tlpan, G.s_int[3]) || h2d_vec(h, BUF_TLKB, tlkb, G.s_int[4]) || h2d_vec(h, BUF_TLK, tlk, G.s_int[5]) ||
+        h2d_vec(h, BUF_CU, culist, G.s_int[12]) || h2d_vec(h, BUF_CHAINTAB, chaintab, G.s_int[13])) return -1;
+    if (dalloc(h, BUF_DVEC, (size_t)vec0 * 8) || dalloc(h, BUF_WINV, (size_t)n * 1024 * 8 * (1 + (size_t)(h->ll_mode ? h->max_nc : 0)))) return -1;
     if (dalloc(h, BUF_VARACT, (size_t)vec0 * 4)) return -1;
     if (h2d(h, BUF_PAIRA, pair_a) || h2d(h, BUF_PAIRB, pair_b)) return -1;
     h->solver = probs[0]->solver;
@@ -774,7 +804,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     B.obs_uv = dp<double>(h, BUF_OBSUV); B.obs_w = dp<double>(h, BUF_OBSW);
     B.lvl = dp<unsigned char>(h, BUF_LVL); B.chi2_e = dp<double>(h, BUF_CHI2E); B.depth_e = dp<double>(h, BUF_DEPTH);
     B.chi2_f = (probs[0]->variant == VBA_VARIANT_PRV_IDP) ? nullptr : dp<double>(h, BUF_CHI2F);
-    B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC); B.slot = dp<double>(h, BUF_SLOT); B.n0rec = dp<double>(h, BUF_N0REC); B.kf_fix = dp<unsigned char>(h, BUF_KFFIX);
+    B.erec = dp<double>(h, BUF_EREC); B.prec = dp<double>(h, BUF_PREC); B.slot = dp<double>(h, BUF_SLOT); B.kf_fix = dp<unsigned char>(h, BUF_KFFIX);
     B.imu_i = dp<int>(h, BUF_IMUI); B.imu_j = dp<int>(h, BUF_IMUJ);
     B.imu_meas = dp<double>(h, BUF_IMUMEAS); B.imu_info = dp<double>(h, BUF_IMUINFO);
     B.imuH = dp<double>(h, BUF_IMUH); B.imu_chi = dp<double>(h, BUF_IMUCHI); B.imu_jrec = dp<double>(h, BUF_IMUJREC);
@@ -783,8 +813,8 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     B.l_packed = h->ll_mode ? 1 : 0;
     B.tl_step_begin = dp<int>(h, BUF_TLSTEP); B.tl_pairs = dp<int>(h, BUF_TLPAIR);
     B.tl_pan_begin = dp<int>(h, BUF_TLPANB); B.tl_pan = dp<int>(h, BUF_TLPAN);
-    B.tl_kl_begin = dp<int>(h, BUF_TLKB); B.tl_kl = dp<int>(h, BUF_TLK);
-    B.dvec = dp<double>(h, BUF_DVEC); B.winv = dp<double>(h, BUF_WINV);
+    B.tl_kl_begin = dp<int>(h, BUF_TLKB); B.tl_kl = dp<int>(h, BUF_TLK); B.tl_cu = dp<int>(h, BUF_CU); B.tl_ct = dp<int>(h, BUF_CHAINTAB);
+    B.dvec = dp<double>(h, BUF_DVEC); B.winv = dp<double>(h, BUF_WINV); B.w_total = n; B.w_stride = h->max_nc;
     B.slot_perm = dp<int>(h, BUF_SLOTPERM); B.pt_perm = dp<int>(h, BUF_PTPERM);
     B.var_act = dp<int>(h, BUF_VARACT);
     B.pair_a = dp<int>(h, BUF_PAIRA); B.pair_b = dp<int>(h, BUF_PAIRB);
@@ -806,7 +836,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     if (dalloc(h, BUF_DBG, 4096)) return -1;
     B.dbg = dp<double>(h, BUF_DBG);
     static_assert(VBA_NB <= 64, "k_init_pads covers the pads with one wave");
-    hipLaunchKernelGGL(k_init_pads, dim3(n), dim3(64), 0, h->up_stream, B);
+    VBA_LAUNCH(k_init_pads, dim3(n), dim3(64), 0, h->up_stream, B);
     {   // the device half of the structure build
         StBuild T;
         T.obs_pt = dp<int>(h, BUF_OBSPT); T.slot_perm = dp<int>(h, BUF_SLOTPERM); T.pt_perm = dp<int>(h, BUF_PTPERM);
@@ -821,21 +851,21 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
         T.row_lds = getenv("VBA_ST_ROW_LDS") ? 1 : 0;   // (read per upload: the test flips it inside one process)
         T.slot_o = dp<int>(h, BUF_SLOTO);
         T.slot_ref = dp<int>(h, BUF_SLOTREF); T.slot_q = dp<int>(h, BUF_SLOTQ); T.rec_q = dp<int>(h, BUF_RECQ); T.tsq = dp<int>(h, BUF_TSQ);
-        hipLaunchKernelGGL(k_st_hist, dim3(n), dim3(n <= 64 ? 1024 : 256), sh_order, h->up_stream, B, T);
+        VBA_LAUNCH(k_st_hist, dim3(n), dim3(n <= 64 ? 1024 : 256), sh_order, h->up_stream, B, T);
         {
             const int max_chunks = std::max(1, h->max_pt_blk);   // 64-landmark blocks of the largest window
             if (dalloc(h, BUF_RECCNT, (size_t)kf0 * max_chunks * 2 * 4)) return -1;
             T.rec_cnt = dp<int>(h, BUF_RECCNT);
-            hipLaunchKernelGGL(k_st_lm_count, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
-            hipLaunchKernelGGL(k_st_rec_scan, dim3(n), dim3(256), 0, h->up_stream, B, T, max_chunks);
-            hipLaunchKernelGGL(k_st_lm_fill, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
-            hipLaunchKernelGGL(k_st_rec_count, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
-            hipLaunchKernelGGL(k_st_rec_scan, dim3(n), dim3(256), 0, h->up_stream, B, T, max_chunks);
-            hipLaunchKernelGGL(k_st_rec_fill, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
+            VBA_LAUNCH(k_st_lm_count, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
+            VBA_LAUNCH(k_st_rec_scan, dim3(n), dim3(256), 0, h->up_stream, B, T, max_chunks);
+            VBA_LAUNCH(k_st_lm_fill, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
+            VBA_LAUNCH(k_st_rec_count, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
+            VBA_LAUNCH(k_st_rec_scan, dim3(n), dim3(256), 0, h->up_stream, B, T, max_chunks);
+            VBA_LAUNCH(k_st_rec_fill, dim3(max_chunks, n), dim3(64), 0, h->up_stream, B, T, max_chunks);
         }
-        hipLaunchKernelGGL(k_st_count, dim3(h->max_free, n), dim3(64), sh_row, h->up_stream, B, T, h->max_free);
-        hipLaunchKernelGGL(k_st_scan, dim3(n), dim3(256), 0, h->up_stream, B, T);
-        hipLaunchKernelGGL(k_st_fill, dim3(h->max_free, n), dim3(64), sh_row, h->up_stream, B, T, h->max_free);
+        VBA_LAUNCH(k_st_count, dim3(h->max_free, n), dim3(64), sh_row, h->up_stream, B, T, h->max_free);
+        VBA_LAUNCH(k_st_scan, dim3(n), dim3(256), 0, h->up_stream, B, T);
+        VBA_LAUNCH(k_st_fill, dim3(h->max_free, n), dim3(64), sh_row, h->up_stream, B, T, h->max_free);
         HIPCHK(h, hipGetLastError());
     }
     const double t_enq = now_ms();
@@ -847,6 +877,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
         h->up_pending = true;
     } else
         HIPCHK(h, hipStreamSynchronize(h->up_stream));
+    if (timing) fprintf(stderr, "[vba] chain columns: min %d max %d, update tiles %d, rows %d, ll %d\n", h->min_nc, h->max_nc, h->max_cu, h->max_chain_rows, (int)h->ll_mode);
     if (timing) fprintf(stderr, "[vba] %p t=%.1f upload %d windows: total %.3f ms (structure %.3f, pack %.3f, alloc+H2D enqueue %.3f, sync %.3f)\n", (void*)h, now_ms(), n,
                         now_ms() - t_begin, t_struct, t_pack - t_begin - t_struct, t_enq - t_pack, now_ms() - t_enq);
     h->uploaded = true;
@@ -855,13 +886,28 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     return 0;
 }
 
+// The caller's stop flag (g2o's forceStopFlag, sparse_optimizer.h:188) at ITS width: the reference hands over `bool* pbStopFlag` =
+// &LocalMapping::mbAbortBA, one byte that the Tracking thread writes (include/Optimizer.h:22-24, src/LocalMapping.cpp:1769-1772);
+// a C caller may keep an int.  The byte / word is read, never written.
+struct StopRef {
+    const volatile void* p = nullptr;
+    int width = 0;   // bytes: 1 (vba_*_b) or 4
+    bool set() const {
+        if (!p) return false;
+        return width == 1 ? *reinterpret_cast<const volatile unsigned char*>(p) != 0 : *reinterpret_cast<const volatile int*>(p) != 0;
+    }
+    explicit operator bool() const { return p != nullptr; }
+};
+StopRef stop_int(const volatile int* f) { StopRef r; r.p = f; r.width = 4; return r; }
+StopRef stop_byte(const volatile unsigned char* f) { StopRef r; r.p = f; r.width = 1; return r; }
+
 // ---- the launch schedule ------------------------------------------------------------------------------
 // g2o polls forceStopFlag before every iteration (sparse_optimizer.cpp:376).  The device reads a pinned word; whoever enqueues or
 // waits on the host copies the caller's flag into it -- at every iteration it enqueues and while it waits for the device.
-inline void forward_stop(Handle* h, const volatile int* stop_flag) {
-    if (stop_flag && *stop_flag) *h->stop_host = 1;
+inline void forward_stop(Handle* h, StopRef stop_flag) {
+    if (stop_flag.set()) *h->stop_host = 1;
 }
-hipError_t wait_event_forwarding(Handle* h, hipEvent_t ev, const volatile int* stop_flag) {
+hipError_t wait_event_forwarding(Handle* h, hipEvent_t ev, StopRef stop_flag) {
     if (!stop_flag) return hipEventSynchronize(ev);
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
@@ -870,7 +916,7 @@ hipError_t wait_event_forwarding(Handle* h, hipEvent_t ev, const volatile int* s
         std::this_thread::yield();
     }
 }
-void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr) {
+void enqueue_solve_iteration(Handle* h, StopRef stop_flag = StopRef()) {
     const Batch& B = h->B;
     const int n = h->n_win;         // windows of this group: grid sizes
     const int rn = h->regime_n;     // windows of the batch: kernel choice
@@ -881,27 +927,27 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
         if (idp) {
             static const int fused_schur = getenv("VBA_SCHUR_SPLIT") ? 0 : 1;
             if (rn >= 8 && fused_schur) {
-                hipLaunchKernelGGL(k_schur_all, dim3((h->max_free + h->max_quads) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_quads);
+                VBA_LAUNCH(k_schur_all, dim3((h->max_free + h->max_quads) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_quads);
             } else if (fused_schur) {
-                hipLaunchKernelGGL(k_schur_all_w, dim3((h->max_free + h->max_offp) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_offp);
+                VBA_LAUNCH(k_schur_all_w, dim3((h->max_free + h->max_offp) * ngrp), dim3(64), 0, h->stream, B, h->max_free, h->max_offp);
             } else {
-            hipLaunchKernelGGL(k_schur_diag, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free);
-            if (rn >= 8) hipLaunchKernelGGL(k_schur_off, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
-            else hipLaunchKernelGGL(k_schur_off_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
+            VBA_LAUNCH(k_schur_diag, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free);
+            if (rn >= 8) VBA_LAUNCH(k_schur_off, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
+            else VBA_LAUNCH(k_schur_off_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
             }
         } else {
-            hipLaunchKernelGGL(k_dinv, dim3(h->max_pt_blk, n), dim3(64), 0, h->stream, B);
+            VBA_LAUNCH(k_dinv, dim3(h->max_pt_blk, n), dim3(64), 0, h->stream, B);
             // (diagonal and off-diagonal pairs in two launches: fusing them as for the inverse-depth records gained nothing at C2)
-            hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 0);
-            if (rn >= 8) hipLaunchKernelGGL(k_schur_off3, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
-            else hipLaunchKernelGGL(k_schur_off3_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
+            VBA_LAUNCH(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, h->stream, B, h->max_free, 0);
+            if (rn >= 8) VBA_LAUNCH(k_schur_off3, dim3(h->max_quads * ngrp), dim3(64), 0, h->stream, B, h->max_quads);
+            else VBA_LAUNCH(k_schur_off3_w, dim3(h->max_offp * ngrp), dim3(64), 0, h->stream, B, h->max_offp);
         }
     }
     if (h->solver == VBA_SOLVER_PCG) {
         // Two launches per CG iteration for all windows of the group; the host enqueues BATCHES of iterations and reads one pinned
         // word per batch (did any window go on?) two batches behind the device.  Converged windows exit at the first instruction.
         ProfScope ps(h, VBA_PROF_FACTOR);
-        hipLaunchKernelGGL(k_pcg_init, dim3(n), dim3(256), 0, h->stream, B);
+        VBA_LAUNCH(k_pcg_init, dim3(n), dim3(256), 0, h->stream, B);
         const int per_batch = 32, RING = 16, row_blocks = (h->max_nS + PCG_ROWS - 1) / PCG_ROWS;
         volatile int* ring = h->stop_host + 1024 + 16 * h->cur_group;
         int* ring_dev = h->stop_dev + 1024 + 16 * h->cur_group;
@@ -915,13 +961,13 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
             forward_stop(h, stop_flag);
             ring[b % RING] = 0;
             for (int it = 0; it < per_batch; it++) {
-                hipLaunchKernelGGL(k_pcg_matvec, dim3(row_blocks, n), dim3(256), 0, h->stream, B);
-                hipLaunchKernelGGL(k_pcg_step, dim3(n), dim3(256), 0, h->stream, B, ring_dev + (b % RING));
+                VBA_LAUNCH(k_pcg_matvec, dim3(row_blocks, n), dim3(256), 0, h->stream, B);
+                VBA_LAUNCH(k_pcg_step, dim3(n), dim3(256), 0, h->stream, B, ring_dev + (b % RING));
             }
             ev.push_back(get_evt(h));
             (void)hipEventRecord(ev.back(), h->stream);
         }
-        hipLaunchKernelGGL(k_pcg_finish, dim3(n), dim3(256), 0, h->stream, B);
+        VBA_LAUNCH(k_pcg_finish, dim3(n), dim3(256), 0, h->stream, B);
     } else {
     {
         ProfScope ps(h, VBA_PROF_FACTOR);
@@ -931,25 +977,37 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
         // column in two launches, because the fused kernel redid the diagonal tile and two panel solves in every tile-pair workgroup.
         // With the DPP elimination of k_chol_step4 (then: its first form, k_chol_step3) the fused launch wins up to the left-looking threshold -- 64 windows 9.2 ms per step
         // against 12.7, 128: 15.1 / 17.7, 200: 21.8 / 23.1, left-looking at 200: 21.7 -- and the split kernels are gone.)
+        // the chain columns [0, nc) of every window in one launch (vba_chain.h); the per-column kernels start behind them
+        const int k_first = h->max_nc > 0 ? std::min(h->min_nc, h->max_nc) : 0;
+        if (h->max_nc > 0) {
+            if (h->ll_mode) {
+                VBA_LAUNCH(k_chol_chain_diag, dim3(n), dim3(64), 0, h->stream, B);
+                if (h->max_chain_rows > 0) VBA_LAUNCH(k_chol_chain_panel, dim3(h->max_chain_rows * ngrp), dim3(64), 0, h->stream, B, h->max_chain_rows);
+            }
+            else {
+                VBA_LAUNCH(k_chol_chain_rows, dim3(std::max(1, h->max_chain_rows), n), dim3(256), 0, h->stream, B);
+                if (h->max_cu > 0) VBA_LAUNCH(k_chol_chain_upd, dim3(h->max_cu, n), dim3(512), 0, h->stream, B);
+            }
+        }
         if (h->ll_mode) {
-            for (int k = 0; k < h->max_nb; k++) {  // every tile read once, updated in registers, written once
-                hipLaunchKernelGGL(k_chol_diag_ll2, dim3(n), dim3(64), 0, h->stream, B, k);
-                if (h->pan_grid[k] > 0) hipLaunchKernelGGL(k_chol_panel_ll, dim3(h->pan_grid[k] * ngrp), dim3(64), 0, h->stream, B, k, h->pan_grid[k]);
+            for (int k = k_first; k < h->max_nb; k++) {  // every tile read once, updated in registers, written once
+                VBA_LAUNCH(k_chol_diag_ll2, dim3(n), dim3(64), 0, h->stream, B, k);
+                if (h->pan_grid[k] > 0) VBA_LAUNCH(k_chol_panel_ll, dim3(h->pan_grid[k] * ngrp), dim3(64), 0, h->stream, B, k, h->pan_grid[k]);
             }
         } else {
             // form 1 (test hook vba_debug_set_chol_step / VBA_CHOL_STEP=1): the first version of the step -- diagonal tile, then the
             // panel solves, v_readlane broadcasts; kept as the cross-check of the hand-written DPP instruction stream
             static const int env_form = getenv("VBA_CHOL_STEP") ? atoi(getenv("VBA_CHOL_STEP")) : 0;
             const int step_form = h->opt_chol_step > 0 ? h->opt_chol_step : (env_form > 0 ? env_form : 4);
-            for (int k = 0; k < h->max_nb; k++) {
-                if (step_form == 1) hipLaunchKernelGGL(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
+            for (int k = k_first; k < h->max_nb; k++) {
+                if (step_form == 1) VBA_LAUNCH(k_chol_step, dim3(h->step_grid[k], n), dim3(64), 0, h->stream, B, k);
                 else if (h->n_win == 1 && n == 1 && (int)h->one_sb.size() > k + 1) {   // one window: descriptor and step table ride in the kernel arguments
                     const WinDesc& d0 = h->desc[0];
                     StepOne so;
                     so.algo = d0.algo; so.nS = d0.nS; so.nb = d0.nb; so.vec0 = d0.vec0; so.S0 = d0.S0;
                     so.pair_off = d0.tl_pair0 + h->one_sb[k]; so.npair = h->one_sb[k + 1] - h->one_sb[k];
-                    hipLaunchKernelGGL(k_chol_step4<true>, dim3(h->step_grid[k], 1), dim3(128), 0, h->stream, B, k, so);
-                } else hipLaunchKernelGGL(k_chol_step4<false>, dim3(h->step_grid[k], n), dim3(128), 0, h->stream, B, k, StepOne());
+                    VBA_LAUNCH(k_chol_step4<true>, dim3(h->step_grid[k], 1), dim3(128), 0, h->stream, B, k, so);
+                } else VBA_LAUNCH(k_chol_step4<false>, dim3(h->step_grid[k], n), dim3(128), 0, h->stream, B, k, StepOne());
             }
         }
     }
@@ -958,17 +1016,17 @@ void enqueue_solve_iteration(Handle* h, const volatile int* stop_flag = nullptr)
         static const int trsv_old = getenv("VBA_TRSV_OLD") ? 1 : 0;
         if (h->ll_mode || trsv_old) {
             const size_t shm = ((size_t)h->max_nS + 256 + 32 * 33) * sizeof(double);
-            hipLaunchKernelGGL(k_trsv, dim3(n), dim3(256), shm, h->stream, B);
+            VBA_LAUNCH(k_trsv, dim3(n), dim3(256), shm, h->stream, B);
         } else {   // row-major factor: a solving wave + seven waves that work one column ahead
             const size_t shm = ((size_t)h->max_nS + 2 * TRSV_P_DW * 32 + 2 * 32 * 65 + 32) * sizeof(double) + ((size_t)h->max_pan + h->max_nb + 2) * sizeof(int);
-            hipLaunchKernelGGL(k_trsv_p, dim3(n), dim3(512), shm, h->stream, B);
+            VBA_LAUNCH(k_trsv_p, dim3(n), dim3(512), shm, h->stream, B);
         }
     }
     }
     {
         ProfScope ps(h, VBA_PROF_UPDATE);
-        if (idp) hipLaunchKernelGGL(k_update, dim3(h->max_pt_blk + h->max_kf_blk, n), dim3(64), 0, h->stream, B, h->max_pt_blk);
-        else hipLaunchKernelGGL(k_update_xyz, dim3(h->max_pt_blk + h->max_kf_blk, n), dim3(64), 0, h->stream, B, h->max_pt_blk);
+        if (idp) VBA_LAUNCH(k_update, dim3(h->max_pt_blk + h->max_kf_blk, n), dim3(64), 0, h->stream, B, h->max_pt_blk);
+        else VBA_LAUNCH(k_update_xyz, dim3(h->max_pt_blk + h->max_kf_blk, n), dim3(64), 0, h->stream, B, h->max_pt_blk);
     }
 }
 
@@ -978,19 +1036,19 @@ void enqueue_lin(Handle* h, int mode) {
         const size_t shm = LIN2_LDS;
         static const int fuse_imu = getenv("VBA_LIN_IMU_SPLIT") ? 0 : 1;
         if (fuse_imu && h->max_imu > 0 && h->regime_n < 64) {   // few windows: edges and IMU factors in one launch
-            hipLaunchKernelGGL(k_lin2_imu, dim3(h->max_lin_blk + h->max_imu, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
+            VBA_LAUNCH(k_lin2_imu, dim3(h->max_lin_blk + h->max_imu, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
             return;
         }
-        hipLaunchKernelGGL(k_lin2, dim3(h->max_lin_blk, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
+        VBA_LAUNCH(k_lin2, dim3(h->max_lin_blk, h->n_win), dim3(256), shm, h->stream, h->B, h->max_lin_blk, mode);
     } else {
-        hipLaunchKernelGGL(k_lin_xyz_e, dim3(h->max_lin_blk, h->n_win), dim3(256), 0, h->stream, h->B, mode);
-        if (h->any_lin_fallback) hipLaunchKernelGGL(k_lin_xyz, dim3(h->max_pt_blk, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
+        VBA_LAUNCH(k_lin_xyz_e, dim3(h->max_lin_blk, h->n_win), dim3(256), 0, h->stream, h->B, mode);
+        if (h->any_lin_fallback) VBA_LAUNCH(k_lin_xyz, dim3(h->max_pt_blk, h->n_win), dim3(64), 0, h->stream, h->B, h->max_pt_blk, mode);
     }
     if (h->max_imu > 0 && h->regime_n < 64) {   // few windows: latency matters, one launch
-        hipLaunchKernelGGL(k_lin_imu_pair, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, mode);
+        VBA_LAUNCH(k_lin_imu_pair, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B, mode);
     } else if (h->max_imu > 0) {   // the IMU factors: a lane per keyframe pair for the Lie-group part, then a wave per pair for J^T Omega J
-        hipLaunchKernelGGL(k_lin_imu_res, dim3((h->max_imu + 63) / 64, h->n_win), dim3(64), 0, h->stream, h->B, mode);
-        if (mode == LIN_FULL) hipLaunchKernelGGL(k_lin_imu_hess, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B);
+        VBA_LAUNCH(k_lin_imu_res, dim3((h->max_imu + 63) / 64, h->n_win), dim3(64), 0, h->stream, h->B, mode);
+        if (mode == LIN_FULL) VBA_LAUNCH(k_lin_imu_hess, dim3(h->max_imu, h->n_win), dim3(64), 0, h->stream, h->B);
     }
 }
 
@@ -1014,7 +1072,7 @@ struct Group {
 // 300 k workgroups only exit).  The host learns through one
 // pinned word per slot group whether any window of the group of windows is still going, and stays two slot groups ahead of
 // the device (as the Gauss-Newton schedule does): no host round trip per trial, none per outer iteration on the critical path.
-int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile int* stop_flag) {
+int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, StopRef stop_flag) {
     const int big_blk = std::max(std::max(h->max_kf_blk, h->max_pt_blk), h->max_obs_blk);
     const int kp_blk = std::max(h->max_kf_blk, h->max_pt_blk);
     const Batch B_all = h->B;
@@ -1023,55 +1081,55 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
     auto use = [&](const Group& g) { h->B = g.B; h->n_win = g.n_win; h->stream = g.stream; h->cur_group = (int)(&g - &groups[0]); };
     auto stage_begin = [&](Group& g, int stage) {
         ProfScope ps(h, VBA_PROF_MISC);
-        if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
-        hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
-        if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
-        hipLaunchKernelGGL(k_stage_mark, dim3(h->max_free + (h->max_imu + 63) / 64, g.n_win), dim3(64), 0, g.stream, g.B, h->max_free);
+        if (h->regime_n >= 64) VBA_LAUNCH(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+        VBA_LAUNCH(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
+        if (stage == 1) VBA_LAUNCH(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+        VBA_LAUNCH(k_stage_mark, dim3(h->max_free + (h->max_imu + 63) / 64, g.n_win), dim3(64), 0, g.stream, g.B, h->max_free);
     };
     auto stage_end = [&](Group& g) {
         if (h->variant == VBA_VARIANT_PRV_IDP) return;
         ProfScope ps(h, VBA_PROF_MISC);
-        hipLaunchKernelGGL(k_depth_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        VBA_LAUNCH(k_depth_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
     };
     auto outer = [&](Group& g) {   // linearise + computeLambdaInit of one outer iteration
         enqueue_lin(h, LIN_FULL);
         const int ngrp = (g.n_win >= 8) ? 8 * ((g.n_win + 7) / 8) : g.n_win;
         {   // H_pp diagonal for computeLambdaInit (the block it writes into S is rewritten by the first trial): a Schur diagonal pass
             ProfScope ps(h, VBA_PROF_SCHUR);
-            hipLaunchKernelGGL(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, g.stream, g.B, h->max_free, 1);
+            VBA_LAUNCH(k_schur_diag3, dim3(h->max_free * ngrp), dim3(64), 0, g.stream, g.B, h->max_free, 1);
         }
         ProfScope ps(h, VBA_PROF_CONTROL);
-        if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
-        hipLaunchKernelGGL(k_ctrl_lm_outer, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
+        if (h->regime_n >= 64) VBA_LAUNCH(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+        VBA_LAUNCH(k_ctrl_lm_outer, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
     };
     auto trial = [&](Group& g, int* alive_dev, int* alive_mirror) {
         {
             ProfScope ps(h, VBA_PROF_MISC);
-            hipLaunchKernelGGL(k_backup, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+            VBA_LAUNCH(k_backup, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
         }
         enqueue_solve_iteration(h, stop_flag);
         enqueue_lin(h, LIN_ERR_TRIAL);
         {
             ProfScope ps(h, VBA_PROF_CONTROL);
-            if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
-            hipLaunchKernelGGL(k_ctrl_lm_trial, dim3(g.n_win), dim3(64), 0, g.stream, g.B, alive_dev, alive_mirror);
+            if (h->regime_n >= 64) VBA_LAUNCH(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+            VBA_LAUNCH(k_ctrl_lm_trial, dim3(g.n_win), dim3(64), 0, g.stream, g.B, alive_dev, alive_mirror);
         }
         {
             ProfScope ps(h, VBA_PROF_MISC);   // pop of a rejected step (with k_backup, the push)
-            hipLaunchKernelGGL(k_restore, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+            VBA_LAUNCH(k_restore, dim3(kp_blk, g.n_win), dim3(64), 0, g.stream, g.B);
         }
     };
     auto finish = [&](Group& g) {
         ProfScope ps(h, VBA_PROF_MISC);
         if (h->variant != VBA_VARIANT_PRV_IDP)
-            hipLaunchKernelGGL(k_chi2_fresh_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
-        hipLaunchKernelGGL(k_final_edges, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
-        hipLaunchKernelGGL(k_final_sum, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
+            VBA_LAUNCH(k_chi2_fresh_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        VBA_LAUNCH(k_final_edges, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        VBA_LAUNCH(k_final_sum, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
     };
     for (auto& g : groups) {
         use(g);
         ProfScope ps(h, VBA_PROF_MISC);
-        hipLaunchKernelGGL(k_reset, dim3(std::max(1, std::min(32, big_blk / 4)), g.n_win), dim3(256), 0, g.stream, g.B);
+        VBA_LAUNCH(k_reset, dim3(std::max(1, std::min(32, big_blk / 4)), g.n_win), dim3(256), 0, g.stream, g.B);
     }
     const int RING = 32;   // pinned alive words per window group (its 64-word block: [0, RING) used here)
     int rc = 0;
@@ -1118,7 +1176,7 @@ int enqueue_schedule_lm(Handle* h, std::vector<Group>& groups, const volatile in
 // The two-stage schedule of a batch cut into window groups.  The groups are independent; their launches are enqueued
 // INTERLEAVED, iteration by iteration, each on its own stream, so that while one group sits in the latency-bound block
 // columns of its factorisation another one streams through its bandwidth-bound linearise / Schur kernels.
-int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* stop_flag) {
+int enqueue_schedule(Handle* h, std::vector<Group>& groups, StopRef stop_flag) {
     if (h->algo == VBA_ALGO_LM) return enqueue_schedule_lm(h, groups, stop_flag);
     const int big_blk = std::max(std::max(h->max_kf_blk, h->max_pt_blk), h->max_obs_blk);
     const Batch B_all = h->B;
@@ -1130,16 +1188,16 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
     for (auto& g : groups) {
         use(g);
         ProfScope ps(h, VBA_PROF_MISC);
-        hipLaunchKernelGGL(k_reset, dim3(std::max(1, std::min(32, big_blk / 4)), g.n_win), dim3(256), 0, g.stream, g.B);
+        VBA_LAUNCH(k_reset, dim3(std::max(1, std::min(32, big_blk / 4)), g.n_win), dim3(256), 0, g.stream, g.B);
     }
     for (int stage = 0; stage < 2 && rc == 0; stage++) {
         for (auto& g : groups) {
             use(g);
             ProfScope ps(h, VBA_PROF_MISC);
-            if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
-        hipLaunchKernelGGL(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
-            if (stage == 1) hipLaunchKernelGGL(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
-            hipLaunchKernelGGL(k_stage_mark, dim3(h->max_free + (h->max_imu + 63) / 64, g.n_win), dim3(64), 0, g.stream, g.B, h->max_free);
+            if (h->regime_n >= 64) VBA_LAUNCH(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+        VBA_LAUNCH(k_stage_clear, dim3(h->max_ns_blk, g.n_win), dim3(64), 0, g.stream, g.B, stage);
+            if (stage == 1) VBA_LAUNCH(k_classify, dim3(h->max_obs_blk, g.n_win), dim3(64), 0, g.stream, g.B);
+            VBA_LAUNCH(k_stage_mark, dim3(h->max_free + (h->max_imu + 63) / 64, g.n_win), dim3(64), 0, g.stream, g.B, h->max_free);
         }
         {
             // The host stays at most two iterations ahead of the device: before enqueuing iteration it of a group it waits
@@ -1182,8 +1240,8 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
                     enqueue_lin(h, LIN_FULL);
                     {
                         ProfScope ps(h, VBA_PROF_CONTROL);
-                        if (h->regime_n >= 64) hipLaunchKernelGGL(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
-                        hipLaunchKernelGGL(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 0, word_report ? stage * 32 + it : -1);
+                        if (h->regime_n >= 64) VBA_LAUNCH(k_poll_stop, dim3(1), dim3(1), 0, g.stream, g.B);
+                        VBA_LAUNCH(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 0, word_report ? stage * 32 + it : -1);
                     }
                     if (pace && !word_report) {
                         ev[gi][it] = get_evt(h);
@@ -1197,14 +1255,14 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
                 use(g);
                 enqueue_lin(h, LIN_ERR);
                 ProfScope ps(h, VBA_PROF_CONTROL);
-                hipLaunchKernelGGL(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 1, -1);
+                VBA_LAUNCH(k_ctrl_gn, dim3(g.n_win), dim3(64), 0, g.stream, g.B, 1, -1);
             }
         }
         if (h->variant != VBA_VARIANT_PRV_IDP)
             for (auto& g : groups) {
                 use(g);
                 ProfScope ps(h, VBA_PROF_MISC);
-                hipLaunchKernelGGL(k_depth_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+                VBA_LAUNCH(k_depth_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
             }
     }
     for (auto& g : groups) {
@@ -1212,15 +1270,15 @@ int enqueue_schedule(Handle* h, std::vector<Group>& groups, const volatile int* 
         use(g);
         ProfScope ps(h, VBA_PROF_MISC);
         if (h->variant != VBA_VARIANT_PRV_IDP)
-            hipLaunchKernelGGL(k_chi2_fresh_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
-        hipLaunchKernelGGL(k_final_edges, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
-        hipLaunchKernelGGL(k_final_sum, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
+            VBA_LAUNCH(k_chi2_fresh_xyz, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        VBA_LAUNCH(k_final_edges, dim3(std::max(h->max_obs_blk, 1), g.n_win), dim3(64), 0, g.stream, g.B);
+        VBA_LAUNCH(k_final_sum, dim3(g.n_win), dim3(64), 0, g.stream, g.B);
     }
     restore();
     return rc;
 }
 
-int do_run(Handle* h, const volatile int* stop_flag) {
+int do_run(Handle* h, StopRef stop_flag) {
     static const bool timing = getenv("VBA_TIMING") != nullptr;
     const double t_run0 = timing ? now_ms() : 0.0;
     if (!h->uploaded) return fail(h, "vba_batch_run before vba_batch_upload");
@@ -1228,8 +1286,9 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     h->B.dbg_stop_after = h->opt_stop_after;
     const Batch B = h->B;
     const int n = h->n_win;
-    *h->stop_host = (stop_flag && *stop_flag) ? 1 : 0;
+    *h->stop_host = stop_flag.set() ? 1 : 0;
     for (int i = 64; i < 1024; i++) h->stop_host[i] = 0;
+    const long long launch0 = h->n_launch;
     h->evts.clear();
     h->evt_used = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -1310,15 +1369,17 @@ int do_run(Handle* h, const volatile int* stop_flag) {
     // wait, forwarding the caller's stop flag (g2o forceStopFlag) into the device-visible word
     if (stop_flag) {
         while (hipEventQuery(ev_all) == hipErrorNotReady) {
-            if (*stop_flag) *h->stop_host = 1;
+            if (stop_flag.set()) *h->stop_host = 1;
             std::this_thread::yield();
         }
     }
     HIPCHK(h, hipEventSynchronize(ev_all));
     if (h->dl_prefetched) memcpy(h->hctrl.data(), h->res_host.p, sizeof(WinCtrl) * n);
+    h->prof.kernel_launches = h->n_launch - launch0;
     if (h->profile) {
         vba_profile& pf = h->prof;
         memset(&pf, 0, sizeof pf);
+        pf.kernel_launches = h->n_launch - launch0;
         for (auto& e : h->evts) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, e.a, e.b);
@@ -1553,7 +1614,12 @@ int vba_batch_upload(void* handle, int32_t n, vba_problem* const* problems) {
 int vba_batch_run(void* handle, const volatile int* stop_flag) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
-    return do_run(h, stop_flag);
+    return do_run(h, stop_int(stop_flag));
+}
+int vba_batch_run_b(void* handle, const volatile unsigned char* stop_flag) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    return do_run(h, stop_byte(stop_flag));
 }
 int vba_batch_download(void* handle, int32_t n, vba_problem* const* inout, vba_result* const* out) {
     Handle* h = reinterpret_cast<Handle*>(handle);
@@ -1561,10 +1627,12 @@ int vba_batch_download(void* handle, int32_t n, vba_problem* const* inout, vba_r
     return do_download(h, n, inout, out);
 }
 
-int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile int* stop_flag) {
+}  // extern "C"
+namespace {
+int solve_one(void* handle, vba_problem* inout, vba_result* out, StopRef stop_flag) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h || !inout || !out) return -1;
-    if (stop_flag && *stop_flag) {  // src/Optimizer.cpp:453-455: return before anything is built
+    if (stop_flag.set()) {  // src/Optimizer.cpp:453-455: return before anything is built
         out->status = VBA_ABORTED_BEFORE;
         out->its_done[0] = out->its_done[1] = 0;
         out->n_outliers = 0; out->n_trace = 0; out->lin_iterations = 0;
@@ -1577,6 +1645,18 @@ int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile 
     if (do_run(h, stop_flag)) return -1;
     return do_download(h, 1, ps, rs);
 }
+int batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_result* const* out, StopRef stop_flag);
+}  // namespace
+extern "C" {
+int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile int* stop_flag) { return solve_one(handle, inout, out, stop_int(stop_flag)); }
+int vba_solve_b(void* handle, vba_problem* inout, vba_result* out, const volatile unsigned char* stop_flag) { return solve_one(handle, inout, out, stop_byte(stop_flag)); }
+int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_result* const* out, const volatile int* stop_flag) {
+    return batch_solve(handle, n, inout, out, stop_int(stop_flag));
+}
+int vba_batch_solve_b(void* handle, int32_t n, vba_problem* const* inout, vba_result* const* out, const volatile unsigned char* stop_flag) {
+    return batch_solve(handle, n, inout, out, stop_byte(stop_flag));
+}
+}  // extern "C"
 
 // Fresh windows in, solved windows out: the batch is cut into chunks and several chunks are in flight at once, each on its
 // own lane (a sub-handle with its own streams, device buffers and pinned staging), so that the host-side packing, the H2D
@@ -1585,7 +1665,8 @@ int vba_solve(void* handle, vba_problem* inout, vba_result* out, const volatile 
 // kernels a batch of its size runs (the choice depends on the window count: thresholds 8 / 64 / 256), so chunks of the
 // default size give bit for bit what one big upload + run + download gives; across a threshold the sums run in another
 // fixed order and the results agree to rounding.
-int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_result* const* out, const volatile int* stop_flag) {
+namespace {
+int batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_result* const* out, StopRef stop_flag) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
     if (n <= 0 || !inout) return fail(h, "vba_batch_solve: bad arguments");
@@ -1638,12 +1719,12 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
         Handle* l = nullptr;
         if (make_handle(h->device, h, &l) != 0) return fail(h, "vba_batch_solve: could not create a lane");
         l->opt_ll_min = h->opt_ll_min;
+        l->opt_no_chain = h->opt_no_chain;
         l->opt_stop_after = h->opt_stop_after;
         h->lanes.push_back(l);
     }
     const int n_chunks2 = (int)cbeg.size() - 1;
     std::atomic<int> next(0), bad(0);
-    std::mutex mu;
     // Lanes that start together stay in step (all pack, then all solve, then all scatter: the GPU idles while the hosts pack).
     // A run token breaks the symmetry: only `run_slots` lanes may be inside the solve at a time, the others pack / transfer /
     // build the structure of their next chunk or scatter their last one meanwhile.
@@ -1697,13 +1778,11 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
             if (!rc) rc = do_download(lane, cn, inout + w0, out ? out + w0 : nullptr);
             if (timing) fprintf(stderr, "[vba_batch_solve] chunk %d (%d windows): upload %.1f..%.1f  run ..%.1f  download ..%.1f ms\n", c, cn, t0 - t_call, t1 - t_call, t2 - t_call, now_ms() - t_call);
             if (rc) {
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    if (!bad.load()) h->err = "vba_batch_solve, windows " + std::to_string(w0) + ".." + std::to_string(w0 + cn - 1) + ": " + lane->err;
-                }
-                {   // `bad` is set and announced under the mutex the waiting lanes evaluate their predicate under: a lane that has just
-                    // found `up_turn == c || bad` false cannot miss this wake-up
+                {   // the message and `bad` change together, under the mutex the waiting lanes evaluate their predicate under: the first
+                    // failing lane writes the message (two lanes failing together cannot both), and a lane that has just found
+                    // `up_turn == c || bad` false cannot miss this wake-up
                     std::lock_guard<std::mutex> lk(up_mu);
+                    if (!bad.load()) h->err = "vba_batch_solve, windows " + std::to_string(w0) + ".." + std::to_string(w0 + cn - 1) + ": " + lane->err;
                     bad.store(1);
                 }
                 up_cv.notify_all();   // lanes waiting for their upload turn see `bad`
@@ -1717,7 +1796,14 @@ int vba_batch_solve(void* handle, int32_t n, vba_problem* const* inout, vba_resu
     for (auto& t : pool) t.join();
     return bad.load() ? -1 : 0;
 }
+}  // namespace
 
+extern "C" {
+
+// ---- test / diagnostic hooks: NOT part of include/vislam_ba.h and not in the shipped library.  `make` builds a second flavour,
+// libvislam_ba_hooks.so (-DVBA_TEST_HOOKS), that the tests load when they need to look inside (tests/test_abi_exports.py checks
+// that libvislam_ba.so exports exactly the header).
+#ifdef VBA_TEST_HOOKS
 // test/debug hook (not part of include/vislam_ba.h): raw copy out of one device buffer of the last batch
 int vba_debug_copy(void* handle, int32_t buf_id, uint64_t offset_bytes, void* dst, uint64_t nbytes) {
     Handle* h = reinterpret_cast<Handle*>(handle);
@@ -1736,8 +1822,6 @@ int vba_debug_tile_products(void* handle, int32_t w, int64_t* out) {
     out[2] = h->desc[w].order; out[3] = h->win_tiles[w];
     return 0;
 }
-// test hook (ctypes): the size of the host thread pool of a handle in this process (cores of this rank's share, see host_threads)
-int vba_debug_host_threads() { return host_threads(); }
 int vba_debug_set_streams(void* handle, int32_t n) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h) return -1;
@@ -1783,13 +1867,26 @@ int vba_debug_buf_id(const char* name) {
     static const char* names[] = {"DESC", "CTRL", "POSE", "VEL", "BIAS", "KFR", "POSE0", "VEL0", "BIAS0", "POSEBK", "VELBK", "BIASBK", "PT", "PT0",
         "PTBK", "PTREF", "PTOBS", "OBSKF", "OBSPT", "OBSUV", "OBSW", "LVL", "CHI2E", "CHI2F", "DEPTH", "EREC", "PREC", "SLOT", "IMUI", "IMUJ",
         "IMUMEAS", "IMUINFO", "IMUH", "IMUCHI", "S", "LF", "YV", "TLSTEP", "TLPAIR", "TLPANB", "TLPAN", "VEC", "BPOSE", "VARACT", "PAIRA",
-        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "N0REC", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
-        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE", "SLOTO", "SLOTREF", "SLOTQ", "RECQ", "TSQ", "RECCNT", "RESULTS", "PRUN0", "PREFBEG", "PREFLIST"};
+        "PAIRB", "ITEMBEG", "ITEMS", "PIMUBEG", "PIMU", "PART", "OUTL", "OUTCHI", "LINBLK", "OFFPAIR", "PAIRMASK", "DBG", "CU", "KFFIX", "TLKB", "TLK", "DVEC", "WINV", "SLOTPERM", "PTPERM",
+        "LMASK", "KFSEG", "REFSEG", "ITEMMID", "STKEY", "LMORDER", "SLOTOBS", "PTINV", "KEYSEG", "TSLOT", "ADJBEG", "ADJ", "PCGV", "PCGM", "KFDIR", "MASKQ", "SLOTMASK", "REFQ", "PCGS", "IMUJREC", "ALIVE", "SLOTO", "SLOTREF", "SLOTQ", "RECQ", "TSQ", "RECCNT", "RESULTS", "PRUN0", "PREFBEG", "PREFLIST", "CHAINTAB"};
     static_assert(sizeof(names) / sizeof(names[0]) == BUF_N, "buffer name table out of date");
     for (int i = 0; i < BUF_N; i++)
         if (!strcmp(names[i], name)) return i;
     return -1;
 }
+
+// chain columns of the factorisation (vba_chain.h): 0 = one launch per block column everywhere, 1 = the default policy
+int vba_debug_set_chain(void* handle, int32_t on) {
+    Handle* h = reinterpret_cast<Handle*>(handle);
+    if (!h) return -1;
+    h->opt_no_chain = on ? 0 : 1;
+    for (Handle* l : h->lanes) l->opt_no_chain = h->opt_no_chain;
+    return 0;
+}
+#endif  // VBA_TEST_HOOKS
+
+// the size of the host thread pool of a handle in this process (this rank's share of the cores: host_threads above)
+int vba_host_threads(void) { return host_threads(); }
 
 int vba_preintegrate(void* handle, int32_t n_edges, const int32_t* sample_begin, const double* gyr, const double* acc,
                      const double* dt, double gyr_meas_cov, double acc_meas_cov, double* imu_meas, double* cov_pvphi,
@@ -1820,7 +1917,7 @@ int vba_preintegrate(void* handle, int32_t n_edges, const int32_t* sample_begin,
         HIPCHK(h, hipMemcpyAsync(d_a, acc, (size_t)ns * 24, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(d_dt, dt, (size_t)ns * 8, hipMemcpyHostToDevice, h->stream));
     }
-    hipLaunchKernelGGL(k_preint, dim3(n_edges), dim3(128), 0, h->stream, n_edges, d_sb, d_g, d_a, d_dt, gyr_meas_cov, acc_meas_cov,
+    VBA_LAUNCH(k_preint, dim3(n_edges), dim3(128), 0, h->stream, n_edges, d_sb, d_g, d_a, d_dt, gyr_meas_cov, acc_meas_cov,
                        d_m, d_c, imu_info_prv ? d_i : nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(imu_meas, d_m, b_m, hipMemcpyDeviceToHost, h->stream));
@@ -1953,7 +2050,7 @@ int vba_pose_optimize(void* handle, int32_t n_frames, vba_frame_problem* const* 
     B.err = reinterpret_cast<double*>(base + b_in + b_out + b_lvl);
     B.n_frames = n_frames;
     HIPCHK(h, hipMemcpyAsync(base, hin, b_in, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_pose_opt, dim3(n_frames), dim3(64), 0, h->stream, B);
+    VBA_LAUNCH(k_pose_opt, dim3(n_frames), dim3(64), 0, h->stream, B);
     HIPCHK(h, hipGetLastError());
     char* hout = reinterpret_cast<char*>(h->pose_host_out.p);
     HIPCHK(h, hipMemcpyAsync(hout, base + b_in, b_out + b_lvl, hipMemcpyDeviceToHost, h->stream));

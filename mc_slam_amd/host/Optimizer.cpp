@@ -1,12 +1,10 @@
 // Optimizer.cpp -- see Optimizer.h.  Line references: src/Optimizer.cpp of mc275/MC_SLAM.
 #include "Optimizer.h"
 
-#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <iostream>
 #include <chrono>
-#include <thread>
 
 namespace ORB_SLAM2 {
 
@@ -99,33 +97,22 @@ void FinishProblem(PackedWindow& W) {
     W.R.obs_chi2 = W.chi2.data();
 }
 
-// g2o's forceStopFlag is a bool* written by the Tracking thread (LocalMapping::mbAbortBA); the C-ABI polls an int
-struct StopMirror {
-    std::atomic<int> flag{0};
-    std::atomic<bool> done{false};
-    std::thread th;
-    explicit StopMirror(bool* src) {
-        if (!src) return;
-        flag = *src ? 1 : 0;
-        th = std::thread([this, src] {
-            // the device looks at the flag between outer iterations (~0.25 ms apart for a local window): polling a few
-            // times per iteration is as prompt as g2o's own check and leaves the core to the Tracking thread
-            while (!done.load()) {
-                if (*reinterpret_cast<volatile bool*>(src)) { flag = 1; break; }
-                std::this_thread::sleep_for(std::chrono::microseconds(50));
-            }
-        });
-    }
-    ~StopMirror() {
-        done = true;
-        if (th.joinable()) th.join();
-    }
-    const volatile int* ptr() { return reinterpret_cast<const volatile int*>(&flag); }
-};
+// g2o's forceStopFlag is a bool* written by the Tracking thread (&LocalMapping::mbAbortBA, src/LocalMapping.cpp:1769-1772): the
+// backend reads the caller's flag at its own width (vba_solve_b), so the pointer goes straight through -- the device sees a raised
+// flag at its next poll because the host forwards it whenever it enqueues an iteration and while it waits.  (Until round 4 the ABI
+// only took an int*: a thread per call mirrored the bool into one.)
+static_assert(sizeof(bool) == 1, "vba_solve_b reads the stop flag as one byte");
+inline const volatile unsigned char* StopPtr(bool* pbStopFlag) { return reinterpret_cast<const volatile unsigned char*>(pbStopFlag); }
+
+// wall-clock split of the last facade call of this thread (Optimizer::LastTiming): extraction, solve (vba_solve_b: H2D + structure +
+// two-stage solve + D2H), erase + write-back under the map lock
+thread_local FacadeTiming t_timing;
+inline double NowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
 
 const PackedWindow& Optimizer::LastWindow() { return t_last; }
+const FacadeTiming& Optimizer::LastTiming() { return t_timing; }
 PackedWindow& Optimizer::LastWindowMutable() { return t_last; }
 
 // ------------------------------------------------------------------------------------------------
@@ -272,17 +259,21 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
 void Optimizer::LocalBAPRVIDP(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocalKeyFrames, bool* pbStopFlag, Map* pMap,
                               const Vector3d& gw, LocalMapping* pLM) {
     PackedWindow& W = t_last;
+    t_timing = FacadeTiming();
+    const double t0 = NowMs();
     if (!PackLocalBAPRVIDP(pCurKF, lLocalKeyFrames, gw, W)) return;
+    t_timing.extract_ms = NowMs() - t0;
     if (pbStopFlag && *pbStopFlag) return;                                                                        // :453-455
     void* h = handle();
     if (!h) { std::cerr << "LocalBAPRVIDP: no HIP device, local BA skipped (the backend has no CPU path)" << std::endl; return; }
-    {
-        StopMirror stop(pbStopFlag);
-        if (vba_solve(h, &W.P, &W.R, pbStopFlag ? stop.ptr() : nullptr) != 0) {
-            std::cerr << "LocalBAPRVIDP: " << vba_last_error(h) << std::endl;
-            return;
-        }
+    const double t1 = NowMs();
+    if (vba_solve_b(h, &W.P, &W.R, StopPtr(pbStopFlag)) != 0) {
+        std::cerr << "LocalBAPRVIDP: " << vba_last_error(h) << std::endl;
+        return;
     }
+    const double t2 = NowMs();
+    t_timing.solve_ms = t2 - t1;
+    struct WriteBackTimer { double t; ~WriteBackTimer() { t_timing.writeback_ms = NowMs() - t; t_timing.total_ms = t_timing.extract_ms + t_timing.solve_ms + t_timing.writeback_ms; } } wbt{t2};
     if (W.R.status == VBA_ABORTED_BEFORE) return;
     if (W.R.status == VBA_ABORTED_AFTER_STAGE1)
         std::cerr << "Hint: local mapping optimize only 5 iter. Need more computation resource." << std::endl;  // :469-470
@@ -328,8 +319,7 @@ void Optimizer::LocalBundleAdjustmentNavStatePRV(KeyFrame* pCurKF, const std::li
     void* h = handle();
     if (!h) { std::cerr << "LocalBundleAdjustmentNavStatePRV: no HIP device, local BA skipped (the backend has no CPU path)" << std::endl; return; }
     {
-        StopMirror stop(pbStopFlag);
-        if (vba_solve(h, &W.P, &W.R, pbStopFlag ? stop.ptr() : nullptr) != 0) {
+        if (vba_solve_b(h, &W.P, &W.R, StopPtr(pbStopFlag)) != 0) {
             std::cerr << "LocalBundleAdjustmentNavStatePRV: " << vba_last_error(h) << std::endl;
             return;
         }
@@ -468,8 +458,7 @@ void Optimizer::LocalBundleAdjustmentImpl(KeyFrame* pKF, const std::list<KeyFram
     void* h = handle();
     if (!h) { std::cerr << "LocalBundleAdjustment: no HIP device, local BA skipped (the backend has no CPU path)" << std::endl; return; }
     {
-        StopMirror stop(pbStopFlag);
-        if (vba_solve(h, &W.P, &W.R, pbStopFlag ? stop.ptr() : nullptr) != 0) {
+        if (vba_solve_b(h, &W.P, &W.R, StopPtr(pbStopFlag)) != 0) {
             std::cerr << "LocalBundleAdjustment: " << vba_last_error(h) << std::endl;
             return;
         }
@@ -537,8 +526,7 @@ void PackMapPoints(const std::vector<MapPoint*>& vpMP, std::map<KeyFrame*, int>&
 bool RunGlobal(PackedWindow& W, bool* pbStopFlag, const char* who) {
     void* h = handle();
     if (!h) { std::cerr << who << ": no HIP device, global BA skipped (the backend has no CPU path)" << std::endl; return false; }
-    StopMirror stop(pbStopFlag);
-    if (vba_solve(h, &W.P, &W.R, pbStopFlag ? stop.ptr() : nullptr) != 0) {
+    if (vba_solve_b(h, &W.P, &W.R, StopPtr(pbStopFlag)) != 0) {
         std::cerr << who << ": " << vba_last_error(h) << std::endl;
         return false;
     }

@@ -13,6 +13,10 @@
 
 namespace ORB_SLAM2 {
 
+// wall-clock split of one facade call (LocalBAPRVIDP): graph extraction (src/Optimizer.cpp:49-451), the solve behind the C-ABI,
+// erase + write-back under the map lock (:496-623)
+struct FacadeTiming { double extract_ms = 0, solve_ms = 0, writeback_ms = 0, total_ms = 0; };
+
 // flat arrays of one window in the layout of vba_problem, plus the bookkeeping the write-back needs
 struct PackedWindow {
     vba_problem P;
@@ -69,6 +73,7 @@ public:
     static bool PackLocalBAPRVIDP(KeyFrame* pKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw, PackedWindow& W);
     static bool PackLocalBundleAdjustment(KeyFrame* pKF, PackedWindow& W);
     static const PackedWindow& LastWindow();
+    static const FacadeTiming& LastTiming();   // of this thread's last LocalBAPRVIDP call
     static PackedWindow& LastWindowMutable();   // test harness: extraction-only calls pack into it
     static int Device;  // HIP device of the backend handle (one handle per calling thread)
 };

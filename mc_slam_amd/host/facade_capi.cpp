@@ -98,6 +98,20 @@ static std::list<KeyFrame*> window(FcMap* M, const long* ids, int n) {
     for (int i = 0; i < n; i++) l.push_back(M->kfs.at(ids[i]).get());
     return l;
 }
+// LocalBAPRVIDP with the CALLER'S flag: `stop` is a bool (one byte) that another thread may raise while the call runs, exactly as
+// LocalMapping::InterruptBA does with mbAbortBA (src/LocalMapping.cpp:1769-1772)
+int fc_local_ba_prvidp_flag(void* m, const long* ids, int n, const double* gw, bool* stop) {
+    FcMap* M = reinterpret_cast<FcMap*>(m);
+    std::list<KeyFrame*> l = window(M, ids, n);
+    const Vector3d g{{gw[0], gw[1], gw[2]}};
+    Optimizer::LocalBAPRVIDP(l.back(), l, stop, &M->map, g, &M->lm);
+    return 0;
+}
+// wall-clock split of this thread's last LocalBAPRVIDP: extraction, solve, erase + write-back, total (ms)
+void fc_last_timing(double* out4) {
+    const FacadeTiming& t = Optimizer::LastTiming();
+    out4[0] = t.extract_ms; out4[1] = t.solve_ms; out4[2] = t.writeback_ms; out4[3] = t.total_ms;
+}
 // mode 0: full LocalBAPRVIDP; 1: extraction only (no GPU needed)
 int fc_local_ba_prvidp(void* m, const long* ids, int n, const double* gw, int stop, int mode) {
     FcMap* M = reinterpret_cast<FcMap*>(m);

@@ -78,6 +78,7 @@ def pin_rank(env=None):
         if share:
             try:
                 os.sched_setaffinity(0, share)
+                env.setdefault("VBA_RANK_CPUS", ",".join(str(c) for c in share))   # the marker the library reads: this rank IS pinned to its share
             except OSError:
                 pass
         if "VBA_UPLOAD_THREADS" not in env:

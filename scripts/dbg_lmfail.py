@@ -2,7 +2,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from mc_slam_amd import abi, synth, backend
-ba = backend.LocalBA(0)
+ba = backend.LocalBA(0, hooks=True)
 p = synth.make_window(abi.VARIANT_SE3_XYZ, algo=abi.ALGO_LM, n_kf=8, n_fixed=2, n_pt=150, n_obs=800, seed=170)
 p.obs_w = np.zeros_like(p.obs_w)
 good = synth.make_window(abi.VARIANT_SE3_XYZ, algo=abi.ALGO_LM, n_kf=8, n_fixed=2, n_pt=150, n_obs=800, seed=172)

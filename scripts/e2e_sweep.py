@@ -8,7 +8,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 nd = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 wins = bench.make_windows([("c3", 100 + i, False, "caller") for i in range(nd)], 16)
 batch = [wins[i % nd] for i in range(n)]
-ba = backend.LocalBA(0)
+ba = backend.LocalBA(0, hooks=True)
 ba.upload(batch); ba.run()
 t = time.perf_counter(); ba.run(); ba.run(); tr = (time.perf_counter() - t) / 2
 print("resident %.0f windows/s" % (n / tr), flush=True)

@@ -4,7 +4,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from mc_slam_amd import synth, backend
 p = synth.config_c3(seed=3)
-ba = backend.LocalBA(0)
+ba = backend.LocalBA(0, hooks=True)
 for _ in range(3): ba.solve(p)
 bid = ba.lib.vba_debug_buf_id(b"DBG")
 a = np.zeros(32)

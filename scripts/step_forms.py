@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from mc_slam_amd import abi, synth, backend
-ba = backend.LocalBA(0)
+ba = backend.LocalBA(0, hooks=True)
 ba.lib.vba_debug_set_chol_step.argtypes = [C.c_void_p, C.c_int32]
 forms = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "4,1").split(",")]
 cases = {"c3 x1": [synth.config_c3(seed=3)], "c3 x20": [synth.config_c3(seed=10 + i) for i in range(20)],

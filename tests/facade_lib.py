@@ -30,6 +30,9 @@ def lib():
         l.fc_add_observation.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_float, C.c_float, C.c_int]
         l.fc_local_ba_prvidp.argtypes = [C.c_void_p, _pl, C.c_int, _pd, C.c_int, C.c_int]
         l.fc_local_ba_vision.argtypes = [C.c_void_p, C.c_long, C.c_int]
+        l.fc_local_ba_prvidp_flag.argtypes = [C.c_void_p, _pl, C.c_int, _pd, C.POINTER(C.c_bool)]
+        l.fc_last_timing.argtypes = [_pd]
+        l.fc_last_timing.restype = None
         l.fc_local_ba_prv_xyz.argtypes = [C.c_void_p, _pl, C.c_int, _pd, C.c_int, C.c_int]
         l.fc_local_ba_vision_list.argtypes = [C.c_void_p, _pl, C.c_int, C.c_int, C.c_int]
         l.fc_global_ba_prv.argtypes = [C.c_void_p, _pd, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int]
@@ -123,6 +126,17 @@ class FacadeMap:
     def local_ba_prvidp(self, stop=0, extract_only=False):
         ids = self.window_ids()
         return self.L.fc_local_ba_prvidp(self.m, ids.ctypes.data_as(_pl), len(ids), _d(self.p.g_w), stop, 1 if extract_only else 0)
+
+    def local_ba_prvidp_flag(self, flag):
+        """Optimizer::LocalBAPRVIDP with the caller's own `bool` (a ctypes c_bool another thread may raise while the call runs)"""
+        ids = self.window_ids()
+        return self.L.fc_local_ba_prvidp_flag(self.m, ids.ctypes.data_as(_pl), len(ids), _d(self.p.g_w), C.byref(flag))
+
+    def last_timing(self):
+        """wall-clock split of the last LocalBAPRVIDP of this thread (ms): extraction, solve, erase + write-back, total"""
+        t = np.zeros(4)
+        self.L.fc_last_timing(t.ctypes.data_as(_pd))
+        return dict(extract_ms=t[0], solve_ms=t[1], writeback_ms=t[2], total_ms=t[3])
 
     def global_ba_prv(self, n_it=20, loop_kf=0, robust=True, stop=0, extract_only=False):
         return self.L.fc_global_ba_prv(self.m, _d(self.p.g_w), n_it, loop_kf, int(robust), stop, 1 if extract_only else 0)

@@ -55,8 +55,30 @@ int main(int argc, char** argv) {
                     if (ok) seen[r] = 1;
                 }
         }
-        printf("%s order %d mwords %d item_cap %lld mask_bits %lld tiles %zu klist %zu pimu %zu pan %zu h_tiles %llx h_mask %llx\n", ok ? "ok" : "error inconsistent",
-               st.order, st.mwords, st.item_cap, mask_bits, st.tpairs.size(), st.klist.size(), st.pimu.size() / 2, st.pan.size(),
+        {   // chain columns: row J < nc of L has no tile left of (J, J-1); the tables of the chain kernels agree with the tile lists
+            const int nb = (int)st.step_begin.size() - 1;
+            ok = ok && st.nc >= 0 && st.nc < std::max(nb, 1) && (int)st.chain_tab.size() == 4 * st.nc && st.cu.size() % 4 == 0;
+            for (int J = 0; J < st.nc && ok; J++) {
+                unsigned long long mask = 0;
+                int ride = 0;
+                for (int i = st.pan_begin[J]; i < st.pan_begin[J + 1]; i++) {
+                    const int I = st.pan[i];
+                    if (I == J + 1 && J + 1 < st.nc) ride = 1;
+                    else { ok = ok && I >= st.nc && I - st.nc < 64; mask |= 1ull << ((I - st.nc) & 63); }
+                }
+                ok = ok && (unsigned)st.chain_tab[4 * J] == (unsigned)(mask & 0xffffffffull) && (unsigned)st.chain_tab[4 * J + 1] == (unsigned)(mask >> 32) && st.chain_tab[4 * J + 2] == ride;
+                const int ent = st.pan_begin[J] + J;   // the k list of the diagonal entry: empty or {J - 1}
+                const int nk = st.kl_begin[ent + 1] - st.kl_begin[ent];
+                ok = ok && (nk == 0 || (nk == 1 && st.klist[st.kl_begin[ent]] == J - 1));
+            }
+            for (size_t q = 0; q + 3 < st.cu.size() && ok; q += 4) {
+                const int I = st.cu[q] >> 16, J = st.cu[q] & 0xffff;
+                ok = ok && J >= st.nc && I >= J && st.cu[q + 1] < st.cu[q + 2];
+                for (int e = st.cu[q + 1]; e < st.cu[q + 2]; e++) ok = ok && st.klist[e] < st.nc;
+            }
+        }
+        printf("%s order %d mwords %d item_cap %lld mask_bits %lld tiles %zu klist %zu pimu %zu pan %zu nc %d h_tiles %llx h_mask %llx\n", ok ? "ok" : "error inconsistent",
+               st.order, st.mwords, st.item_cap, mask_bits, st.tpairs.size(), st.klist.size(), st.pimu.size() / 2, st.pan.size(), st.nc,
                (unsigned long long)fnv(st.tpairs), (unsigned long long)fnv(st.pair_mask));
         vba_problem_free(P);
     }

@@ -24,6 +24,17 @@ def test_header_symbols_are_exported():
         assert getattr(lib, n) is not None
 
 
+def test_shipped_library_exports_exactly_the_header():
+    """the test / diagnostic hooks (vba_debug_*) exist only in the hooks flavour of the library"""
+    import subprocess
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return sorted(set(l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("vba_")))
+    assert exported(backend.LIB_PATH) == _declared()
+    hooks = exported(backend.HOOKS_LIB_PATH)
+    assert set(_declared()) < set(hooks) and any(n.startswith("vba_debug_") for n in hooks)
+
+
 def test_struct_layout_matches_header():
     # sizes the C compiler gives the same structs (checked once with gcc -> constants below); guards ctypes drift
     import subprocess, tempfile, textwrap

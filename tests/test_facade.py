@@ -1,6 +1,8 @@
 """The C++ host facade (mc_slam_amd/host): same static Optimizer API as the reference, KeyFrame / MapPoint in,
 KeyFrame / MapPoint out.  CPU part: graph extraction reproduces the window the map was built from.
 GPU part: the facade's in-place results equal a direct C-ABI solve of the extracted window."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -60,6 +62,59 @@ def test_stop_flag_returns_before_touching_anything():
     after = [fm.nav(t)[0] for t in fm.window_ids()]
     assert all((a == b).all() for a, b in zip(before, after)) and fm.L.fc_map_updated(fm.m) == 0
     fm.close()
+
+
+@pytest.mark.gpu
+def test_bool_flag_raised_from_another_thread_inside_local_ba_prvidp(oracle):
+    """The path the live system takes: Tracking calls LocalMapping::InterruptBA, which sets the `bool` mbAbortBA that LocalMapping
+    handed to Optimizer::LocalBAPRVIDP as pbStopFlag (/root/reference/src/LocalMapping.cpp:1769-1772, 1035) -- while the solve
+    runs.  The facade passes the bool* straight to vba_solve_b (no mirror thread); the backend forwards it to the device whenever
+    it enqueues an iteration and while it waits.  Whatever the moment, the map must come back as the oracle's result for SOME
+    poll count; at least one of the delays must land inside the solve (status 1: stage 2 skipped, stage-1 state written back)."""
+    import threading, time
+    p = synth.config_c3(seed=21, n_kf=30, n_pt=2500, n_obs=14000)
+    fm0 = facade.FacadeMap(p)
+    fm0.local_ba_prvidp(extract_only=True)
+    e = facade.last_problem()
+    fm0.close()
+    table = {}
+    for n in list(range(0, 17)) + [-1]:
+        qo, ro = oracle.solve(e, stop_after=n)
+        table.setdefault((ro.status, tuple(ro.its_done)), (qo, ro))
+    full = oracle.solve(e)[1]
+    assert full.status == 0 and full.its_done[1] >= 1
+    # calibration: how long extraction and solve take here (the flag has to go up after the first and before the end of the second)
+    for _ in range(2):    # (the first call of the thread creates the backend handle; a map serves one call: the second finds its map points marked)
+        fm = facade.FacadeMap(p)
+        fm.local_ba_prvidp_flag(C.c_bool(False))
+        tm = fm.last_timing()
+        fm.close()
+    assert tm["solve_ms"] > 0
+    seen = set()
+    for frac in (0.3, 0.5, 0.15, 0.7, 0.4, 0.25, 0.6, 0.1, 0.85, 0.05):
+        delay = (tm["extract_ms"] + frac * tm["solve_ms"]) * 1e-3
+        fm = facade.FacadeMap(p)
+        flag = C.c_bool(False)
+        th = threading.Thread(target=lambda: (time.sleep(delay), setattr(flag, "value", True)))
+        th.start()
+        fm.local_ba_prvidp_flag(flag)
+        th.join()
+        if fm.last_timing()["solve_ms"] == 0.0:      # raised before the solve began: the call returned at src/Optimizer.cpp:453-455
+            assert fm.L.fc_map_updated(fm.m) == 0
+            fm.close()
+            continue
+        r = facade.lib().fc_last_result().contents
+        key = (r.status, (r.its_done[0], r.its_done[1]))
+        assert key in table, (delay, key, sorted(table))
+        qo, ro = table[key]
+        for i, t in enumerate(fm.window_ids()):      # the keyframes hold the oracle's state of that poll count
+            nav, _T = fm.nav(int(t))
+            assert np.abs(nav[:3] - qo.kf_pose[i, :3]).max() <= 1e-6 and np.abs(nav[7:10] - qo.kf_vel[i]).max() <= 1e-5
+        seen.add(key)
+        fm.close()
+        if any(k[0] == 1 and k[1][0] >= 1 for k in seen):
+            break
+    assert any(k[0] == 1 and k[1][0] >= 1 for k in seen), ("the flag never arrived inside the solve", sorted(seen), tm)
 
 
 @pytest.mark.gpu

@@ -17,7 +17,7 @@ TRANS_ATOL = 1e-6
 
 @pytest.fixture(scope="module")
 def ba():
-    b = backend.LocalBA(0)
+    b = backend.LocalBA(0, hooks=True)
     yield b
     b.close()
 
@@ -525,6 +525,56 @@ def test_large_batches_switch_factorisation_kernels(ba, oracle, variant, nwin):
         _check(p, q, r, qo, ro)
     for i in range(4, nwin):   # twins inside the batch agree bit for bit
         assert (qs[i].kf_pose == qs[i % 4].kf_pose).all() and rs[i].chi2_vis == rs[i % 4].chi2_vis
+
+
+def test_chain_columns_in_one_launch_agree_with_one_launch_per_column(ba, oracle):
+    """The V/Bias block columns of the IMU chain ("chain columns": row J of the factor has no tile left of (J, J-1)) are factored by
+    one launch per factorisation instead of one per column (csrc/vba_chain.h): k_chol_chain_rows + k_chol_chain_upd for a handful
+    of windows, k_chol_chain_diag + k_chol_chain_panel in the left-looking regime.  Same elimination order, sums in another fixed
+    order: both forms against the oracle and against each other (to rounding), full-size ragged C3 windows (40..60 keyframes, 11..16
+    chain columns), alone, five in one call (ragged: different chain lengths in one launch), and a window whose IMU chain is broken
+    in the middle (two keyframes without an IMU factor between them: a chain column without its sub-diagonal tile)."""
+    ps = [synth.config_c3_ragged(100 + s) for s in (1, 2, 5, 7, 9)]
+    broken = synth.config_c3(seed=11, n_kf=30, n_pt=1500, n_obs=9000)
+    keep = np.array([k for k in range(broken.n_imu) if k != broken.n_imu // 2])
+    broken = broken.copy()
+    broken.imu_kf_i, broken.imu_kf_j = broken.imu_kf_i[keep].copy(), broken.imu_kf_j[keep].copy()
+    broken.imu_meas, broken.imu_info_prv = broken.imu_meas[keep].copy(), broken.imu_info_prv[keep].copy()
+    ps.append(broken)
+    ba.lib.vba_debug_set_chain.argtypes = [C.c_void_p, C.c_int32]
+    res = {}
+    try:
+        for ll in (0, 1):
+            ba.lib.vba_debug_set_ll_min(ba.h, 1 if ll else 0)
+            for chain in (1, 0):
+                ba.lib.vba_debug_set_chain(ba.h, chain)
+                one, launches = [], []
+                for p in ps:
+                    one.append(ba.solve(p))
+                    launches.append(ba.get_profile()["kernel_launches"])
+                ba.upload(ps[:5]); ba.run(); qs, rs = ba.download()
+                res[ll, chain] = (one, list(zip(qs, rs)))
+                res[ll, chain, "launches"] = launches
+    finally:
+        ba.lib.vba_debug_set_chain(ba.h, 1)
+        ba.lib.vba_debug_set_ll_min(ba.h, 0)
+    for ll in (0, 1):   # the chain kernels really ran: 2 launches instead of nc (right-looking) / 2 nc (left-looking) per factorisation
+        saved = [a - b for a, b in zip(res[ll, 0, "launches"], res[ll, 1, "launches"])]   # (a window in keyframe order has no chain columns: 0)
+        assert sum(1 for x in saved if x >= 50) >= 3 and min(saved) >= 0, saved
+    for i, p in enumerate(ps):
+        qo, ro = oracle.solve(p)
+        for ll in (0, 1):
+            (q, r), (q0, r0) = res[ll, 1][0][i], res[ll, 0][0][i]
+            _check(p, q, r, qo, ro)
+            _check(p, q0, r0, qo, ro)
+            assert r.its_done == r0.its_done and (r.obs_outlier == r0.obs_outlier).all()
+            np.testing.assert_allclose(r.chi2_trace, r0.chi2_trace, rtol=1e-8)
+            assert np.abs(q.kf_pose - q0.kf_pose).max() < 1e-8
+            if i < 5:   # inside the five-window call
+                qb, rb = res[ll, 1][1][i]
+                _check(p, qb, rb, qo, ro)
+                if ll:  # left-looking: the kernels do not depend on the window count -- bit for bit
+                    assert (qb.kf_pose == q.kf_pose).all() and rb.chi2_vis == r.chi2_vis
 
 
 def test_left_looking_kernels_at_full_window_size(ba, oracle):

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ba():
-    b = backend.LocalBA(0)
+    b = backend.LocalBA(0, hooks=True)
     b.lib.vba_debug_set_stop_after.argtypes = [C.c_void_p, C.c_int32]
     yield b
     b.lib.vba_debug_set_stop_after(b.h, -1)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ba():
-    b = backend.LocalBA(0)
+    b = backend.LocalBA(0, hooks=True)
     yield b
     b.close()
 

@@ -66,7 +66,7 @@ cpus = launch.pin_rank(os.environ)
 import ctypes
 lib = ctypes.CDLL(os.path.join(os.environ["REPO_ROOT"], "mc_slam_amd", "csrc", "libvislam_ba.so"))
 sys.stderr.write(json.dumps({"rank": int(os.environ["RANK"]), "cpus": cpus, "affinity": sorted(os.sched_getaffinity(0)),
-                             "threads_env": os.environ.get("VBA_UPLOAD_THREADS"), "threads_lib": lib.vba_debug_host_threads()}) + "\n")
+                             "threads_env": os.environ.get("VBA_UPLOAD_THREADS"), "threads_lib": lib.vba_host_threads()}) + "\n")
 print(json.dumps({"ok": 1}))
 """
 
@@ -93,7 +93,7 @@ def test_spawned_ranks_pin_themselves_and_the_library_sizes_its_pool(tmp_path):
 
 def test_library_pool_follows_local_world_size_without_the_launcher():
     """under torchrun nobody exports VBA_UPLOAD_THREADS: the library divides the cores it may run on by LOCAL_WORLD_SIZE itself"""
-    code = ("import ctypes, os; l = ctypes.CDLL(os.path.join(%r, 'mc_slam_amd', 'csrc', 'libvislam_ba.so')); print(l.vba_debug_host_threads())" % ROOT)
+    code = ("import ctypes, os; l = ctypes.CDLL(os.path.join(%r, 'mc_slam_amd', 'csrc', 'libvislam_ba.so')); print(l.vba_host_threads())" % ROOT)
     n = len(os.sched_getaffinity(0))
     for world, want in ((1, max(min(2, n), min(16, n))), (4, max(min(2, n), min(16, max(1, n // 4))))):
         env = dict(os.environ)
@@ -101,6 +101,26 @@ def test_library_pool_follows_local_world_size_without_the_launcher():
         env["LOCAL_WORLD_SIZE"] = str(world)
         got = int(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip())
         assert got == want, (world, got, want)
+
+
+def test_library_pool_in_a_restricted_cpuset_still_divides_by_the_local_world():
+    """a cpuset-limited container shows fewer cores than the machine has; without the launcher's marker (VBA_RANK_CPUS) the ranks
+    still SHARE what it shows: 4 ranks on a mask of m cores take m / 4 threads each, not m"""
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        pytest.skip("needs at least four cores")
+    mask = allowed[:max(4, len(allowed) // 2)]
+    code = ("import ctypes, os; os.sched_setaffinity(0, %r); l = ctypes.CDLL(os.path.join(%r, 'mc_slam_amd', 'csrc', 'libvislam_ba.so')); print(l.vba_host_threads())"
+            % (mask, ROOT))
+    m = len(mask)
+    for extra, want in (({}, max(min(2, m), min(16, max(1, m // 4)))),
+                        ({"VBA_RANK_CPUS": ",".join(map(str, mask))}, max(min(2, m), min(16, m)))):   # pinned by the launcher: the whole share
+        env = dict(os.environ)
+        env.pop("VBA_UPLOAD_THREADS", None); env.pop("VBA_RANK_CPUS", None); env.pop("WORLD_SIZE", None)
+        env["LOCAL_WORLD_SIZE"] = "4"
+        env.update(extra)
+        got = int(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip())
+        assert got == want, (extra, got, want)
 
 
 def test_spawn_relays_rank0_and_forwards_stderr(tmp_path):
