@@ -46,9 +46,10 @@ def csrc_sha():
 def _gen_window(spec):
     """(workload, seed, uniform, landmark order) -> Problem; runs in forked worker processes (numpy only, no GPU, no torch)"""
     from mc_slam_amd import synth
-    wl, seed, uniform, order = spec
+    wl, seed, uniform, order = spec[:4]
+    mix = spec[4] if len(spec) > 4 else "r3"
     if wl == "c3":
-        return synth.config_c3(seed=seed, landmark_order=order) if uniform else synth.config_c3_ragged(seed=seed, landmark_order=order)
+        return synth.config_c3(seed=seed, landmark_order=order) if uniform else synth.config_c3_ragged(seed=seed, landmark_order=order, kinds=(mix != "r2"))
     if wl in ("c4", "c3s", "c2", "c2s"):   # local windows: the order the caller hands landmarks over in matters to the record layout
         return {"c4": synth.config_c4, "c3s": synth.config_c3s, "c2": synth.config_c2, "c2s": synth.config_c2s}[wl](seed=seed, landmark_order=order)
     return synth.config_gba(seed=seed)   # (the global BA walks pMap->GetAllMapPoints(): no keyframe grouping)
@@ -135,6 +136,9 @@ def main():
                     help="local-window workloads (c3, c3s, c4, c2, c2s): 'caller' = landmarks in the order the reference's caller builds lLocalMapPoints in -- keyframe by "
                          "keyframe over lLocalKeyFrames, every keyframe appending the map points no earlier one has listed (src/Optimizer.cpp:59-78, 3877-3894), i.e. grouped by "
                          "the first local keyframe that observes them; 'random' = the generator's order (uncorrelated with the keyframes; the workload of rounds 1-3a)")
+    ap.add_argument("--iteration-mix", default="r3", choices=["r3", "r2"],
+                    help="c3: 'r3' = three kinds of window (5+3 / 4..5+2 / 3..4+1 Gauss-Newton iterations: 60 / 20 / 20 %%, the workload since round 3); 'r2' = every "
+                         "window of the first kind (all 5+3): the iteration mix of rounds 1-2, same sizes -- with --landmark-order random the round-2 workload exactly")
     ap.add_argument("--uniform", action="store_true", help="c3: every window exactly 50 KF / 5 000 landmarks / 30 000 edges instead of sizes drawn around it")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "gba", "pose", "c3s", "c2s"],
                     help="c3 = BASELINE configs[2] (the headline metric); c2 / c4 = configs[1] / configs[3], gba = map-scale global BA, pose = IMU-aided per-frame pose "
@@ -172,7 +176,7 @@ def main():
     specs = []
     if args.workload != "pose":
         n_distinct = max(1, min(args.distinct, args.batch))
-        specs = [(args.workload, shard.window_seed(g), args.uniform, args.landmark_order) for g in shard.window_ids(n_distinct * world, rank, world)]
+        specs = [(args.workload, shard.window_seed(g), args.uniform, args.landmark_order, args.iteration_mix) for g in shard.window_ids(n_distinct * world, rank, world)]
     # under rocprofv3 the profiler's preloaded library has initialised the GPU runtime before main(): forking such a process is
     # what this pool forbids (children inherit the runtime's locks; an intermittent hang of a PMC pass was traced to it) -> serial
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -537,7 +541,10 @@ def main():
                        "parallelism": "independent windows sharded %d per GPU, no data-path collective" % args.batch,
                        "value_is": "kernel-only (windows resident in HBM, no PCIe in the timed region); value_end_to_end includes H2D + D2H",
                        "host_threads": int(ba.lib.vba_host_threads()), "cpu_affinity": {"cores": len(my_cpus), "first": my_cpus[0], "last": my_cpus[-1]},
+                       "iteration_mix": args.iteration_mix if args.workload == "c3" and not args.uniform else None,
                        "mean_outer_iterations": float(np.mean(its))},
+            # work-normalised: outer (Gauss-Newton / LM) iterations of all windows per second -- comparable across iteration mixes
+            "window_iterations_per_s": value * float(np.mean(its)),
             "end_to_end": e2e, "single_window": single, "pcg": pcg,
             "roofline": roofline, "cpu_baseline": cpu, "verified": verified,
         }

@@ -43,7 +43,8 @@ struct Batch {
     const int *pair_a, *pair_b, *item_begin, *items, *pimu_begin, *pimu;
     const int *adj_begin, *adj;         // PCG: per free keyframe the other free keyframes it shares a landmark or an IMU edge with
     double* kf_dir;                     // XYZ landmarks: per keyframe the damping-independent part of its diagonal block and b_p (32 doubles)
-    double *pcg_v, *pcg_m, *pcg_s;      // PCG: x r z p q (5 nS per window); inverted diagonal blocks (225 per keyframe); CG state (8 per window)
+    double *pcg_v, *pcg_m, *pcg_s;      // PCG: x r z p q (5 nS per window); preconditioner blocks (450 per keyframe); CG state (8 per window)
+    int pcg_tri;                        // PCG: block-tridiagonal (keyframe chain) preconditioner instead of block-Jacobi
     const int *slot_o, *rec_lm;         // [n_obs] observation of the record in every slot; [n_pt] landmark of every landmark record
     const int* slot_lm;                 // [n_obs] landmark of the record in every slot (XYZ gathers fetch the landmark's Sigma through it)
     const int* item_mid;                // per pair: its first item that involves the landmark's reference keyframe

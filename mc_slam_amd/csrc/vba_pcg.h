@@ -3,8 +3,8 @@
 // Not in the reference: its g2o only carries the direct solvers (Thirdparty/g2o/g2o/solvers/linear_solver_{eigen,cholmod,
 // dense}.h) and every optimiser of src/Optimizer.cpp uses LinearSolverEigen.  Selected with vba_problem.solver =
 // VBA_SOLVER_PCG; the LDL^T path stays the default.  The algorithm is the textbook one g2o's own linear_solver_pcg.h (absent
-// from the reference's copy) implements: block-Jacobi preconditioner (the pdim x pdim diagonal block of every keyframe,
-// inverted once per solve), CG on S x = b, stop at sqrt(r'M^-1 r / r0'M^-1 r0) <= 1e-10 or after 20 n_p iterations.
+// from the reference's copy) implements, CG on S x = b with a block preconditioner -- block-tridiagonal over the keyframe chain
+// (round 4, below; VBA_PCG_JACOBI=1: the block-Jacobi of rounds 1-3, the pdim x pdim diagonal block of every keyframe), stop at sqrt(r'M^-1 r / r0'M^-1 r0) <= 1e-10 or after 20 n_p iterations.
 //
 // S is the matrix the Schur kernels assemble (lower triangle, block-sparse by keyframe pair).  k_pcg_init mirrors its non-zero
 // blocks above the diagonal once per solve, so that every product walks rows, and inverts the diagonal blocks; one CG iteration
@@ -21,6 +21,8 @@
 #include "vba_kernels.h"
 
 #define PCG_TOL 1e-10
+#define PCG_MBLK 450   // doubles of preconditioner data per keyframe: D_a^-1 (225), G_a (225)
+DEVI double* pcg_vec(const Batch& B, const WinDesc& d, int which) { return B.pcg_v + 5 * (size_t)d.vec0 + (size_t)which * d.nS; }   // x r z p q
 
 // Cholesky-based inverse of the SPD pdim x pdim diagonal blocks (pdim <= 15) of one window: sixteen lanes per block -- a lane per
 // row of L, then per column of L^-1, then per row of the inverse -- with the block, L (in place) and L^-1 in LDS.  (First version: one
@@ -30,7 +32,7 @@
 DEVI void pcg_block_inverses(const Batch& B, const WinDesc& d, double (*sA)[15 * PCG_BI_STRIDE], double (*sLi)[15 * PCG_BI_STRIDE], int* bad) {
     const int t = threadIdx.x, g = t >> 4, i = t & 15, P = d.pdim, nf = d.n_free, n = d.nS;
     const double* S = B.S + d.S0;
-    double* Mi = B.pcg_m + 225 * (size_t)d.kf0;
+    double* Mi = B.pcg_m + PCG_MBLK * (size_t)d.kf0;
     for (int a0 = 0; a0 < nf; a0 += 16) {
         const int a = a0 + g;
         const bool act = a < nf && i < P;
@@ -63,7 +65,7 @@ DEVI void pcg_block_inverses(const Batch& B, const WinDesc& d, double (*sA)[15 *
         }
         __syncthreads();
         if (act) {   // row i of A^-1 = L^-T L^-1
-            double* out = Mi + 225 * (size_t)a + i * P;
+            double* out = Mi + PCG_MBLK * (size_t)a + i * P;
             for (int j = 0; j < P; j++) {
                 double s = 0.0;
                 for (int k = (i > j ? i : j); k < P; k++) s += Li[k * PCG_BI_STRIDE + i] * Li[k * PCG_BI_STRIDE + j];
@@ -74,26 +76,196 @@ DEVI void pcg_block_inverses(const Batch& B, const WinDesc& d, double (*sA)[15 *
     }
 }
 
-// per-window CG state lives in WinCtrl-independent scratch: pcg_s[8 * win + ..] = rz, rz0, done, iterations, bad
+// per-window CG state lives in WinCtrl-independent scratch: pcg_s[8 * win + ..] = rz, rz0, done, iterations, bad, preconditioner
 #define PCG_RZ 0
 #define PCG_RZ0 1
 #define PCG_DONE 2
 #define PCG_ITS 3
 #define PCG_BAD 4
+#define PCG_MODE 5    // 1: block-tridiagonal (keyframe chain) preconditioner, 0: block-Jacobi (fallback)
 #define PCG_STATE 8
+
+// ---- block-tridiagonal preconditioner (round 4) -------------------------------------------------------------------------------
+// Block-Jacobi ignores exactly the coupling that makes cond(S) ~ 5e9: the IMU chain ties the velocity / bias blocks of consecutive
+// keyframes together with information up to 2.5e9 (src/IMU/imudata.cpp:25, src/Optimizer.cpp:244-249).  M = the block-tridiagonal
+// part of S in keyframe order -- the 15x15 diagonal blocks and the blocks (a, a-1), IMU and vision terms alike -- factored once per
+// solve as M = L D L^T (block Thomas: D_a = S_aa - C_a D_{a-1}^-1 C_a^T, L_{a,a-1} = G_a = C_a D_{a-1}^-1) and applied per CG
+// iteration with one forward and one backward sweep over the keyframes (one wave per window, the next keyframe's blocks in
+// flight while the current one is multiplied).  The truncation of an SPD matrix need not be SPD: if a D_a is not positive definite
+// the window falls back to block-Jacobi.  pcg_m holds per keyframe D_a^-1 (225) and G_a (225).
+// the inverse of one SPD P x P block (P <= 15) in LDS: threads 0..15 work, EVERY thread of the workgroup passes the barriers
+DEVI void pcg_inv_block(double* A, double* Li, double* out, int P, int* bad) {
+    const int i = threadIdx.x;
+    const bool act = i < P;
+    for (int j = 0; j < P; j++) {   // column j of L (in place)
+        if (act && i == j) {
+            double s = A[j * PCG_BI_STRIDE + j];
+            for (int k = 0; k < j; k++) s -= A[j * PCG_BI_STRIDE + k] * A[j * PCG_BI_STRIDE + k];
+            if (!(s > 0.0)) *bad = 1;
+            A[j * PCG_BI_STRIDE + j] = sqrt(s);
+        }
+        __syncthreads();
+        if (act && i > j) {
+            double s = A[i * PCG_BI_STRIDE + j];
+            for (int k = 0; k < j; k++) s -= A[i * PCG_BI_STRIDE + k] * A[j * PCG_BI_STRIDE + k];
+            A[i * PCG_BI_STRIDE + j] = s / A[j * PCG_BI_STRIDE + j];
+        }
+        __syncthreads();
+    }
+    if (act)
+        for (int r = i; r < P; r++) {   // column i of L^-1
+            double s = (r == i) ? 1.0 : 0.0;
+            for (int k = i; k < r; k++) s -= A[r * PCG_BI_STRIDE + k] * Li[k * PCG_BI_STRIDE + i];
+            Li[r * PCG_BI_STRIDE + i] = s / A[r * PCG_BI_STRIDE + r];
+        }
+    __syncthreads();
+    if (act)
+        for (int j = 0; j < P; j++) {   // row i of A^-1 = L^-T L^-1
+            double s = 0.0;
+            for (int k = (i > j ? i : j); k < P; k++) s += Li[k * PCG_BI_STRIDE + i] * Li[k * PCG_BI_STRIDE + j];
+            out[i * PCG_BI_STRIDE + j] = s;
+        }
+    __syncthreads();
+}
+// block Thomas factorisation of the tridiagonal part (256 threads, S already mirrored); returns through *bad
+DEVI void pcg_tridiag_factor(const Batch& B, const WinDesc& d, double* sA, double* sLi, double* sDi, double* sC, double* sG, int* bad) {
+    const int t = threadIdx.x, P = d.pdim, nf = d.n_free, n = d.nS;
+    const double* S = B.S + d.S0;
+    double* M = B.pcg_m + PCG_MBLK * (size_t)d.kf0;
+    const int r = t / 15, q = t % 15;   // one entry of a P x P block per thread (t < 225)
+    const bool ent = t < 225 && r < P && q < P;
+    for (int a = 0; a < nf; a++) {
+        double v = 0.0;
+        if (ent) v = S[(size_t)vpos(d, a, r) * n + vpos(d, a, q)];
+        if (a > 0) {
+            if (ent) sC[r * PCG_BI_STRIDE + q] = S[(size_t)vpos(d, a, r) * n + vpos(d, a - 1, q)];
+            __syncthreads();
+            if (ent) {   // G_a = C_a D_{a-1}^-1
+                double g = 0.0;
+                for (int k = 0; k < P; k++) g += sC[r * PCG_BI_STRIDE + k] * sDi[k * PCG_BI_STRIDE + q];
+                sG[r * PCG_BI_STRIDE + q] = g;
+                M[PCG_MBLK * (size_t)a + 225 + r * P + q] = g;
+            }
+            __syncthreads();
+            if (ent)     // D_a = S_aa - G_a C_a^T
+                for (int k = 0; k < P; k++) v -= sG[r * PCG_BI_STRIDE + k] * sC[q * PCG_BI_STRIDE + k];
+        }
+        if (ent) sA[r * PCG_BI_STRIDE + q] = v;
+        __syncthreads();
+        pcg_inv_block(sA, sLi, sDi, P, bad);
+        if (ent) M[PCG_MBLK * (size_t)a + r * P + q] = sDi[r * PCG_BI_STRIDE + q];
+        __syncthreads();
+        if (*bad) return;   // (uniform: read behind a barrier)
+    }
+}
+// z = M^-1 r with the factors above: ONE wave (lanes: row = lane & 15, four lanes share a row's dot product); y lives in LDS
+DEVI void pcg_precond_tri(const Batch& B, const WinDesc& d, double* y) {
+    const int lane = threadIdx.x & 63, r = lane & 15, part = lane >> 4, P = d.pdim, nf = d.n_free;
+    const double* M = B.pcg_m + PCG_MBLK * (size_t)d.kf0;
+    const double* rs = pcg_vec(B, d, 1);
+    double* zs = pcg_vec(B, d, 2);
+    const bool row = r < P;
+    auto dot4 = [&](const double (&m)[4], const double* x) {   // this lane's share: columns part, part + 4, part + 8, part + 12
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int c = part + 4 * u; if (c < P) s += m[u] * x[c]; }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        return s;
+    };
+    auto load4 = [&](const double* blk, bool transposed, double (&m)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int c = part + 4 * u; m[u] = (row && c < P) ? (transposed ? blk[c * P + r] : blk[r * P + c]) : 0.0; }
+    };
+    // The sweeps are chains of nf dependent 15x15 products; what they must never wait for is memory: the blocks of the next PF
+    // keyframes are always in flight (a block comes from L2 in ~1-2 us, a step takes ~0.1 us; with one step of look-ahead a
+    // C4 sweep cost 0.7 ms per CG iteration).
+    constexpr int PF = 8;
+    // forward: y_a = r_a - G_a y_{a-1}
+    {
+        double g[PF][4], rv[PF];
+        // (every fetch issues the same loads whatever a is -- out-of-range keyframes are clamped and their values never used: a load
+        // under a branch makes the compiler wait for ALL outstanding loads, vmcnt(0), at the next use)
+        auto fetch = [&](int a, int slot) {
+            const int ac = a < 1 ? 1 : (a >= nf ? nf - 1 : a);
+            load4(M + PCG_MBLK * (size_t)(nf > 1 ? ac : 0) + 225, false, g[slot]);
+            rv[slot] = rs[vpos(d, a < nf ? a : nf - 1, row ? r : 0)];
+        };
+#pragma unroll
+        for (int u = 0; u < PF; u++) fetch(u, u);
+        int a0 = 0;
+        for (; a0 + PF <= nf; a0 += PF) {            // whole groups: straight-line code, the loads counted exactly
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int a = a0 + u;
+                double v = rv[u];
+                const double dp = dot4(g[u], y + 16 * (a > 0 ? a - 1 : 0));
+                v = (a > 0) ? v - dp : v;
+                fetch(a + PF, u);                     // (the slot is free: its block has just been used)
+                if (part == 0 && row) y[16 * a + r] = v;
+                wave_lds_sync();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {                // the last nf % PF keyframes: their blocks are in the slots already
+            const int a = a0 + u;
+            if (a < nf) {
+                double v = rv[u];
+                if (a > 0) v -= dot4(g[u], y + 16 * (a - 1));
+                if (part == 0 && row) y[16 * a + r] = v;
+                wave_lds_sync();
+            }
+        }
+    }
+    // backward: z_a = D_a^-1 y_a - G_{a+1}^T z_{a+1}   (z overwrites y in LDS)
+    {
+        double di[PF][4], gt[PF][4];
+        auto fetch = [&](int a, int slot) {   // what keyframe a needs: D_a^-1 and G_{a+1}^T (clamped like above)
+            const int ac = a < 0 ? 0 : a;
+            load4(M + PCG_MBLK * (size_t)ac, false, di[slot]);
+            load4(M + PCG_MBLK * (size_t)(ac + 1 < nf ? ac + 1 : ac) + 225, true, gt[slot]);
+        };
+#pragma unroll
+        for (int u = 0; u < PF; u++) fetch(nf - 1 - u, u);
+        int a0 = nf - 1;
+        for (; a0 - PF + 1 >= 0; a0 -= PF) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const int a = a0 - u;
+                double v = dot4(di[u], y + 16 * a);
+                const double dp = dot4(gt[u], y + 16 * (a + 1 < nf ? a + 1 : a));
+                v = (a + 1 < nf) ? v - dp : v;
+                fetch(a - PF, u);
+                wave_lds_sync();
+                if (part == 0 && row) { y[16 * a + r] = v; zs[vpos(d, a, r)] = v; }
+                wave_lds_sync();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int a = a0 - u;
+            if (a >= 0) {
+                double v = dot4(di[u], y + 16 * a);
+                if (a + 1 < nf) v -= dot4(gt[u], y + 16 * (a + 1));
+                wave_lds_sync();
+                if (part == 0 && row) { y[16 * a + r] = v; zs[vpos(d, a, r)] = v; }
+                wave_lds_sync();
+            }
+        }
+    }
+}
 #define PCG_ROWS 64   // rows per matvec workgroup
 
-DEVI double* pcg_vec(const Batch& B, const WinDesc& d, int which) { return B.pcg_v + 5 * (size_t)d.vec0 + (size_t)which * d.nS; }   // x r z p q
 
 // z = M^-1 r for rows [i0, i1) of the window, one thread per row
 DEVI void pcg_precond(const Batch& B, const WinDesc& d, int t, int nt) {
     const int P = d.pdim;
-    const double* Mi = B.pcg_m + 225 * (size_t)d.kf0;
+    const double* Mi = B.pcg_m + PCG_MBLK * (size_t)d.kf0;
     const double* rs = pcg_vec(B, d, 1);
     double* zs = pcg_vec(B, d, 2);
     for (int i = t; i < P * d.n_free; i += nt) {
         const int a = i / P, r = i % P;
-        const double* m = Mi + 225 * (size_t)a + r * P;
+        const double* m = Mi + PCG_MBLK * (size_t)a + r * P;
         double s = 0.0;
         for (int q = 0; q < P; q++) s += m[q] * rs[vpos(d, a, q)];
         zs[vpos(d, a, r)] = s;
@@ -105,6 +277,7 @@ __global__ void __launch_bounds__(256) k_pcg_init(Batch B) {
     __shared__ double red[4];
     __shared__ int sh_bad;
     __shared__ double sA[16][15 * PCG_BI_STRIDE], sLi[16][15 * PCG_BI_STRIDE];
+    extern __shared__ double pcg_y[];   // 16 doubles per keyframe: the sweeps of the tridiagonal preconditioner
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
     const WinCtrl& c = B.ctrl[w];
@@ -129,7 +302,13 @@ __global__ void __launch_bounds__(256) k_pcg_init(Batch B) {
         }
     }
     __syncthreads();
-    pcg_block_inverses(B, d, sA, sLi, &sh_bad);
+    int mode = B.pcg_tri ? 1 : 0;
+    if (mode) {   // block Thomas on the tridiagonal part; not positive definite -> block-Jacobi
+        pcg_tridiag_factor(B, d, sA[0], sLi[0], sA[1], sA[2], sA[3], &sh_bad);
+        __syncthreads();
+        if (sh_bad) { mode = 0; __syncthreads(); if (t == 0) sh_bad = 0; __syncthreads(); }
+    }
+    if (!mode) pcg_block_inverses(B, d, sA, sLi, &sh_bad);
     double *xs = pcg_vec(B, d, 0), *rs = pcg_vec(B, d, 1), *zs = pcg_vec(B, d, 2), *ps = pcg_vec(B, d, 3);
     const double* rhs = B.vec + d.vec0;
     for (int i = t; i < np; i += 256) { xs[i] = 0.0; rs[i] = rhs[i]; }
@@ -138,12 +317,14 @@ __global__ void __launch_bounds__(256) k_pcg_init(Batch B) {
         if (t == 0) { st[PCG_DONE] = 1.0; st[PCG_BAD] = 1.0; st[PCG_ITS] = 0.0; }
         return;
     }
-    pcg_precond(B, d, t, 256);
+    if (mode) { if (t < 64) pcg_precond_tri(B, d, pcg_y); }
+    else pcg_precond(B, d, t, 256);
     __syncthreads();
     double loc = 0.0;
     for (int i = t; i < np; i += 256) { ps[i] = zs[i]; loc += rs[i] * zs[i]; }
     const double rz = block_sum256(loc, red);
     if (t == 0) {
+        st[PCG_MODE] = (double)mode;
         st[PCG_RZ] = rz; st[PCG_RZ0] = rz; st[PCG_ITS] = 0.0; st[PCG_BAD] = 0.0;
         st[PCG_DONE] = (rz > 0.0) ? 0.0 : 1.0;   // zero right-hand side: x = 0
     }
@@ -195,6 +376,7 @@ __global__ void __launch_bounds__(256) k_pcg_matvec(Batch B) {
 // the rest of the iteration, one workgroup per window
 __global__ void __launch_bounds__(256) k_pcg_step(Batch B, int* alive) {
     __shared__ double red[4];
+    extern __shared__ double pcg_y[];
     const int w = blockIdx.x;
     const WinDesc& d = B.desc[w];
     double* st = B.pcg_s + PCG_STATE * (size_t)d.win;
@@ -215,7 +397,8 @@ __global__ void __launch_bounds__(256) k_pcg_step(Batch B, int* alive) {
     double *xs = pcg_vec(B, d, 0), *rs = pcg_vec(B, d, 1), *zs = pcg_vec(B, d, 2), *ps = pcg_vec(B, d, 3), *qs = pcg_vec(B, d, 4);
     for (int i = t; i < np; i += 256) { xs[i] += alpha * ps[i]; rs[i] -= alpha * qs[i]; }
     __syncthreads();
-    pcg_precond(B, d, t, 256);
+    if (st[PCG_MODE] != 0.0) { if (t < 64) pcg_precond_tri(B, d, pcg_y); }
+    else pcg_precond(B, d, t, 256);
     __syncthreads();
     loc = 0.0;
     for (int i = t; i < np; i += 256) loc += rs[i] * zs[i];

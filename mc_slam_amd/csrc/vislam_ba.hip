@@ -760,7 +760,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     if (pcg) {
         adjbeg.resize((size_t)kf0 + n, 0);
         if (h2d_vec(h, BUF_ADJBEG, adjbeg, G.s_int[7]) || h2d_vec(h, BUF_ADJ, adj, G.s_int[8])) return -1;
-        if (dalloc(h, BUF_PCGV, (size_t)vec0 * 5 * 8) || dalloc(h, BUF_PCGM, (size_t)kf0 * 225 * 8) || dalloc(h, BUF_PCGS, (size_t)n * 8 * 8)) return -1;
+        if (dalloc(h, BUF_PCGV, (size_t)vec0 * 5 * 8) || dalloc(h, BUF_PCGM, (size_t)kf0 * 450 * 8) || dalloc(h, BUF_PCGS, (size_t)n * 8 * 8)) return -1;
     }
     if (h2d(h, BUF_PIMUBEG, pimu_begin) || h2d(h, BUF_PIMU, pimu) || h2d_vec(h, BUF_LINBLK, linblk, G.s_int[6])) return -1;
     prun0.resize(linblk.size() / 4 + 1, 0); prefbeg.resize((size_t)kf0 + n + 1, 0); preflist.resize((size_t)pt0 + 1, 0);
@@ -821,6 +821,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     B.item_begin = dp<int>(h, BUF_ITEMBEG); B.items = dp<int>(h, BUF_ITEMS); B.item_mid = dp<int>(h, BUF_ITEMMID);
     B.kf_dir = dp<double>(h, BUF_KFDIR); B.slot_lm = dp<int>(h, BUF_SLOTOBS); B.slot_o = dp<int>(h, BUF_SLOTO); B.rec_lm = dp<int>(h, BUF_PTINV);
     B.adj_begin = dp<int>(h, BUF_ADJBEG); B.adj = dp<int>(h, BUF_ADJ); B.pcg_v = dp<double>(h, BUF_PCGV); B.pcg_m = dp<double>(h, BUF_PCGM); B.pcg_s = dp<double>(h, BUF_PCGS);
+    { static const int jac = getenv("VBA_PCG_JACOBI") ? 1 : 0; B.pcg_tri = jac ? 0 : 1; }
     B.lmask = dp<unsigned long long>(h, BUF_LMASK); B.kf_seg = dp<int>(h, BUF_KFSEG); B.ref_seg = dp<int>(h, BUF_REFSEG);
     B.pimu_begin = dp<int>(h, BUF_PIMUBEG); B.pimu = dp<int>(h, BUF_PIMU);
     B.lin_blk = dp<int>(h, BUF_LINBLK);
@@ -947,7 +948,8 @@ void enqueue_solve_iteration(Handle* h, StopRef stop_flag = StopRef()) {
         // Two launches per CG iteration for all windows of the group; the host enqueues BATCHES of iterations and reads one pinned
         // word per batch (did any window go on?) two batches behind the device.  Converged windows exit at the first instruction.
         ProfScope ps(h, VBA_PROF_FACTOR);
-        VBA_LAUNCH(k_pcg_init, dim3(n), dim3(256), 0, h->stream, B);
+        const size_t pcg_shm = (size_t)h->max_free * 16 * sizeof(double);   // the sweeps of the tridiagonal preconditioner
+        VBA_LAUNCH(k_pcg_init, dim3(n), dim3(256), pcg_shm, h->stream, B);
         const int per_batch = 32, RING = 16, row_blocks = (h->max_nS + PCG_ROWS - 1) / PCG_ROWS;
         volatile int* ring = h->stop_host + 1024 + 16 * h->cur_group;
         int* ring_dev = h->stop_dev + 1024 + 16 * h->cur_group;
@@ -962,7 +964,7 @@ void enqueue_solve_iteration(Handle* h, StopRef stop_flag = StopRef()) {
             ring[b % RING] = 0;
             for (int it = 0; it < per_batch; it++) {
                 VBA_LAUNCH(k_pcg_matvec, dim3(row_blocks, n), dim3(256), 0, h->stream, B);
-                VBA_LAUNCH(k_pcg_step, dim3(n), dim3(256), 0, h->stream, B, ring_dev + (b % RING));
+                VBA_LAUNCH(k_pcg_step, dim3(n), dim3(256), pcg_shm, h->stream, B, ring_dev + (b % RING));
             }
             ev.push_back(get_evt(h));
             (void)hipEventRecord(ev.back(), h->stream);

@@ -2,6 +2,7 @@
 #include "Optimizer.h"
 
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <iostream>
 #include <chrono>
@@ -73,6 +74,40 @@ bool PRVInformation(const std::array<double, 81>& cov, double* info) {
     return true;
 }
 
+// KeyFrame* -> row of the window.  Every observation of the window looks its keyframe up (30 000 times for a 50-keyframe window):
+// an open-addressing table over a few hundred slots instead of a std::map walk (the reference pays optimizer.vertex(id), a
+// tr1::unordered_map look-up, per edge endpoint: Thirdparty/g2o/g2o/core/hyper_graph.cpp:60-66).
+struct KfTable {
+    std::vector<std::pair<const KeyFrame*, int>> slot;
+    size_t mask = 0;
+    void reset(size_t n) {
+        size_t cap = 64;
+        while (cap < 4 * n) cap *= 2;
+        slot.assign(cap, {nullptr, -1});
+        mask = cap - 1;
+    }
+    static size_t hash(const KeyFrame* k) { return (size_t)((reinterpret_cast<uintptr_t>(k) >> 4) * 0x9E3779B97F4A7C15ull >> 20); }
+    void put(const KeyFrame* k, int row) {
+        if (2 * (size_t)(row + 1) > slot.size()) {   // (the fixed keyframes are discovered on the way: grow before the table fills)
+            std::vector<std::pair<const KeyFrame*, int>> old;
+            old.swap(slot);
+            reset(old.size());
+            for (auto& e : old) if (e.first) put(e.first, e.second);
+        }
+        size_t i = hash(k) & mask;
+        while (slot[i].first && slot[i].first != k) i = (i + 1) & mask;
+        slot[i] = {k, row};
+    }
+    int get(const KeyFrame* k) const {
+        size_t i = hash(k) & mask;
+        while (slot[i].first) {
+            if (slot[i].first == k) return slot[i].second;
+            i = (i + 1) & mask;
+        }
+        return -1;
+    }
+};
+
 void FinishProblem(PackedWindow& W) {
     vba_problem& P = W.P;
     P.n_kf = (int32_t)W.vKF.size();
@@ -140,6 +175,12 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
                 lLocalMapPoints.push_back(pMP);
                 pMP->mnBALocalForKF = pCurKF->mnId;
             }
+    // One copy of every map point's observation list serves both passes that read it -- the search for the fixed cameras (:82-127) and
+    // the edges (:337-451); GetObservations() returns the std::map by value (include/MapPoint.h), the reference copies it twice.
+    std::vector<MapPoint*> vLocalMP(lLocalMapPoints.begin(), lLocalMapPoints.end());
+    std::vector<mapMapPointObs> vObs(vLocalMP.size());
+    size_t nObsTotal = 0;
+    for (size_t i = 0; i < vLocalMP.size(); i++) { vObs[i] = vLocalMP[i]->GetObservations(); nObsTotal += vObs[i].size(); }
     std::list<KeyFrame*> lFixedCameras;                                                                           // :82-127
     KeyFrame* pKFPrevLocal = lLocalKeyFrames.front()->GetPrevKeyFrame();
     if (pKFPrevLocal) {
@@ -147,8 +188,8 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
         if (!pKFPrevLocal->isBad()) lFixedCameras.push_back(pKFPrevLocal);
     } else
         std::cerr << "pKFPrevLocal is NULL?" << std::endl;
-    for (MapPoint* pMP : lLocalMapPoints)
-        for (auto& mit : pMP->GetObservations()) {
+    for (size_t i = 0; i < vLocalMP.size(); i++)
+        for (auto& mit : vObs[i]) {
             KeyFrame* pKFi = mit.first;
             if (pKFi->mnBALocalForKF != pCurKF->mnId && pKFi->mnBAFixedForKF != pCurKF->mnId) {
                 pKFi->mnBAFixedForKF = pCurKF->mnId;
@@ -156,10 +197,11 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
             }
         }
     // vertices -> rows: free keyframes (window order = ascending mnId) first, fixed after            (:159-232)
-    std::map<KeyFrame*, int> kfIdx;
-    for (KeyFrame* k : lLocalKeyFrames) { kfIdx[k] = (int)W.vKF.size(); W.vKF.push_back(k); }
+    KfTable kfIdx;
+    kfIdx.reset(lLocalKeyFrames.size() + lFixedCameras.size());
+    for (KeyFrame* k : lLocalKeyFrames) { kfIdx.put(k, (int)W.vKF.size()); W.vKF.push_back(k); }
     W.P.n_kf_free = (int32_t)W.vKF.size();
-    for (KeyFrame* k : lFixedCameras) { kfIdx[k] = (int)W.vKF.size(); W.vKF.push_back(k); }
+    for (KeyFrame* k : lFixedCameras) { kfIdx.put(k, (int)W.vKF.size()); W.vKF.push_back(k); }
     for (KeyFrame* k : W.vKF) {
         const NavState& ns = k->GetNavState();
         const Vector3d P = ns.Get_P(), V = ns.Get_V(), bg = ns.Get_BiasGyr(), ba = ns.Get_BiasAcc(), dbg = ns.Get_dBias_Gyr(), dba = ns.Get_dBias_Acc();
@@ -171,10 +213,10 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
     // IMU factors: one EdgeNavStatePRV + one EdgeNavStateBias per local keyframe                     (:251-312)
     for (KeyFrame* pKF1 : lLocalKeyFrames) {
         KeyFrame* pKF0 = pKF1->GetPrevKeyFrame();
-        if (!pKF0 || !kfIdx.count(pKF0)) { std::cerr << "pKF0 missing" << std::endl; continue; }
+        if (!pKF0 || kfIdx.get(pKF0) < 0) { std::cerr << "pKF0 missing" << std::endl; continue; }
         const IMUPreintegrator& M = pKF1->GetIMUPreInt();
-        W.imuI.push_back(kfIdx[pKF0]);
-        W.imuJ.push_back(kfIdx[pKF1]);
+        W.imuI.push_back(kfIdx.get(pKF0));
+        W.imuJ.push_back(kfIdx.get(pKF1));
         W.meas.push_back(M.getDeltaTime());
         for (double v : M.getDeltaP()) W.meas.push_back(v);
         for (double v : M.getDeltaV()) W.meas.push_back(v);
@@ -184,17 +226,22 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
         if (!PRVInformation(M.getCovPVPhi(), info)) { std::cerr << "singular preintegration covariance" << std::endl; return false; }
         W.info.insert(W.info.end(), info, info + 81);
     }
+    W.obsKF.reserve(nObsTotal); W.uv.reserve(2 * nObsTotal); W.w.reserve(nObsTotal);
+    W.vEdgeKF.reserve(nObsTotal); W.vEdgeMP.reserve(nObsTotal);
+    W.pt.reserve(3 * vLocalMP.size()); W.ref.reserve(vLocalMP.size()); W.refXY.reserve(2 * vLocalMP.size());
+    W.vMP.reserve(vLocalMP.size()); W.begin.reserve(vLocalMP.size() + 1);
     W.begin.push_back(0);
     if (!idp) {   // VertexSBAPointXYZ + one EdgeNavStatePRPointXYZ per observation (:1151-1193)
-        for (MapPoint* pMP : lLocalMapPoints) {
+        for (size_t ip = 0; ip < vLocalMP.size(); ip++) {
+            MapPoint* pMP = vLocalMP[ip];
             double Pw[3];
             pMP->GetWorldPos(Pw);
-            for (auto& mit : pMP->GetObservations()) {
+            for (auto& mit : vObs[ip]) {
                 KeyFrame* pKFi = mit.first;
                 if (pKFi->isBad()) continue;
                 if (pKFi->mvuRight[mit.second] >= 0) { std::cerr << "Stereo not supported yet" << std::endl; continue; }
                 const KeyPoint& kpUn = pKFi->mvKeysUn[mit.second];
-                W.obsKF.push_back(kfIdx[pKFi]);
+                W.obsKF.push_back(kfIdx.get(pKFi));
                 W.uv.push_back(kpUn.pt.x); W.uv.push_back(kpUn.pt.y);
                 W.w.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);
                 W.vEdgeKF.push_back(pKFi);
@@ -208,8 +255,9 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
         }
     }
     // landmarks and EdgePRIDP edges                                                                   (:337-451)
-    for (MapPoint* pMP : lLocalMapPoints) {
+    for (size_t ip = 0; ip < vLocalMP.size(); ip++) {
         if (!idp) break;
+        MapPoint* pMP = vLocalMP[ip];
         double Pw[3];
         pMP->GetWorldPos(Pw);
         KeyFrame* pRefKF = pMP->GetReferenceKeyFrame();
@@ -219,9 +267,10 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
         pRefKF->GetTranslation(tcw);
         const double dc = Rcw[6] * Pw[0] + Rcw[7] * Pw[1] + Rcw[8] * Pw[2] + tcw[2];                             // :355-358
         if (dc < 0.01) continue;                                                                                 // :360-365
-        mapMapPointObs observations = pMP->GetObservations();
-        if (!observations.count(pRefKF)) { std::cerr << "!observations.count(pRefKF)" << std::endl; continue; }
-        const KeyPoint& kpRefUn = pRefKF->mvKeysUn[observations[pRefKF]];
+        const mapMapPointObs& observations = vObs[ip];
+        const auto itRef = observations.find(pRefKF);
+        if (itRef == observations.end()) { std::cerr << "!observations.count(pRefKF)" << std::endl; continue; }
+        const KeyPoint& kpRefUn = pRefKF->mvKeysUn[itRef->second];
         const double normx = (kpRefUn.pt.x - pRefKF->cx) / pRefKF->fx, normy = (kpRefUn.pt.y - pRefKF->cy) / pRefKF->fy;  // :382-385
         const size_t nBefore = W.obsKF.size();
         for (auto& mit : observations) {
@@ -229,7 +278,7 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
             if (pKFi == pRefKF || pKFi->isBad()) continue;                                                       // :395-400
             if (pKFi->mvuRight[mit.second] >= 0) { std::cerr << "Stereo not supported yet" << std::endl; continue; }
             const KeyPoint& kpUn = pKFi->mvKeysUn[mit.second];
-            W.obsKF.push_back(kfIdx[pKFi]);
+            W.obsKF.push_back(kfIdx.get(pKFi));
             W.uv.push_back(kpUn.pt.x); W.uv.push_back(kpUn.pt.y);
             W.w.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);                                                  // float -> double, :428-429
             W.vEdgeKF.push_back(pKFi);
@@ -237,7 +286,7 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
         }
         if (W.obsKF.size() == nBefore) continue;  // no edge -> the vertex is never added (:407-412, 588-589)
         W.pt.insert(W.pt.end(), {1.0 / dc, normx, normy});
-        W.ref.push_back(kfIdx[pRefKF]);
+        W.ref.push_back(kfIdx.get(pRefKF));
         W.refXY.push_back(normx); W.refXY.push_back(normy);
         W.vMP.push_back(pMP);
         W.begin.push_back((int32_t)W.obsKF.size());

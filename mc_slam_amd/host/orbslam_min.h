@@ -181,10 +181,7 @@ public:
         T[15] = 1.0f;
         SetPose(T);
     }
-    void EraseMapPointMatch(MapPoint* pMP) {
-        for (auto& m : mvpMapPoints)
-            if (m == pMP) m = nullptr;
-    }
+    void EraseMapPointMatch(MapPoint* pMP);   // src/KeyFrame.cpp:573-579: through pMP->GetIndexInKeyFrame(this) (below MapPoint)
     std::vector<KeyFrame*> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
 
     // state (public here: the test harness fills it)
@@ -212,6 +209,10 @@ public:
     mapMapPointObs GetObservations() { return mObservations; }
     KeyFrame* GetReferenceKeyFrame() { return mpRefKF; }
     void EraseObservation(KeyFrame* pKF) { mObservations.erase(pKF); }
+    int GetIndexInKeyFrame(KeyFrame* pKF) {   // src/MapPoint.cpp: the keypoint index of this point in pKF, -1 if pKF does not observe it
+        const auto it = mObservations.find(pKF);
+        return it == mObservations.end() ? -1 : (int)it->second;
+    }
     void UpdateNormalAndDepth() { ++nNormalUpdates; }  // bookkeeping of the map, out of scope
 
     mapMapPointObs mObservations;
@@ -249,5 +250,9 @@ public:
 };
 
 inline bool cmpKeyFrameId::operator()(const KeyFrame* a, const KeyFrame* b) const { return a->mnId < b->mnId; }
+inline void KeyFrame::EraseMapPointMatch(MapPoint* pMP) {
+    const int idx = pMP->GetIndexInKeyFrame(this);
+    if (idx >= 0) mvpMapPoints[idx] = nullptr;
+}
 
 }  // namespace ORB_SLAM2

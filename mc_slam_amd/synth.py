@@ -392,22 +392,24 @@ def config_c3(seed=3, n_kf=50, n_pt=5000, n_obs=30000, landmark_order="random"):
     return make_window(abi.VARIANT_PRV_IDP, n_kf=n_kf, n_fixed=1, n_pt=n_pt, n_obs=n_obs, seed=seed, landmark_order=landmark_order)
 
 
-def config_c3_ragged(seed=3, landmark_order="random"):
+def config_c3_ragged(seed=3, landmark_order="random", kinds=True):
     """A LocalBAPRVIDP window whose size is drawn around BASELINE configs[2]: 40..60 keyframes (mean 50), 100 landmarks per
     keyframe, 6 edges per landmark (mean 5 000 / 30 000) -- so that the windows of a batch differ in size, co-visibility and
     ITERATION COUNTS the way the windows of a real session do (everything depends on the seed only).  Three kinds of window:
     60 %: one-pixel keypoint noise and 2..8 % gross outliers (the window still holds the mismatches of its newest keyframes):
           Gauss-Newton runs 5 + 3 iterations;
     20 %: no gross outliers left (earlier passes erased them), keypoint noise 0.3 px: 4..5 + 2;
-    20 %: no gross outliers, 0.1 px: 3..4 + 1 (the |dchi2| < 1e-3 stop is absolute, so it comes earlier where chi2 is small)."""
+    20 %: no gross outliers, 0.1 px: 3..4 + 1 (the |dchi2| < 1e-3 stop is absolute, so it comes earlier where chi2 is small).
+    kinds=False: the iteration mix of round 2 -- every window of the first kind (the same sizes, all 5 + 3), so that a rate can be
+    compared like for like across rounds (bench.py --iteration-mix r2)."""
     r = np.random.default_rng(1000003 * seed + 17)
     n_kf = int(r.integers(40, 61))
     outlier_frac = float(r.uniform(0.02, 0.08))
     kind = float(r.uniform())
     pix = 1.0
-    if kind >= 0.8:
+    if kinds and kind >= 0.8:
         outlier_frac, pix = 0.0, 0.1
-    elif kind >= 0.6:
+    elif kinds and kind >= 0.6:
         outlier_frac, pix = 0.0, 0.3
     return make_window(abi.VARIANT_PRV_IDP, n_kf=n_kf, n_fixed=1, n_pt=100 * n_kf, n_obs=600 * n_kf, seed=seed,
                        outlier_frac=outlier_frac, pix_noise=pix, landmark_order=landmark_order)
