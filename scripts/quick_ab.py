@@ -7,7 +7,8 @@ from mc_slam_amd import synth, backend
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-p = synth.config_c3(seed=3)
+order = sys.argv[3] if len(sys.argv) > 3 else "caller"
+p = synth.config_c3(seed=3, landmark_order=order)
 ba = backend.LocalBA(0)
 ts = []
 for i in range(25):
@@ -20,7 +21,7 @@ for i in range(25):
     ts.append(time.perf_counter() - t0)
 ts = np.array(ts[4:]) * 1e3
 print("single window: median %.3f ms  min %.3f ms" % (np.median(ts), ts.min()))
-wins = [synth.config_c3(seed=100 + i) for i in range(16)]
+wins = [synth.config_c3(seed=100 + i, landmark_order=order) for i in range(16)]
 batch = [wins[i % 16] for i in range(n)]
 ba.upload(batch)
 ba.run()
