@@ -3,6 +3,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <chrono>
@@ -164,6 +166,8 @@ bool Optimizer::PackLocalBundleAdjustmentNavStatePRV(KeyFrame* pCurKF, const std
 // (LocalBAPRVIDP, :32-625) or world XYZ (LocalBundleAdjustmentNavStatePRV, :937-1388)
 bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocalKeyFrames, const Vector3d& gw, bool idp,
                             PackedWindow& W) {
+    static const bool ptm = getenv("VBA_FACADE_TIMING") != nullptr;
+    double tp[8]; int ti = 0; tp[ti++] = NowMs();
     W = PackedWindow();
     std::memset(&W.P, 0, sizeof W.P);
     if (pCurKF != lLocalKeyFrames.back()) std::cerr << "pCurKF != lLocalKeyFrames.back. check" << std::endl;  // :37-38
@@ -175,12 +179,14 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
                 lLocalMapPoints.push_back(pMP);
                 pMP->mnBALocalForKF = pCurKF->mnId;
             }
+    tp[ti++] = NowMs();
     // One copy of every map point's observation list serves both passes that read it -- the search for the fixed cameras (:82-127) and
     // the edges (:337-451); GetObservations() returns the std::map by value (include/MapPoint.h), the reference copies it twice.
     std::vector<MapPoint*> vLocalMP(lLocalMapPoints.begin(), lLocalMapPoints.end());
     std::vector<mapMapPointObs> vObs(vLocalMP.size());
     size_t nObsTotal = 0;
     for (size_t i = 0; i < vLocalMP.size(); i++) { vObs[i] = vLocalMP[i]->GetObservations(); nObsTotal += vObs[i].size(); }
+    tp[ti++] = NowMs();
     std::list<KeyFrame*> lFixedCameras;                                                                           // :82-127
     KeyFrame* pKFPrevLocal = lLocalKeyFrames.front()->GetPrevKeyFrame();
     if (pKFPrevLocal) {
@@ -196,6 +202,7 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
                 if (!pKFi->isBad()) lFixedCameras.push_back(pKFi);
             }
         }
+    tp[ti++] = NowMs();
     // vertices -> rows: free keyframes (window order = ascending mnId) first, fixed after            (:159-232)
     KfTable kfIdx;
     kfIdx.reset(lLocalKeyFrames.size() + lFixedCameras.size());
@@ -226,6 +233,7 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
         if (!PRVInformation(M.getCovPVPhi(), info)) { std::cerr << "singular preintegration covariance" << std::endl; return false; }
         W.info.insert(W.info.end(), info, info + 81);
     }
+    tp[ti++] = NowMs();
     W.obsKF.reserve(nObsTotal); W.uv.reserve(2 * nObsTotal); W.w.reserve(nObsTotal);
     W.vEdgeKF.reserve(nObsTotal); W.vEdgeMP.reserve(nObsTotal);
     W.pt.reserve(3 * vLocalMP.size()); W.ref.reserve(vLocalMP.size()); W.refXY.reserve(2 * vLocalMP.size());
@@ -292,6 +300,7 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
         W.begin.push_back((int32_t)W.obsKF.size());
         W.P.K[0] = pRefKF->fx; W.P.K[1] = pRefKF->fy; W.P.K[2] = pRefKF->cx; W.P.K[3] = pRefKF->cy;              // :422
     }
+    tp[ti++] = NowMs();
     W.P.variant = idp ? VBA_VARIANT_PRV_IDP : VBA_VARIANT_PRV_XYZ;
     W.P.algo = idp ? VBA_ALGO_GN : VBA_ALGO_LM;                                                                   // :136 / :1028
     Matrix3d Rcb; Vector3d tcb;
@@ -302,6 +311,8 @@ bool Optimizer::PackLocalVI(KeyFrame* pCurKF, const std::list<KeyFrame*>& lLocal
     W.P.depth_min = idp ? 0.01 : 0.0; W.P.rho_min = 2e-6;                                                         // g2otypes.h:122-127 / :300-303, :484
     if (W.vMP.empty() || W.obsKF.empty()) return false;   // an empty graph: the reference's optimize() changes nothing
     FinishProblem(W);
+    tp[ti++] = NowMs();
+    if (ptm) { fprintf(stderr, "[facade] pack:"); for (int i = 1; i < ti; i++) fprintf(stderr, " %.3f", tp[i] - tp[i - 1]); fprintf(stderr, " ms (marks+list | obs copies | fixed cams | rows+imu | edges | finish)\n"); }
     return true;
 }
 
