@@ -493,7 +493,7 @@ def main():
         tile_products = None
         if batch[0].variant != 0:   # visual-inertial windows: tile products of the symbolic factorisation under both elimination orders
             import ctypes as C
-            tp = np.zeros((len(wins), 4), dtype=np.int64)
+            tp = np.zeros((len(wins), 5), dtype=np.int64)
             bh = backend.LocalBA(local_rank, hooks=True)   # (a diagnostic of the symbolic factorisation: the hooks flavour of the library)
             bh.upload(wins)
             for i in range(len(wins)):
@@ -501,7 +501,9 @@ def main():
             bh.close()
             if (tp[:, 0] >= 0).all():
                 tile_products = {"vbias_first_mean": float(tp[:, 0].mean()), "keyframe_order_mean": float(tp[:, 1].mean()),
-                                 "windows_in_keyframe_order": int(tp[:, 2].sum()), "chosen_mean": float(tp[:, 3].mean())}
+                                 "two_sided_mean": float(tp[:, 4].mean()) if (tp[:, 4] >= 0).all() else None,
+                                 "windows_in_keyframe_order": int((tp[:, 2] == 1).sum()), "windows_two_sided": int((tp[:, 2] == 2).sum()),
+                                 "chosen_mean": float(tp[:, 3].mean())}
         rng = lambda f: [int(min(f(w) for w in wins)), int(max(f(w) for w in wins))]
         out = {
             "metric": {"c3": "LocalBA windows/sec (50 KF, 5k pts, 30k obs, IMU edges)",

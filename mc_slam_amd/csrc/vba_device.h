@@ -51,6 +51,9 @@ struct WinDesc {
     int ct0;        // offset (records of four ints) of the window's chain-column table (Structure::chain_tab)
     int cu0, n_cu;  // few-window regime: the window's tiles that collect updates from chain columns (k_chol_chain_upd)
     int vp_pr0, vp_prs, vp_vb0, vp_vbs;  // position of dof r of free keyframe a: r < 6 ? pr0 + prs a + r : vb0 + vbs a + r - 6
+    int vp_h, vp_vb1;   // order 2 (two-sided): the V/Bias block of keyframe a >= vp_h sits at vp_vb1 - 9 a (other orders: vp_h = INT_MAX)
+    int pad0[3], padn[3];  // rows of S that belong to no variable (identity): up to three ranges (order 2 pads each chain and the tail)
+    int nc_split;       // > 0: the chain columns [0, nc_split) and [nc_split, nc) are independent (k_chol_chain_rows walks them side by side)
     long long S0;   // offset (doubles) into S
     long long mask0; // offset (64-bit words) of the window's landmark masks (n_pt x mwords)
     int mwords;      // 64-bit words per landmark mask = ceil(n_kf / 64)
@@ -244,7 +247,7 @@ DEVI void so3inv(const double* a, double* o) {
 // blocks first (9 per keyframe, chain order) and all PR blocks last: the V/Bias part of the factor then
 // stays block-banded and whole 32x32 tiles of L are structurally zero (skipped by the tile lists).
 DEVI int vpos(const WinDesc& d, int a, int r) {
-    return r < 6 ? d.vp_pr0 + d.vp_prs * a + r : d.vp_vb0 + d.vp_vbs * a + (r - 6);
+    return r < 6 ? d.vp_pr0 + d.vp_prs * a + r : (a < d.vp_h ? d.vp_vb0 + d.vp_vbs * a : d.vp_vb1 - 9 * a) + (r - 6);
 }
 DEVI double rl64(double v, int lane) {  // wave-uniform broadcast of one lane's double
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);

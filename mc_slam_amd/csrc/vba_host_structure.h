@@ -38,24 +38,54 @@ struct Structure {
     int mwords = 1;
     long long item_cap = 0;            // upper bound of the off-diagonal items (exact when every keyframe is free)
     int order = 0;                     // elimination order of the reduced system (see below)
-    long long prod_order[2] = {-1, -1}; // tile products of the symbolic factorisation under order 0 / order 1 (-1: not evaluated)
+    long long prod_order[3] = {-1, -1, -1}; // tile products of the symbolic factorisation under orders 0 / 1 / 2 (-1: not evaluated)
     std::vector<int> kl_begin, klist;  // left-looking factorisation: per column entry the steps k < J that update it
     // Chain columns: the leading block columns J < nc whose row of L has no tile left of (J, J-1) -- the V/Bias blocks of the IMU chain
     // under the V/Bias-first order.  One launch walks them per window (k_chol_chain) instead of one launch per column.  Few-window
     // regime: `cu` lists the tiles (I,J), J >= nc, that collect updates from chain columns -- (I << 16 | J, first and end position of the chain columns in its k list, 0) per tile
     // (k_chol_chain_upd brings them up to date in one launch before the per-column steps take over).
     int nc = 0;
+    int nc_split = 0;                  // > 0: chain columns [0, nc_split) and [nc_split, nc) do not depend on each other (no tile couples
+                                       // column nc_split - 1 to column nc_split): the few-window chain kernel walks them side by side
+    int nS = 0;                        // rows of the reduced system under the chosen order (a multiple of the tile size)
     std::vector<int> cu;
     std::vector<int> chain_tab;        // per chain column J: (mask lo, mask hi, rides, 0) -- bit q of the mask: tile (nc + q, J) is in the factor;
                                        // rides: tile (J+1, J) is in the factor and J+1 is a chain column
 };
 
+// Order 2 ("two-sided", few windows): the V/Bias blocks first like order 0, but as TWO chains that meet in the middle -- keyframes
+// 0 .. h-1 ascending from position 0, keyframes nf-1 .. h descending from the next tile boundary -- and the PR blocks from the tile
+// boundary behind them.  The chains share no tile, so the chain kernel walks them side by side (7 + 7 block columns in 7 rounds
+// instead of 13 in a row for 49 keyframes); the one coupling between them (keyframes h-1 and h) lands in the last tile of the
+// second chain, which becomes an ordinary column behind the chains.  Pads between the parts are identity rows like the tail pad.
+inline void two_sided_layout(int nf, int& h, int& baseB, int& pr0) {
+    int best = 1 << 30;
+    h = nf / 2; baseB = 0; pr0 = 0;
+    for (int c = std::max(1, nf / 2 - 3); c <= std::min(nf - 1, nf / 2 + 3); c++) {
+        const int TA = (9 * c + VBA_NB - 1) / VBA_NB, TB = (9 * (nf - c) + VBA_NB - 1) / VBA_NB;
+        const int cost = 64 * std::max(TA, TB - 1) + (TA + TB);
+        if (cost < best) { best = cost; h = c; baseB = VBA_NB * TA; pr0 = VBA_NB * (TA + TB); }
+    }
+}
 inline int vpos_host(int order, int pdim, int nf, int a, int r) {
     if (pdim != 15) return 6 * a + r;
+    if (order == 2) {
+        int h, baseB, pr0;
+        two_sided_layout(nf, h, baseB, pr0);
+        return r < 6 ? pr0 + 6 * a + r : (a < h ? 9 * a : baseB + 9 * (nf - 1 - a)) + (r - 6);
+    }
     return order ? 15 * a + r : (r < 6 ? 9 * nf + 6 * a + r : 9 * a + (r - 6));
 }
+inline int order_rows(int order, int pdim, int nf) {   // rows of the reduced system before rounding up to the tile size
+    if (pdim == 15 && order == 2) {
+        int h, baseB, pr0;
+        two_sided_layout(nf, h, baseB, pr0);
+        return pr0 + 6 * nf;
+    }
+    return pdim * nf;
+}
 
-inline int build_structure(const vba_problem* P, Structure& st, std::string& err) {
+inline int build_structure(const vba_problem* P, Structure& st, std::string& err, bool prefer_two_sided = false) {
     auto fail = [&err](int, const char* m) { err = m; return -1; };
     const int h = 0;
     static const bool timing = getenv("VBA_TIMING") != nullptr;
@@ -212,8 +242,9 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
     //   order 1: keyframe by keyframe [PR_a V_a Bias_a] -- a block band whose width is the co-visibility span: best
     //            for long, thin windows and for maps
     const int pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
-    const int np = pdim * nf, nS = ((np + VBA_NB - 1) / VBA_NB) * VBA_NB, nb = nS / VBA_NB;
     auto symbolic = [&](int order, bool lists) -> long long {
+    const int np = order_rows(order, pdim, nf), nS = ((np + VBA_NB - 1) / VBA_NB) * VBA_NB, nb = nS / VBA_NB;
+    st.nS = nS;
     st.tpairs.clear(); st.pan.clear();
     std::vector<unsigned char> T((size_t)nb * nb, 0);
     for (int i = 0; i < nb; i++) T[(size_t)i * nb + i] = 1;
@@ -278,7 +309,11 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
         }
         if (nc == nb && nc > 0) nc--;   // (the last column has nothing to its right: leave it to the per-column kernels)
         st.nc = (chain_min > 0 && nc >= chain_min) ? nc : 0;
+        st.nc_split = 0;
+        for (int J = 1; J < st.nc; J++)    // a column whose predecessor does not couple to it, nearest to the middle
+            if (!T[(size_t)J * nb + (J - 1)] && std::abs(2 * J - st.nc) < std::abs(2 * st.nc_split - st.nc)) st.nc_split = J;
         if (nb - nc > 64) st.nc = 0;      // (the row masks of chain_tab are 64 bits wide)
+        if (!st.nc) st.nc_split = 0;
         st.chain_tab.clear();
         for (int J = 0; J < st.nc; J++) {
             unsigned long long mask = 0;
@@ -332,12 +367,14 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
     static const int env_order = getenv("VBA_ORDER") ? atoi(getenv("VBA_ORDER")) : -1;
     st.order = 0;
     if (pdim == 15) {
-        if (env_order >= 0) st.order = env_order ? 1 : 0;
+        if (env_order >= 0) st.order = std::min(env_order, 2);
         else {
             const long long c0 = symbolic(0, false), c1 = symbolic(1, false);
-            st.prod_order[0] = c0; st.prod_order[1] = c1;
-            st.order = (10 * c1 < 7 * c0) ? 1 : 0;  // only a clear win: a batch that mixes both orders pays for both patterns
-            if (timing) fprintf(stderr, "[vba] tile products of the factorisation: V/Bias-first %lld, keyframe order %lld (nb %d)\n", c0, c1, nb);
+            const long long c2 = (prefer_two_sided && nf >= 12 && P->solver != VBA_SOLVER_PCG) ? symbolic(2, false) : -1;
+            st.prod_order[0] = c0; st.prod_order[1] = c1; st.prod_order[2] = c2;
+            const long long cv = (c2 >= 0 && c2 < c0) ? c2 : c0;   // the better V/Bias-first variant
+            st.order = (10 * c1 < 7 * cv) ? 1 : (cv == c0 ? 0 : 2);  // keyframe order only on a clear win: a batch that mixes patterns pays for each
+            if (timing) fprintf(stderr, "[vba] tile products of the factorisation: V/Bias-first %lld, keyframe order %lld, two-sided %lld\n", c0, c1, c2);
         }
     }
     symbolic(st.order, true);

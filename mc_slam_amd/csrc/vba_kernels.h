@@ -123,8 +123,11 @@ DEVI bool imu_robust(const WinDesc& d) { return !(d.protocol == 1 && !d.robust);
 // upload: identity on the padded diagonal of S (rows np..nS, fewer than VBA_NB of them); the solve never touches the pads
 __global__ void __launch_bounds__(64) k_init_pads(Batch B) {
     const WinDesc& d = B.desc[blockIdx.x];
-    const int i = d.np + threadIdx.x;
-    if (i < d.nS) B.S[d.S0 + (size_t)i * d.nS + i] = 1.0;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int i = d.pad0[q] + threadIdx.x;
+        if ((int)threadIdx.x < d.padn[q]) B.S[d.S0 + (size_t)i * d.nS + i] = 1.0;
+    }
 }
 
 // one PCIe read per control launch instead of one per window

@@ -286,9 +286,9 @@ struct ProfScope {
 using vba_host::Structure;
 using vba_host::vpos_host;
 using vba_host::now_ms;
-int build_structure(Handle* h, const vba_problem* P, Structure& st) {
+int build_structure(Handle* h, const vba_problem* P, Structure& st, bool two_sided = false) {
     std::string err;
-    if (vba_host::build_structure(P, st, err)) return fail(h, err);
+    if (vba_host::build_structure(P, st, err, two_sided)) return fail(h, err);
     if (h->opt_lin_fallback && P->variant != VBA_VARIANT_PRV_IDP) st.linblk.clear();   // test hook: the thread-per-landmark linearisation
     return 0;
 }
@@ -402,7 +402,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     h->arena_on = n <= arena_max;
     h->desc.assign(n, WinDesc());
     h->win_tiles.assign(n, 0);
-    h->win_prod_order.assign(2 * (size_t)n, -1);
+    h->win_prod_order.assign(3 * (size_t)n, -1);
     Staging& G = h->stg;
     auto &pose = G.pose, &vel = G.vel, &bias = G.bias, &pt = G.pt, &uv = G.uv, &ow = G.ow, &meas = G.meas, &info = G.info;
     auto& kffix = G.kffix;
@@ -435,6 +435,10 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     // units idle).  In between: one launch per block column.  VBA_NO_CHAIN: A/B switch, one launch per block column everywhere.
     static const int chain_rl_max = getenv("VBA_CHAIN_RL_MAX") ? atoi(getenv("VBA_CHAIN_RL_MAX")) : 7;
     const bool chain_on = getenv("VBA_NO_CHAIN") == nullptr && !h->opt_no_chain && (use_left_looking(h, n) || n <= chain_rl_max);
+    // the two-sided V/Bias-first order (vba_host_structure.h, order 2) is a candidate for every window: its two half-length chains leave
+    // half the fill in the PR rows (C3: 408 tile products against 581), and the few-window chain kernel walks them side by side.
+    // VBA_ONE_CHAIN: A/B switch, orders 0 and 1 only as before.
+    const bool two_sided = getenv("VBA_ONE_CHAIN") == nullptr;
     // Per chunk of windows: (1) the per-window structure (item lists, IMU lists, symbolic tile factorisation: 0.7 ms for a C3
     // window) on a pool of host threads, (2) descriptors and offsets in window order on this thread, (3) the concatenated
     // arrays grown once, (4) the pool again copies every window's arrays to its offsets (2.2 MB per C3 window).
@@ -513,7 +517,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
         run_pool(cn, [&](int q) {
             const vba_problem* Q = probs[chunk0 + q];
             if (Q->variant < 0 || Q->variant > 2 || Q->n_kf_free <= 0 || Q->n_kf_free > Q->n_kf || Q->n_pt <= 0 || Q->n_obs <= 0 || Q->n_imu < 0) return;  // reported below
-            if (build_structure(h, Q, sts[q])) bad.store(1);
+            if (build_structure(h, Q, sts[q], two_sided)) bad.store(1);
         });
         t_struct += now_ms() - ts0;
         if (bad.load()) return -1;
@@ -546,7 +550,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
             d.n_imu = (P->variant == VBA_VARIANT_SE3_XYZ) ? 0 : P->n_imu;
             d.pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15;
             d.np = d.pdim * d.n_free;
-            d.nS = ((d.np + VBA_NB - 1) / VBA_NB) * VBA_NB;
+            d.nS = sts[w - chunk0].nS;           // (the order decides: the two-sided order pads each of its parts to a tile boundary)
             d.nb = d.nS / VBA_NB;
             d.its[0] = P->its_stage1; d.its[1] = P->its_stage2;
             d.kf0 = kf0; d.pt0 = pt0; d.obs0 = obs0; d.imu0 = imu0;
@@ -591,9 +595,21 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
             tlpair.insert(tlpair.end(), st.tpairs.begin(), st.tpairs.end());
             tlpan.insert(tlpan.end(), st.pan.begin(), st.pan.end());
             d.order = st.order;
+            d.vp_h = 2147483647; d.vp_vb1 = 0;
+            for (int q = 0; q < 3; q++) { d.pad0[q] = 0; d.padn[q] = 0; }
+            d.pad0[0] = d.np; d.padn[0] = d.nS - d.np;
             if (d.pdim != 15) { d.vp_pr0 = 0; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 0; }
+            else if (d.order == 2) {
+                int hh, baseB, pr0;
+                vba_host::two_sided_layout(d.n_free, hh, baseB, pr0);
+                d.vp_pr0 = pr0; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 9; d.vp_h = hh; d.vp_vb1 = baseB + 9 * (d.n_free - 1);
+                d.pad0[0] = 9 * hh; d.padn[0] = baseB - 9 * hh;
+                d.pad0[1] = baseB + 9 * (d.n_free - hh); d.padn[1] = pr0 - d.pad0[1];
+                d.pad0[2] = pr0 + 6 * d.n_free; d.padn[2] = d.nS - d.pad0[2];
+            }
             else if (d.order) { d.vp_pr0 = 0; d.vp_prs = 15; d.vp_vb0 = 6; d.vp_vbs = 15; }
             else { d.vp_pr0 = 9 * d.n_free; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 9; }
+            d.nc_split = (chain_on && st.nc > 0) ? st.nc_split : 0;
             d.tl_kb0 = (int)tlkb.size(); d.tl_k0 = (int)tlk.size();
             tlkb.insert(tlkb.end(), st.kl_begin.begin(), st.kl_begin.end());
             tlk.insert(tlk.end(), st.klist.begin(), st.klist.end());
@@ -613,7 +629,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
             h->tile_updates += (double)st.tpairs.size();
             h->win_tiles[w] = (int)st.tpairs.size();
             if (n == 1) h->one_sb = st.step_begin;
-            h->win_prod_order[2 * (size_t)w] = st.prod_order[0]; h->win_prod_order[2 * (size_t)w + 1] = st.prod_order[1];
+            for (int q = 0; q < 3; q++) h->win_prod_order[3 * (size_t)w + q] = st.prod_order[q];
             if ((int)st.pair_a.size() != d.n_pairs || (int)st.off_pair.size() != d.n_pairs || (int)st.pair_mask.size() != d.n_pairs ||
                 (int)st.pimu_begin.size() != d.n_pairs + 1 || st.lmask.size() != (size_t)d.n_pt * st.mwords)
                 return fail(h, "internal: structure sizes");
@@ -786,8 +802,13 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     if (use_left_looking(h, n) || pcg) HIPCHK(h, hipMemsetAsync(h->buf[BUF_S].p, 0, S_tot * 8, h->up_stream));
     for (int w = 0; w < n && !(use_left_looking(h, n) || pcg); w++) {  // only the pad rows of S must be zero (identity on their diagonal, below)
         const WinDesc& d = h->desc[w];
-        if (d.nS > d.np)
-            HIPCHK(h, hipMemsetAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)d.np * d.nS, 0, (size_t)(d.nS - d.np) * d.nS * 8, h->up_stream));
+        if (d.order == 2) {   // pads between the parts: their COLUMNS run through tiles of the factor too -- zero the whole block once
+            HIPCHK(h, hipMemsetAsync(dp<double>(h, BUF_S) + d.S0, 0, (size_t)d.nS * d.nS * 8, h->up_stream));
+            continue;
+        }
+        for (int q = 0; q < 3; q++)
+            if (d.padn[q] > 0)
+                HIPCHK(h, hipMemsetAsync(dp<double>(h, BUF_S) + d.S0 + (size_t)d.pad0[q] * d.nS, 0, (size_t)d.padn[q] * d.nS * 8, h->up_stream));
     }
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_VEC].p, 0, (size_t)vec0 * 8, h->up_stream));
     HIPCHK(h, hipMemsetAsync(h->buf[BUF_YV].p, 0, (size_t)vec0 * 8, h->up_stream));
@@ -1816,12 +1837,12 @@ int vba_debug_copy(void* handle, int32_t buf_id, uint64_t offset_bytes, void* ds
     return hipMemcpy(dst, reinterpret_cast<char*>(b.ptr()) + offset_bytes, nbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 // diagnostic (bench.py --workload c3s): tile products of window w's symbolic factorisation under both elimination orders and the
-// order chosen: out = {V/Bias-first, keyframe by keyframe, chosen order, products of the chosen lists}
+// order chosen: out[5] = {V/Bias-first, keyframe by keyframe, chosen order, products of the chosen lists, two-sided V/Bias-first}
 int vba_debug_tile_products(void* handle, int32_t w, int64_t* out) {
     Handle* h = reinterpret_cast<Handle*>(handle);
     if (!h || !out || w < 0 || w >= h->n_win || (size_t)w >= h->win_tiles.size()) return -1;
-    out[0] = h->win_prod_order[2 * (size_t)w]; out[1] = h->win_prod_order[2 * (size_t)w + 1];
-    out[2] = h->desc[w].order; out[3] = h->win_tiles[w];
+    out[0] = h->win_prod_order[3 * (size_t)w]; out[1] = h->win_prod_order[3 * (size_t)w + 1];
+    out[2] = h->desc[w].order; out[3] = h->win_tiles[w]; out[4] = h->win_prod_order[3 * (size_t)w + 2];
     return 0;
 }
 int vba_debug_set_streams(void* handle, int32_t n) {

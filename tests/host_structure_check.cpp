@@ -16,9 +16,13 @@ int main(int argc, char** argv) {
         vba_problem* P = nullptr;
         const int rc = vba_problem_load(argv[a], &P);
         if (rc) { printf("error load %d\n", rc); continue; }
+        // twice: with the orders 0 / 1 only, then with the two-sided order as a candidate (what the library asks for); the second is printed
+        bool ok_all = true, failed = false;
         vba_host::Structure st;
         std::string err;
-        if (vba_host::build_structure(P, st, err)) { printf("error %s\n", err.c_str()); vba_problem_free(P); continue; }
+        for (int two = 0; two < 2 && !failed; two++) {
+        st = vba_host::Structure();
+        if (vba_host::build_structure(P, st, err, two != 0)) { printf("error %s\n", err.c_str()); failed = true; break; }
         long long mask_bits = 0;
         for (unsigned long long m : st.lmask) mask_bits += __builtin_popcountll(m);
         const int nf = P->n_kf_free, npairs = nf * (nf + 1) / 2;
@@ -77,9 +81,27 @@ int main(int argc, char** argv) {
                 for (int e = st.cu[q + 1]; e < st.cu[q + 2]; e++) ok = ok && st.klist[e] < st.nc;
             }
         }
-        printf("%s order %d mwords %d item_cap %lld mask_bits %lld tiles %zu klist %zu pimu %zu pan %zu nc %d h_tiles %llx h_mask %llx\n", ok ? "ok" : "error inconsistent",
-               st.order, st.mwords, st.item_cap, mask_bits, st.tpairs.size(), st.klist.size(), st.pimu.size() / 2, st.pan.size(), st.nc,
+        {   // the positions of the variables under the chosen order: distinct, inside the rows the structure reports
+            const int pdim = (P->variant == VBA_VARIANT_SE3_XYZ) ? 6 : 15, nb = (int)st.step_begin.size() - 1;
+            ok = ok && st.nS == nb * VBA_NB && (two || st.order != 2) && vba_host::order_rows(st.order, pdim, nf) <= st.nS;
+            std::vector<char> seen((size_t)std::max(st.nS, 1), 0);
+            for (int k = 0; k < nf && ok; k++)
+                for (int r = 0; r < pdim && ok; r++) {
+                    const int v = vba_host::vpos_host(st.order, pdim, nf, k, r);
+                    ok = ok && v >= 0 && v < st.nS && !seen[v];
+                    if (ok) seen[v] = 1;
+                }
+            // the split of the chain: no tile couples column nc_split - 1 to column nc_split
+            ok = ok && st.nc_split >= 0 && (st.nc_split == 0 || (st.nc_split < st.nc && st.chain_tab[4 * (st.nc_split - 1) + 2] == 0));
+            if (st.order == 2) ok = ok && (st.nc == 0 || st.nc_split > 0);
+        }
+        ok_all = ok_all && ok;
+        if (!two) continue;
+        ok = ok_all;
+        printf("%s order %d mwords %d item_cap %lld mask_bits %lld tiles %zu klist %zu pimu %zu pan %zu nc %d split %d h_tiles %llx h_mask %llx\n", ok ? "ok" : "error inconsistent",
+               st.order, st.mwords, st.item_cap, mask_bits, st.tpairs.size(), st.klist.size(), st.pimu.size() / 2, st.pan.size(), st.nc, st.nc_split,
                (unsigned long long)fnv(st.tpairs), (unsigned long long)fnv(st.pair_mask));
+        }
         vba_problem_free(P);
     }
     return 0;
