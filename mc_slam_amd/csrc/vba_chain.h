@@ -294,13 +294,15 @@ DEVI void chain_store_rows_perm(const double* rows, double* Lf, int n, int I, in
         *reinterpret_cast<double2*>(Lf + ((size_t)I * 32 + row) * n + (size_t)J * 32 + c) = make_double2(rows[row * 34 + p0], rows[row * 34 + p1]);
     }
 }
-__global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
-    __shared__ double CT[32 * 34];          // C_JJ rows
-    __shared__ double CI[32 * 34];          // C_IJ rows (this workgroup's tile row)
-    __shared__ double XL[2][2 * 32 * 34];   // column parity: rows of L_{J+1,J}, behind them the same rows times D_J (permuted columns)
-    __shared__ double XI[2 * 32 * 34];      // rows of L_IJ (and times D_J: not used)
+__global__ void __launch_bounds__(512) k_chol_chain_rows(Batch B) {
+    // one set per chain (the two-sided order, WinDesc::nc_split: the workgroup's two halves walk the two chains side by side)
+    __shared__ double CTs[2][32 * 34];      // C_JJ rows
+    __shared__ double CIs[2][32 * 34];      // C_IJ rows (this workgroup's tile row)
+    __shared__ double XLs[2][2 * 32 * 34];  // rows of L_{J+1,J}, behind them the same rows times D_J (permuted columns)
+    __shared__ double XIs[2][2 * 32 * 34];  // rows of L_IJ (and times D_J: not used)
     __shared__ double XD[2 * 32 * 34];      // where the diagonal lanes' per-pivot stores go (never read)
-    __shared__ double rcar[32];             // the rhs of the current diagonal tile's rows (wave 0 -> wave 1)
+    __shared__ double rcars[2][32];         // the rhs of the current diagonal tile's rows (wave 0 -> wave 1)
+    __shared__ double rpart[32];            // the second chain's share of b_I - sum_J L_IJ z_J
     __shared__ short lride[CHAIN_MAX_NC], lpres[CHAIN_MAX_NC];
     const int w = blockIdx.y;
     const WinDesc& d = B.desc[w];
@@ -312,30 +314,44 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
     if (I >= d.nb && qrow > 0) return;
     const bool owner = qrow == 0;                   // workgroup 0 writes the chain's own tiles (and carries row nc, if the chain fills it)
     const int n = d.nS;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5, l15 = lane & 15, l4 = lane >> 4;
+    // 512 threads: hardware waves 0..3 are the four eliminating waves (chain 0: waves 0 and 1, chain 1: waves 0 and 1), one per SIMD;
+    // hardware waves 4..7 the waves 2 and 3 of the two chains
+    const int hw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: roles and LDS bases in scalar registers)
+    const bool two = blockDim.x == 512;
+    const int half = two ? ((hw >> 1) & 1) : 0, wave = two ? ((hw & 1) | ((hw >> 2) << 1)) : hw;
+    const int lane = threadIdx.x & 63, r = lane & 31, hi = lane >> 5, l15 = lane & 15, l4 = lane >> 4, tid = 64 * wave + lane;
+    const int split = (two && d.nc_split > 0) ? d.nc_split : (two ? nc : 0);   // (256 threads: one walk over all chain columns)
+    const int J0 = half ? split : 0, J1 = (two && !half) ? split : nc;
+    const int rounds = two ? max(split, nc - split) : nc;
+    double* CT = CTs[half];
+    double* CI = CIs[half];
+    double* XL = XLs[half];
+    double* XI = XIs[half];
+    double* rcar = rcars[half];
     double* S = B.S + d.S0;
     double* Lf = B.Lf + d.S0;
     const double* vec = B.vec + d.vec0;
     double* yv = B.yv + d.vec0;
     double* dvec = B.dvec + d.vec0;
 #ifdef VBA_STAMPS
-#define RSTAMP(i) { if (w == 0 && qrow == 1 && lane == 0 && wave < 2 && J < 20) B.dbg[64 + (wave ? 192 : 0) + 8 * J + (i)] = (double)__builtin_amdgcn_s_memtime(); }
+#define RSTAMP(i) { if (w == 0 && qrow == 1 && lane == 0 && wave < 2 && half == 0 && J < 20) B.dbg[64 + (wave ? 192 : 0) + 8 * J + (i)] = (double)__builtin_amdgcn_s_memtime(); }
     if (w == 0 && qrow == 1 && threadIdx.x == 0) B.dbg[60] = (double)__builtin_amdgcn_s_memtime();
 #else
 #define RSTAMP(i)
 #endif
     // the first tiles are requested before anything is known about the row (a row the chain never fills costs one wasted fetch)
+    const bool live = J0 < J1;
     double c0[4], ci0[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        const int q = threadIdx.x + 256 * u;
-        c0[u] = S[(size_t)(q >> 5) * n + (q & 31)];
-        ci0[u] = (I < d.nb) ? S[((size_t)I * 32 + (q >> 5)) * n + (q & 31)] : 0.0;
+        const int q = tid + 256 * u;
+        c0[u] = live ? S[((size_t)J0 * 32 + (q >> 5)) * n + (size_t)J0 * 32 + (q & 31)] : 0.0;
+        ci0[u] = (live && I < d.nb) ? S[((size_t)I * 32 + (q >> 5)) * n + (size_t)J0 * 32 + (q & 31)] : 0.0;
     }
     int any = 0;
     {
         const int4* ct = reinterpret_cast<const int4*>(B.tl_ct) + d.ct0;
-        for (int J = threadIdx.x; J < nc; J += 256) {
+        for (int J = threadIdx.x; J < nc; J += blockDim.x) {
             const int4 e = ct[J];
             const unsigned long long mask = ((unsigned long long)(unsigned)e.y << 32) | (unsigned)e.x;
             const int pres = (qrow < 64 && I < d.nb) ? (int)((mask >> qrow) & 1ull) : 0;
@@ -346,19 +362,21 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
     }
     any = __syncthreads_or(any);
     if (!any && !owner) return;                     // the chain never fills this tile row
+    if (live) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int q = threadIdx.x + 256 * u;
-        CT[(q >> 5) * 34 + (q & 31)] = c0[u];
-        CI[(q >> 5) * 34 + (q & 31)] = lpres[0] ? ci0[u] : 0.0;
+        for (int u = 0; u < 4; u++) {
+            const int q = tid + 256 * u;
+            CT[(q >> 5) * 34 + (q & 31)] = c0[u];
+            CI[(q >> 5) * 34 + (q & 31)] = lpres[J0] ? ci0[u] : 0.0;
+        }
     }
     double t[32], rr = 0.0, rr_carry = 0.0;
-    // wave 1: the right-hand side rows of tile I ride through every column (b_I -= L_IJ z_J)
-    double rr_I = (wave == 1 && hi && I < d.nb) ? vec[(size_t)I * 32 + r] : 0.0;
-    if (wave == 0 && !hi) rcar[r] = vec[r];
+    // wave 1: the right-hand side rows of tile I ride through every column (b_I -= L_IJ z_J); the second chain collects its share from 0
+    double rr_I = (wave == 1 && hi && I < d.nb && !half) ? vec[(size_t)I * 32 + r] : 0.0;
+    if (wave == 0 && !hi && live) rcar[r] = vec[(size_t)J0 * 32 + r];
     // wave 0: the rows of tile (J+1, J) and the rhs rows of tile J+1 are requested a phase early (the chain never modifies S)
-    const double* ride_row = S + ((size_t)32 + r) * n;      // row r of tile (1, 0); + 32 n + 32 per column
-    const double* ride_rhs = vec + 32 + r;
+    const double* ride_row = S + ((size_t)32 * (J0 + 1) + r) * n + (size_t)32 * J0;      // row r of tile (J0+1, J0); + 32 n + 32 per column
+    const double* ride_rhs = vec + (size_t)32 * (J0 + 1) + r;
     auto prefetch_ride = [&](int J) {
         const bool rd = hi && lride[J];
         const double4* row = reinterpret_cast<const double4*>(ride_row);
@@ -368,11 +386,11 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
             if (rd) v = row[q];
             t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
         }
-        rr = (hi && J + 1 < nc) ? *ride_rhs : 0.0;
+        rr = (hi && J + 1 < J1) ? *ride_rhs : 0.0;
         ride_row += (size_t)32 * n + 32;
         ride_rhs += 32;
     };
-    if (wave == 0) prefetch_ride(0);
+    if (wave == 0 && live) prefetch_ride(J0);
     // the quadrant products of phase F: wave 0: diagonal (0,0), (1,0); wave 1: diagonal (1,1), row (0,0); wave 2: row (0,1), (1,0);
     // wave 3: row (1,1).  Per wave and product: source quadrant of S (a pointer that moves one tile per column), operand rows, target.
     bool q_on[2], q_row[2];
@@ -385,7 +403,7 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
         const int id = id0 < 0 ? 0 : id0;
         q_row[u] = id >= 4;
         const int ti = q_row[u] ? ((id - 4) >> 1) : (id >> 1), tj = q_row[u] ? ((id - 4) & 1) : (id & 1);
-        q_src[u] = S + ((size_t)(q_row[u] ? I : 1) * 32 + 16 * ti + l4) * n + 32 + 16 * tj + l15;   // tile (1,1) / (I,1)
+        q_src[u] = S + ((size_t)(q_row[u] ? I : J0 + 1) * 32 + 16 * ti + l4) * n + (size_t)32 * (J0 + 1) + 16 * tj + l15;   // tile (J0+1,J0+1) / (I,J0+1)
         q_a[u] = (16 * ti + l15) * 34 + l4 * 8;
         q_b[u] = (16 * tj + l15) * 34 + l4 * 8 + ELIM_U_OFF;
         q_dst[u] = (16 * ti + l4) * 34 + 16 * tj + l15;
@@ -397,7 +415,7 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
     // the quadrants of S a wave updates in phase F are requested a column ahead (at the end of the previous column's phase F)
     d4_t ca[2];
     auto fetch_quadrants = [&](int J) {   // for the products of column J: tiles (J+1, J+1) and (I, J+1)
-        const bool up = J + 1 < nc, pn = up && lpres[J + 1] != 0;
+        const bool up = J + 1 < J1, pn = up && lpres[J + 1] != 0;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const bool on = q_on[u] && (q_row[u] ? pn : up);
@@ -406,15 +424,16 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
             q_src[u] += q_row[u] ? 32 : (size_t)32 * n + 32;
         }
     };
-    fetch_quadrants(0);
-    for (int J = 0; J < nc; J++) {
-        const bool ride = lride[J] != 0, pres = lpres[J] != 0;
-        const bool upd = J + 1 < nc, presn = upd && lpres[J + 1] != 0;
-        const int cur = J & 1;
+    if (live) fetch_quadrants(J0);
+    for (int it = 0; it < rounds; it++) {
+        const int J = J0 + it;
+        const bool act = J < J1;                    // (the shorter chain keeps the barriers of the longer one company)
+        const bool ride = act && lride[J] != 0, pres = act && lpres[J] != 0;
+        const bool upd = J + 1 < J1, presn = upd && lpres[J + 1] != 0;
         const size_t dk = (size_t)J * 32;
         // ---------------------------------------------------------------- phase E: the two eliminations
         RSTAMP(0)
-        if (wave == 0 || (wave == 1 && pres)) {
+        if (act && (wave == 0 || (wave == 1 && pres))) {
             if (!hi) {
 #pragma unroll
                 for (int q = 0; q < 32; q++) t[q] = CT[r * 34 + q];
@@ -426,7 +445,7 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
             }
             double dout = 1.0, zout = 0.0;
             RSTAMP(1)
-            elim_tile<2>(t, rr, dout, zout, 4 * l15, 4 * (16 + l15), (hi ? (wave ? XI : XL[cur]) : XD) + r * 34);
+            elim_tile<2>(t, rr, dout, zout, 4 * l15, 4 * (16 + l15), (hi ? (wave ? XI : XL) : XD) + r * 34);
             RSTAMP(2)
             if (wave == 0) {
                 if (owner) {
@@ -454,13 +473,14 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
         lds_barrier();   // A: L_{J+1,J} (and times D_J) and L_IJ are in LDS
         RSTAMP(4)
         // ---------------------------------------------------------------- phase F: the tiles of the next column
+        if (act) {
         if (wave == 0 && !hi) rcar[r] = rr_carry;   // (wave 1 read the old values in front of its elimination)
         {
             double2 xa[2][4], xb[2][4];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const double* XA = (q_row[u] ? XI : XL[cur]) + q_a[u];
-                const double* XB = XL[cur] + q_b[u];
+                const double* XA = (q_row[u] ? XI : XL) + q_a[u];
+                const double* XB = XL + q_b[u];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     xa[u][q] = *reinterpret_cast<const double2*>(XA + 2 * q);
@@ -468,7 +488,7 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
                 }
             }
 #ifdef VBA_STAMPS
-#define FSTAMP(i) { if (w == 0 && qrow == 1 && lane == 0 && wave == 1 && J < 15) B.dbg[448 + 4 * J + (i)] = (double)__builtin_amdgcn_s_memtime(); }
+#define FSTAMP(i) { if (w == 0 && qrow == 1 && lane == 0 && wave == 1 && half == 0 && J < 15) B.dbg[448 + 4 * J + (i)] = (double)__builtin_amdgcn_s_memtime(); }
             { double sink = xa[0][0].x + xa[1][3].y + xb[0][0].x + xb[1][3].y; asm volatile("" :: "v"(sink)); }
             FSTAMP(0)
             { double sink = ca[0][0] + ca[1][3]; asm volatile("" :: "v"(sink)); }
@@ -514,15 +534,27 @@ __global__ void __launch_bounds__(256) k_chol_chain_rows(Batch B) {
         RSTAMP(7)
         if (wave == 3) {
             if (pres) chain_store_rows_perm(XI, Lf, n, I, J, lane);
-            if (owner && ride) chain_store_rows_perm(XL[cur], Lf, n, J + 1, J, lane);
+            if (owner && ride) chain_store_rows_perm(XL, Lf, n, J + 1, J, lane);
         }
         if (upd) fetch_quadrants(J + 1);
-        if (wave == 0 && upd) prefetch_ride(J + 1);
+        }
+        if (act && wave == 0 && upd) prefetch_ride(J + 1);
+        else {   // (defined on every path: the 64 registers of t are free during phase F)
+#pragma unroll
+            for (int q = 0; q < 32; q++) t[q] = 0.0;
+            rr = 0.0;
+        }
         RSTAMP(5)
-        lds_barrier();   // B: C_{J+1,J+1} and C_{I,J+1} are in LDS
+        lds_barrier();   // B: C_{J+1,J+1} and C_{I,J+1} are in LDS (and every read of this column's L rows is done)
         RSTAMP(6)
     }
-    if (wave == 1 && hi && any) (B.vec + d.vec0)[(size_t)I * 32 + r] = rr_I;   // b_I - sum_J L_IJ z_J: the forward substitution of the row
+    if (!any) return;
+    if (two) {   // b_I - sum_J L_IJ z_J: the forward substitution of the row, the shares of the two chains added up
+        if (half && wave == 1 && hi) rpart[r] = rr_I;
+        __syncthreads();
+        if (!half && wave == 1 && hi) (B.vec + d.vec0)[(size_t)I * 32 + r] = rr_I + rpart[r];
+    } else if (wave == 1 && hi)
+        (B.vec + d.vec0)[(size_t)I * 32 + r] = rr_I;
 }
 
 // Few-window regime: S_IJ -= sum_{k < nc} L_Ik D_k L_Jk^T for the tiles (I,J), J >= nc, that collect updates from chain columns (the

@@ -245,6 +245,14 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
     auto symbolic = [&](int order, bool lists) -> long long {
     const int np = order_rows(order, pdim, nf), nS = ((np + VBA_NB - 1) / VBA_NB) * VBA_NB, nb = nS / VBA_NB;
     st.nS = nS;
+    // first and last tile of a keyframe's PR run (sub-block 0) and of its V/Bias run (sub-block 1) under this order
+    std::vector<int> trun((size_t)4 * nf);
+    for (int a = 0; a < nf; a++) {
+        trun[4 * a] = vpos_host(order, pdim, nf, a, 0) / VBA_NB;
+        trun[4 * a + 1] = vpos_host(order, pdim, nf, a, 5) / VBA_NB;
+        trun[4 * a + 2] = pdim == 15 ? vpos_host(order, pdim, nf, a, 6) / VBA_NB : 0;
+        trun[4 * a + 3] = pdim == 15 ? vpos_host(order, pdim, nf, a, 14) / VBA_NB : 0;
+    }
     st.tpairs.clear(); st.pan.clear();
     std::vector<unsigned char> T((size_t)nb * nb, 0);
     for (int i = 0; i < nb; i++) T[(size_t)i * nb + i] = 1;
@@ -257,9 +265,8 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
         const int nsub = ((imu || a == b) && pdim == 15) ? 2 : 1;
         for (int sr = 0; sr < nsub; sr++)
             for (int sc = 0; sc < nsub; sc++) {
-                const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
-                const int ti0 = vpos_host(order, pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(order, pdim, nf, a, r1) / VBA_NB;
-                const int tj0 = vpos_host(order, pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(order, pdim, nf, b, c1) / VBA_NB;
+                const int ti0 = trun[4 * a + 2 * sr], ti1 = trun[4 * a + 2 * sr + 1];
+                const int tj0 = trun[4 * b + 2 * sc], tj1 = trun[4 * b + 2 * sc + 1];
                 for (int ti = ti0; ti <= ti1; ti++)
                     for (int tj = tj0; tj <= tj1; tj++) T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)] = 1;
             }
@@ -351,9 +358,8 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
         const int nsub = (pdim == 15) ? 2 : 1;
         for (int sr = 0; sr < nsub; sr++)
             for (int sc = 0; sc < nsub; sc++) {
-                const int r0 = sr ? 6 : 0, r1 = sr ? 14 : 5, c0 = sc ? 6 : 0, c1 = sc ? 14 : 5;
-                const int ti0 = vpos_host(order, pdim, nf, a, r0) / VBA_NB, ti1 = vpos_host(order, pdim, nf, a, r1) / VBA_NB;
-                const int tj0 = vpos_host(order, pdim, nf, b, c0) / VBA_NB, tj1 = vpos_host(order, pdim, nf, b, c1) / VBA_NB;
+                const int ti0 = trun[4 * a + 2 * sr], ti1 = trun[4 * a + 2 * sr + 1];
+                const int tj0 = trun[4 * b + 2 * sc], tj1 = trun[4 * b + 2 * sc + 1];
                 bool any = false;
                 for (int ti = ti0; ti <= ti1; ti++)
                     for (int tj = tj0; tj <= tj1; tj++) any = any || T[(size_t)std::max(ti, tj) * nb + std::min(ti, tj)];

@@ -205,7 +205,7 @@ struct Handle {
     int max_pt_blk = 0, max_imu = 0, max_pairs = 0, max_nb = 0, max_obs_blk = 0, max_kf_blk = 0, max_ns_blk = 0;
     int max_nS = 0, max_its[2] = {0, 0}, max_free = 0, max_lin_blk = 0, max_quads = 1, max_offp = 1, max_pan = 0;
     size_t chain_lds = 0;   // dynamic LDS of k_chol_chain (its per-column tile tables)
-    int min_nc = 0, max_nc = 0, max_cu = 0, max_chain_rows = 0;   // chain columns of the batch's windows (k_chol_chain); tiles of its update launch
+    int min_nc = 0, max_nc = 0, max_cu = 0, max_chain_rows = 0, max_split = 0;   // chain columns of the batch's windows (k_chol_chain); tiles of its update launch
     std::vector<int> step_grid;  // workgroups per factorisation step (max over the batch)
     std::vector<int> pan_grid;   // panel tiles per step (max over the batch)
     double tile_updates = 0;     // tile-pair updates per factorisation, summed over the batch
@@ -428,7 +428,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     h->max_pt_blk = h->max_imu = h->max_pairs = h->max_nb = h->max_obs_blk = h->max_kf_blk = h->max_ns_blk = h->max_nS = 0;
     h->max_its[0] = h->max_its[1] = 0;
     h->any_lin_fallback = false;
-    h->min_nc = 1 << 30; h->max_nc = 0; h->max_cu = 0; h->chain_lds = 0; h->max_chain_rows = 0;
+    h->min_nc = 1 << 30; h->max_nc = 0; h->max_cu = 0; h->chain_lds = 0; h->max_chain_rows = 0; h->max_split = 0;
     // Chain columns in one launch (vba_chain.h): in the left-looking regime (two lean launches for all chain columns of all windows),
     // and for a handful of windows (one workgroup per tile row walks the chain; measured on MI355X: one window 2.85 ms against 2.89,
     // 64 windows 9.5 ms per run against 8.0 -- every row workgroup redoes the chain's diagonal work, which is only free while compute
@@ -610,6 +610,7 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
             else if (d.order) { d.vp_pr0 = 0; d.vp_prs = 15; d.vp_vb0 = 6; d.vp_vbs = 15; }
             else { d.vp_pr0 = 9 * d.n_free; d.vp_prs = 6; d.vp_vb0 = 0; d.vp_vbs = 9; }
             d.nc_split = (chain_on && st.nc > 0) ? st.nc_split : 0;
+            h->max_split = std::max(h->max_split, d.nc_split);
             d.tl_kb0 = (int)tlkb.size(); d.tl_k0 = (int)tlk.size();
             tlkb.insert(tlkb.end(), st.kl_begin.begin(), st.kl_begin.end());
             tlk.insert(tlk.end(), st.klist.begin(), st.klist.end());
@@ -1008,7 +1009,7 @@ void enqueue_solve_iteration(Handle* h, StopRef stop_flag = StopRef()) {
                 if (h->max_chain_rows > 0) VBA_LAUNCH(k_chol_chain_panel, dim3(h->max_chain_rows * ngrp), dim3(64), 0, h->stream, B, h->max_chain_rows);
             }
             else {
-                VBA_LAUNCH(k_chol_chain_rows, dim3(std::max(1, h->max_chain_rows), n), dim3(256), 0, h->stream, B);
+                VBA_LAUNCH(k_chol_chain_rows, dim3(std::max(1, h->max_chain_rows), n), dim3(h->max_split > 0 ? 512 : 256), 0, h->stream, B);   // (two chains: two halves)
                 if (h->max_cu > 0) VBA_LAUNCH(k_chol_chain_upd, dim3(h->max_cu, n), dim3(512), 0, h->stream, B);
             }
         }

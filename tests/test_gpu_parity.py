@@ -577,6 +577,56 @@ def test_chain_columns_in_one_launch_agree_with_one_launch_per_column(ba, oracle
                     assert (qb.kf_pose == q.kf_pose).all() and rb.chi2_vis == r.chi2_vis
 
 
+def test_two_sided_vbias_order_agrees_with_the_one_sided_order(ba, oracle, monkeypatch):
+    """Order 2 (vba_host_structure.h): the V/Bias blocks as two chains that meet in the middle, pads between the parts of the reduced
+    system.  Fewer tile products than order 0 on every full-size window, and k_chol_chain_rows walks the two chains side by side (512
+    threads).  Against the oracle and against order 0 / 1 (VBA_ONE_CHAIN, read at every upload) to rounding, in both regimes: full-size
+    ragged C3 windows, a window of 13 keyframes (the smallest the order is offered to have 12 free keyframes), a window whose IMU chain is
+    broken next to the split, and a ragged five-window call (chains of different lengths and splits in one launch)."""
+    ps = [synth.config_c3_ragged(100 + s) for s in (1, 2, 5, 7, 9)]
+    ps.append(synth.config_c3(seed=12, n_kf=13, n_pt=600, n_obs=3600))
+    broken = synth.config_c3(seed=11, n_kf=30, n_pt=1500, n_obs=9000).copy()
+    keep = np.array([k for k in range(broken.n_imu) if k != broken.n_imu // 2 - 1])
+    broken.imu_kf_i, broken.imu_kf_j = broken.imu_kf_i[keep].copy(), broken.imu_kf_j[keep].copy()
+    broken.imu_meas, broken.imu_info_prv = broken.imu_meas[keep].copy(), broken.imu_info_prv[keep].copy()
+    ps.append(broken)
+    res, orders = {}, {}
+    try:
+        for ll in (0, 1):
+            ba.lib.vba_debug_set_ll_min(ba.h, 1 if ll else 0)
+            for one in (0, 1):
+                if one: monkeypatch.setenv("VBA_ONE_CHAIN", "1")
+                else: monkeypatch.delenv("VBA_ONE_CHAIN", raising=False)
+                single = [ba.solve(p) for p in ps]
+                ba.upload(ps[:5])
+                tp = np.zeros((5, 5), dtype=np.int64)
+                for i in range(5):
+                    assert ba.lib.vba_debug_tile_products(ba.h, i, tp[i].ctypes.data_as(C.c_void_p)) == 0
+                orders[ll, one] = tp
+                ba.run(); qs, rs = ba.download()
+                res[ll, one] = (single, list(zip(qs, rs)))
+    finally:
+        monkeypatch.delenv("VBA_ONE_CHAIN", raising=False)
+        ba.lib.vba_debug_set_ll_min(ba.h, 0)
+    for ll in (0, 1):
+        tp2, tp1 = orders[ll, 0], orders[ll, 1]
+        assert (tp1[:, 2] != 2).all() and (tp1[:, 4] == -1).all()          # the switch keeps order 2 out
+        assert (tp2[:, 2] == 2).sum() >= 3 and (tp2[:, 4] > 0).all()       # offered to every window, taken by most
+        assert (tp2[tp2[:, 2] == 2, 4] < tp2[tp2[:, 2] == 2, 0]).all()     # ... where it has fewer tile products than order 0
+    for i, p in enumerate(ps):
+        qo, ro = oracle.solve(p)
+        for ll in (0, 1):
+            (q, r), (q1, r1) = res[ll, 0][0][i], res[ll, 1][0][i]
+            _check(p, q, r, qo, ro)
+            _check(p, q1, r1, qo, ro)
+            assert r.its_done == r1.its_done and (r.obs_outlier == r1.obs_outlier).all()
+            np.testing.assert_allclose(r.chi2_trace, r1.chi2_trace, rtol=1e-8)
+            assert np.abs(q.kf_pose - q1.kf_pose).max() < 1e-8
+            if i < 5:
+                qb, rb = res[ll, 0][1][i]
+                _check(p, qb, rb, qo, ro)
+
+
 def test_left_looking_kernels_at_full_window_size(ba, oracle):
     """The left-looking factorisation (tile-packed factor, operands loaded straight into the MFMA registers) is what batches of
     >= 256 windows run; here it is forced on full-size ragged C3 windows (40..60 keyframes: 19..28 block columns) and on a
