@@ -373,13 +373,18 @@ inline int build_structure(const vba_problem* P, Structure& st, std::string& err
     static const int env_order = getenv("VBA_ORDER") ? atoi(getenv("VBA_ORDER")) : -1;
     st.order = 0;
     if (pdim == 15) {
-        if (env_order >= 0) st.order = std::min(env_order, 2);
+        if (env_order >= 0) st.order = (env_order >= 2 && (nf < 4 || P->solver == VBA_SOLVER_PCG)) ? 0 : std::min(env_order, 2);   // (PCG walks keyframe-pair blocks: orders 0 / 1)
         else {
             const long long c0 = symbolic(0, false), c1 = symbolic(1, false);
             const long long c2 = (prefer_two_sided && nf >= 12 && P->solver != VBA_SOLVER_PCG) ? symbolic(2, false) : -1;
             st.prod_order[0] = c0; st.prod_order[1] = c1; st.prod_order[2] = c2;
             const long long cv = (c2 >= 0 && c2 < c0) ? c2 : c0;   // the better V/Bias-first variant
-            st.order = (10 * c1 < 7 * cv) ? 1 : (cv == c0 ? 0 : 2);  // keyframe order only on a clear win: a batch that mixes patterns pays for each
+            // keyframe order only on a clear win for a local window (a batch that mixes patterns pays for each, and the chain kernels make
+            // a V/Bias-first tile product cheaper); for a map (> 64 keyframes: a chain of dozens of block columns walked in sequence,
+            // few windows per call) the fewer products decide -- C4, two kinds of graph (products 8.1 k keyframe order, 14.6 k two-sided):
+            // all keyframe order 839 solves/s, all two-sided 827, one kind each 798
+            const bool kf_order = (nf > 64) ? (c1 < cv) : (10 * c1 < 7 * cv);
+            st.order = kf_order ? 1 : (cv == c0 ? 0 : 2);
             if (timing) fprintf(stderr, "[vba] tile products of the factorisation: V/Bias-first %lld, keyframe order %lld, two-sided %lld\n", c0, c1, c2);
         }
     }

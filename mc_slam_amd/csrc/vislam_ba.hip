@@ -430,10 +430,12 @@ int do_upload(Handle* h, int n, vba_problem* const* probs, bool defer_sync = fal
     h->any_lin_fallback = false;
     h->min_nc = 1 << 30; h->max_nc = 0; h->max_cu = 0; h->chain_lds = 0; h->max_chain_rows = 0; h->max_split = 0;
     // Chain columns in one launch (vba_chain.h): in the left-looking regime (two lean launches for all chain columns of all windows),
-    // and for a handful of windows (one workgroup per tile row walks the chain; measured on MI355X: one window 2.85 ms against 2.89,
-    // 64 windows 9.5 ms per run against 8.0 -- every row workgroup redoes the chain's diagonal work, which is only free while compute
-    // units idle).  In between: one launch per block column.  VBA_NO_CHAIN: A/B switch, one launch per block column everywhere.
-    static const int chain_rl_max = getenv("VBA_CHAIN_RL_MAX") ? atoi(getenv("VBA_CHAIN_RL_MAX")) : 7;
+    // and for up to 64 windows in the right-looking one (one workgroup per tile row walks the chain, the two chains of the two-sided
+    // order side by side).  Every row workgroup redoes the chain's diagonal work, which is only free while compute units idle --
+    // measured on MI355X, ms per run with / without: 1 window 2.11 / 2.37, 8: 2.71 / 3.06, 16: 3.16 / 3.72, 32: 4.70 / 5.10,
+    // 64: 7.44 / 7.52, 96: 10.6 / 10.0, 128: 13.4 / 12.0.  In between: one launch per block column.
+    // VBA_NO_CHAIN: A/B switch, one launch per block column everywhere.
+    static const int chain_rl_max = getenv("VBA_CHAIN_RL_MAX") ? atoi(getenv("VBA_CHAIN_RL_MAX")) : 64;
     const bool chain_on = getenv("VBA_NO_CHAIN") == nullptr && !h->opt_no_chain && (use_left_looking(h, n) || n <= chain_rl_max);
     // the two-sided V/Bias-first order (vba_host_structure.h, order 2) is a candidate for every window: its two half-length chains leave
     // half the fill in the PR rows (C3: 408 tile products against 581), and the few-window chain kernel walks them side by side.

@@ -577,6 +577,30 @@ def test_chain_columns_in_one_launch_agree_with_one_launch_per_column(ba, oracle
                     assert (qb.kf_pose == q.kf_pose).all() and rb.chi2_vis == r.chi2_vis
 
 
+def test_chain_kernels_in_a_batch_of_a_dozen_windows(ba, oracle):
+    """Up to 64 windows a right-looking batch walks its chain columns in one launch (VBA_CHAIN_RL_MAX): twelve ragged C3 windows in one
+    call -- chains of different lengths and splits, the four-pairs-per-wave Schur gather and the XCD-aware mapping of >= 8 windows --
+    against the oracle and against the same call with one launch per block column."""
+    ps = [synth.config_c3_ragged(300 + s) for s in range(12)]
+    ba.lib.vba_debug_set_chain.argtypes = [C.c_void_p, C.c_int32]
+    got = {}
+    try:
+        for chain in (1, 0):
+            ba.lib.vba_debug_set_chain(ba.h, chain)
+            ba.upload(ps); ba.run()
+            got[chain] = (ba.download(), ba.get_profile()["kernel_launches"])
+    finally:
+        ba.lib.vba_debug_set_chain(ba.h, 1)
+    assert got[0][1] - got[1][1] >= 50, (got[0][1], got[1][1])     # the chain kernels ran
+    for i, p in enumerate(ps):
+        qo, ro = oracle.solve(p)
+        q, r = got[1][0][0][i], got[1][0][1][i]
+        q0, r0 = got[0][0][0][i], got[0][0][1][i]
+        _check(p, q, r, qo, ro)
+        assert r.its_done == r0.its_done and (r.obs_outlier == r0.obs_outlier).all()
+        assert np.abs(q.kf_pose - q0.kf_pose).max() < 1e-8
+
+
 def test_two_sided_vbias_order_agrees_with_the_one_sided_order(ba, oracle, monkeypatch):
     """Order 2 (vba_host_structure.h): the V/Bias blocks as two chains that meet in the middle, pads between the parts of the reduced
     system.  Fewer tile products than order 0 on every full-size window, and k_chol_chain_rows walks the two chains side by side (512
