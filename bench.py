@@ -431,6 +431,21 @@ def main():
             tf = classes["factor"]["flops"] / (classes["factor"]["ms"] * 1e-3) / 1e12
             roofline["mfma_factor"] = {"achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "dtype": "f64"}
 
+        # what the Schur walk is actually bound by: scattered 64-byte record fetches.  Records a window's
+        # walk fetches per launch: two per item of its off-diagonal pairs (sum over landmarks of m (m + 1) / 2 for m observations + the
+        # reference record) and a slot + an edge record per observation in the diagonal pass; over the launches each window was active in.
+        if dom == "schur" and batch[0].variant == 2 and classes[dom]["ms"] > 0:
+            recs = 0.0
+            for wdw, it_w in zip(batch, its):
+                m = np.diff(wdw.pt_obs_begin).astype(np.float64)
+                recs += (2.0 * float((m * (m + 1) / 2).sum()) + 2.0 * wdw.n_obs + wdw.n_pt) * it_w
+            roofline["record_fetch"] = {"achieved": recs / (classes[dom]["ms"] * 1e-3) / 1e9, "unit": "G records/s",
+                                        "ceiling_l2_resident": 174.0, "ceiling_past_l2": 78.0,
+                                        "what": "scattered 64-byte record fetches of the Schur class per second; ceilings: scripts/gather_rate_probe.hip on MI355X "
+                                                "(profiles/round4_gather_rate_probe.txt): a lane reading a random record in three 16-byte pieces, table inside / past the XCD's L2; "
+                                                "the class time is measured with the other window groups' kernels sharing the chip (the plain gather alone on one stream: "
+                                                "184 G records/s, profiles/round4_schur_split_probe.txt)"}
+
         cpu = None
         if not args.no_cpu_baseline:
             import oracle_lib
