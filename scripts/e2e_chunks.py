@@ -1,5 +1,5 @@
 """end-to-end (vba_batch_solve) throughput with the chunking of the environment (VBA_CHUNKS / VBA_LANES / VBA_RUN_SLOTS ...):
-python scripts/e2e_chunks.py [n_windows] [distinct]"""
+python scripts/e2e_chunks.py [n_windows] [distinct] [warm-up calls]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +13,8 @@ ba = backend.LocalBA(0)
 ba.upload(batch); ba.run()
 t = time.perf_counter(); ba.run(); ba.run(); tr = (time.perf_counter() - t) / 2
 packed = ba.pack(batch)
-ba.solve_packed(packed)
+for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
+    ba.pack_reset(packed); ba.solve_packed(packed)
 ts = []
 for _ in range(4):
     ba.pack_reset(packed)
